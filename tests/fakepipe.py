@@ -1,0 +1,135 @@
+"""A weight-free stand-in for a diffusers StableDiffusionPipeline, for driving UCE() code.
+
+Used (a) by tools/make_golden.py to run the REAL reference scripts in the build container
+and (b) by the tests to run this repo's drop-in scripts on identical inputs.  It offers
+exactly the surface the reference touches:
+  pipe.unet.named_modules()            uce_sd_erase.py:17
+  pipe.encode_prompt(prompt=..., ...)  uce_sd_erase.py:29-32   -> (Tensor[1,77,d], None)
+  pipe.tokenizer(e, ...)               uce_sd_erase.py:34-39   -> {'attention_mask': [1,77]}
+  pipe.tokenizer.model_max_length      uce_sd_erase.py:36
+  pipe.to(...)                         uce_sd_erase.py:200, uce_sd_debias.py:90
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+MAX_LEN = 77
+
+
+def prompt_embedding(prompt: str, d: int, norm: float = 28.0, cosine: float = 0.64) -> np.ndarray:
+    """Deterministic CLIP-like last-token embedding for an arbitrary string: a shared
+    direction (fixed seed) + a per-string direction seeded by crc32(prompt)."""
+    ru = np.random.Generator(np.random.PCG64(20230828 + d))
+    u = ru.standard_normal(d)
+    u /= np.linalg.norm(u)
+    rz = np.random.Generator(np.random.PCG64(zlib.crc32(prompt.encode("utf-8"))))
+    z = rz.standard_normal(d)
+    z -= (z @ u) * u
+    z /= np.linalg.norm(z)
+    return (norm * (math.sqrt(cosine) * u + math.sqrt(1 - cosine) * z)).astype(np.float32)
+
+
+def token_count(prompt: str) -> int:
+    """Fake tokenisation: one token per whitespace word + BOS + EOS, truncated to 77."""
+    return min(len(prompt.split()) + 2, MAX_LEN)
+
+
+class FakeTokenizer:
+    model_max_length = MAX_LEN
+
+    def __call__(self, text, padding=None, max_length=None, truncation=None, return_tensors=None):
+        n = token_count(text)
+        mask = torch.zeros(1, MAX_LEN, dtype=torch.long)
+        mask[0, :n] = 1
+        return {"attention_mask": mask, "input_ids": mask.clone()}
+
+
+class _Node(nn.Module):
+    pass
+
+
+def build_unet(table: Sequence[Tuple[str, int]], d: int, rng: np.random.Generator,
+               decoys: bool = True) -> nn.Module:
+    """An nn.Module tree whose named_modules() yields `table`'s paths as bias-free
+    nn.Linear(d, o) with nn.Linear-default-range weights, plus decoy modules the UCE name
+    predicate must skip (attn1.*, attn2.to_q, attn2.to_out.0)."""
+    root = _Node()
+
+    def ensure(path: List[str]) -> nn.Module:
+        node = root
+        for p in path:
+            if not hasattr(node, p):
+                node.add_module(p, _Node())
+            node = getattr(node, p)
+        return node
+
+    def linear(o: int, i: int) -> nn.Linear:
+        lin = nn.Linear(i, o, bias=False)
+        bound = 1.0 / math.sqrt(i)
+        lin.weight.data = torch.from_numpy(rng.uniform(-bound, bound, size=(o, i)).astype(np.float32))
+        return lin
+
+    seen_blocks = set()
+    for name, o in table:
+        parts = name.split(".")
+        parent = ensure(parts[:-1])
+        parent.add_module(parts[-1], linear(o, d))
+        blk = ".".join(parts[:-2])
+        if decoys and blk not in seen_blocks:
+            seen_blocks.add(blk)
+            tb = ensure(parts[:-2])
+            a1 = ensure(parts[:-2] + ["attn1"])
+            a1.add_module("to_k", linear(8, 8))
+            a1.add_module("to_v", linear(8, 8))
+            a2 = ensure(parts[:-1])
+            a2.add_module("to_q", linear(8, 8))
+            a2.add_module("to_out", nn.ModuleList([linear(8, 8)]))
+    return root
+
+
+class FakePipe:
+    """encode_prompt places the string's embedding at the reference's last-token index and
+    DIFFERENT vectors at every other position, so an off-by-one index changes the result."""
+
+    def __init__(self, unet: nn.Module, d: int, embeddings: Dict[str, np.ndarray] | None = None):
+        self.unet = unet
+        self.d = d
+        self.tokenizer = FakeTokenizer()
+        self.embeddings = dict(embeddings or {})
+        rp = np.random.Generator(np.random.PCG64(77))
+        self._pos = rp.standard_normal(d).astype(np.float32)
+        self.encode_calls: List[str] = []
+
+    def embedding(self, prompt: str) -> np.ndarray:
+        if prompt not in self.embeddings:
+            self.embeddings[prompt] = prompt_embedding(prompt, self.d)
+        return self.embeddings[prompt]
+
+    def encode_prompt(self, prompt=None, device=None, num_images_per_prompt=1,
+                      do_classifier_free_guidance=False, **kw):
+        self.encode_calls.append(prompt)
+        e = torch.from_numpy(self.embedding(prompt))
+        idx = token_count(prompt) - 2
+        pos = torch.arange(MAX_LEN, dtype=torch.float32) - idx
+        t = e[None, :] + 0.5 * pos[:, None] * torch.from_numpy(self._pos)[None, :]
+        return t[None].contiguous(), None
+
+    def to(self, *a, **k):
+        return self
+
+    def set_progress_bar_config(self, **k):
+        pass
+
+
+def uce_weights(unet: nn.Module) -> List[Tuple[str, torch.Tensor]]:
+    out = []
+    for name, m in unet.named_modules():
+        if "attn2" in name and (name.endswith("to_v") or name.endswith("to_k")):
+            out.append((name, m.weight.detach().clone()))
+    return out

@@ -1,0 +1,97 @@
+"""CPU: the oracle restatement vs the reference's own outputs (golden fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+from tests.golden_io import Case, ERASE_CASES, DEBIAS_CASES, SDPA_CASES, rows
+
+
+@pytest.mark.parametrize("name", ERASE_CASES)
+def test_erase_oracle_matches_reference(name):
+    if name == "erase_n1000p500_d768":
+        torch.set_num_threads(8)
+    c = Case(name)
+    m = c.meta
+    got = O.uce_edit_ref(c.w_old(), rows(c.arr("C_edit")), rows(c.arr("G_edit")), rows(c.arr("C_pres")),
+                         m["erase_scale"], m["preserve_scale"], m["lamb"])
+    for g, ref in zip(got, c.w_ref32()):
+        # same torch ops in the same order on the same inputs: equal to fp32 rounding noise
+        assert O.rel_fro(g, ref) < 2e-6
+
+
+@pytest.mark.parametrize("name", ERASE_CASES)
+def test_erase_exact64_is_self_consistent(name):
+    c = Case(name)
+    m = c.meta
+    got = O.uce_edit_exact64(c.w_old(), rows(c.arr("C_edit")), rows(c.arr("G_edit")), rows(c.arr("C_pres")),
+                             m["erase_scale"], m["preserve_scale"], m["lamb"])
+    for g, ex, ref in zip(got, c.w_exact64(), c.w_ref32()):
+        assert O.rel_fro(g, ex) < 1e-12
+        # the reference itself sits within a few 1e-3 of the fp64 evaluation
+        assert O.rel_fro(ref, ex) < 2e-2
+
+
+@pytest.mark.parametrize("name", DEBIAS_CASES)
+def test_debias_oracle_matches_reference(name):
+    c = Case(name)
+    m = c.meta
+    ds = [x for x in c.arr("direction_scales")]
+    got = O.uce_debias_ref(c.w_old(), rows(c.arr("C_edit")), rows(c.arr("C_debias")), rows(c.arr("C_pres")),
+                           ds, m["edit_scale"], m["preserve_scale"], m["lamb"])
+    for g, ref in zip(got, c.w_ref32()):
+        assert O.rel_fro(g, ref) < 2e-6
+
+
+@pytest.mark.parametrize("name", DEBIAS_CASES)
+def test_debias_collapses_to_cumulative_drift(name):
+    """Final debias weights == the erase closed form with g_e = c_e + (sum_t D_t) C_debias."""
+    c = Case(name)
+    m = c.meta
+    ds = [x for x in c.arr("direction_scales")]
+    G = O.debias_targets(c.t("C_edit"), c.t("C_debias"), ds)
+    got = O.uce_edit_exact64(c.w_old(), rows(c.arr("C_edit")), [g[None] for g in G], rows(c.arr("C_pres")),
+                             m["edit_scale"], m["preserve_scale"], m["lamb"])
+    for g, ex, ref in zip(got, c.w_exact64(), c.w_ref32()):
+        assert O.rel_fro(g, ex) < 1e-12
+        assert O.rel_fro(ref, ex) < 5e-3
+
+
+def test_collapse_to_module_independent_M():
+    """W_new = W_old (I + Delta) with one module-independent Delta."""
+    c = Case("erase_n50_d768")
+    m = c.meta
+    C = torch.cat([c.t("C_edit"), c.t("C_pres")]).double()
+    G = torch.cat([c.t("G_edit"), c.t("C_pres")]).double()
+    s = torch.tensor([m["erase_scale"]] * len(c.arr("C_edit")) + [m["preserve_scale"]] * len(c.arr("C_pres"))).double()
+    A = m["lamb"] * torch.eye(C.shape[1], dtype=torch.float64) + C.T @ (s[:, None] * C)
+    B = (G - C).T @ (s[:, None] * C)
+    Delta = torch.linalg.solve(A, B.T).T
+    for w, ex in zip(c.w_old(), c.w_exact64()):
+        assert O.rel_fro(w.double() + w.double() @ Delta, ex) < 1e-11
+
+
+@pytest.mark.parametrize("name", SDPA_CASES)
+def test_xattn_oracle_matches_torch_sdpa(name):
+    c = Case(name)
+    m = c.meta
+    q, k, v = (c.t(x).view(torch.bfloat16) for x in ("q", "k", "v"))
+    o = O.xattn_ref(q, k, v, m["H"])
+    assert O.rel_fro(o, c.t("o_f32")) < 1e-5
+    assert O.rel_fro(c.t("o_bf16").view(torch.bfloat16).double(), o) < 1e-2
+
+
+def test_module_tables():
+    t = O.sd14_module_table()
+    assert len(t) == 32 and sum(o for _, o in t) == 24960
+    assert all(O.is_uce_module(n) for n, _ in t)
+    x = O.sdxl_module_table()
+    assert len(x) == 140 and sum(o for _, o in x) == 166400
+    assert not O.is_uce_module("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_k")
+    assert not O.is_uce_module("down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_q")
+
+
+def test_last_token_index():
+    assert O.last_token_index(2) == 0          # '' -> BOS
+    assert O.last_token_index(77) == 75        # truncated prompt
+    assert O.last_token_index(4) == 2
