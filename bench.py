@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: concepts/s of the closed-form UCE edit of ALL SD-1.4 cross-attention K/V
+projections (BASELINE.json configs[1]: erase 50 concepts, d = 768, 32 modules = one 24960 x 768
+fp32 slab), inputs resident in HBM.  One "step" = one full pass of the hot path
+(Gram -> SPD solve -> weight update for every module) = one `uce_edit` call.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The edit does not shard ("replicas only"): with N > 1 every rank edits its own
+replica and `value` is the aggregate over ranks.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak
+
+WORKLOADS = {
+    # name: (N_edit, N_preserve, d, module table)
+    "sd14_erase50": (50, 0, 768, "sd14"),
+    "sd14_erase2p3": (2, 3, 768, "sd14"),
+    "sd14_erase100": (100, 0, 768, "sd14"),
+    "sd14_erase1000p500": (1000, 500, 768, "sd14"),
+    "sdxl_debias36x2": (36, 0, 2048, "sdxl"),
+}
+
+
+def make_inputs(name: str, device):
+    from uce_amd import synth as O
+    n_e, n_p, d, table = WORKLOADS[name]
+    mods = O.sd14_module_table() if table == "sd14" else O.sdxl_module_table()
+    rows = sum(o for _, o in mods)
+    N = n_e + n_p
+    emb = O.clip_like_embeddings(N + 1, d, seed=0)
+    rng = np.random.Generator(np.random.PCG64(0))
+    bound = 1.0 / np.sqrt(d)
+    W = torch.from_numpy(rng.uniform(-bound, bound, size=(rows, d)).astype(np.float32)).to(device)
+    C = torch.from_numpy(emb[:N]).to(device)
+    G = torch.from_numpy(np.repeat(emb[N:N + 1], n_e, axis=0)).to(device)
+    s = torch.ones(N, dtype=torch.float32, device=device)
+    return dict(C=C, G=G, s=s, W=W, mods=mods, rows=rows, d=d, n_e=n_e, n_p=n_p, emb=emb)
+
+
+def cpu_baseline(inp, budget_s: float = 12.0):
+    """The oracle (the reference's own op order on torch CPU: sequential rank-1 fp32 updates,
+    torch.inverse and a GEMM per module) timed on the host cores over whole edits of the same
+    workload, bounded to ~budget_s seconds."""
+    from oracle import uce_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    Wc = inp["W"].cpu()
+    ws, off = [], 0
+    for _, o in inp["mods"]:
+        ws.append(Wc[off:off + o])
+        off += o
+    C, G = inp["C"].cpu(), inp["G"].cpu()
+    n_e, n_p = inp["n_e"], inp["n_p"]
+    edit = [C[i:i + 1] for i in range(n_e)]
+    guide = [G[i:i + 1] for i in range(n_e)]
+    pres = [C[n_e + i:n_e + i + 1] for i in range(n_p)]
+    O.uce_edit_ref(ws[:2], edit, guide, pres, 1.0, 1.0, 0.5)          # warm-up (MKL init)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.uce_edit_ref(ws, edit, guide, pres, 1.0, 1.0, 0.5)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 30:
+            break
+    n = n_e + n_p
+    return dict(value=round(n * reps / el, 2), unit="concepts/s", cores=threads, kind="port",
+                sample=f"{reps} whole edits of the {n}-concept workload over all {len(ws)} modules "
+                       f"(torch CPU, {threads} threads, {el:.1f} s)")
+
+
+def time_kernel(fn, iters: int):
+    """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
+    back-to-back launches (the library enqueues on torch's current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="sd14_erase50", choices=sorted(WORKLOADS))
+    ap.add_argument("--algo", default="auto", choices=["auto", "primal", "dual"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from uce_amd import edit as E
+    from uce_amd import cli
+    H = E.UceHandle.get(device)
+    inp = make_inputs(args.workload, device)
+    C, G, s, W = inp["C"], inp["G"], inp["s"], inp["W"]
+    N, d, rows, n_e = C.shape[0], inp["d"], inp["rows"], inp["n_e"]
+    algo = cli.ALGO_IDS[args.algo]
+    out = torch.empty_like(W)
+    H.reserve(d, max(N, d))
+
+    def step():
+        H.edit(C, G, s, 0.5, W, out=out, algo=algo)
+
+    for _ in range(args.warmup):
+        step()
+    H.status()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    H.status()
+
+    # ---- per-kernel timing of the dominant kernel, HIP events on the launch stream
+    use_dual = (algo == 2) or (algo == 0 and ((N + 63) // 64) * 64 < d)
+    iters = max(20, min(200, args.steps))
+    if use_dual and n_e <= 256:
+        Dm, R = H.dual_factors(C, G, s, 0.5)
+        ms = time_kernel(lambda: H.apply_lowrank(W, Dm, R, out=out), iters)
+        alg_bytes = 8.0 * rows * d + 8.0 * n_e * d          # W in + W out (+ the two factors once)
+        roof = dict(kernel="k_apply_lowrank", bound="hbm", achieved=round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", avg_ms=round(ms, 5), algorithmic_bytes=alg_bytes)
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    else:
+        A, Bt = H.gram(C, G, s, 0.5)
+        DT = H.solve_delta(A, Bt)
+        ms = time_kernel(lambda: H.apply(W, DT, out=out), iters)
+        flops = 2.0 * rows * d * d
+        roof = dict(kernel="k_apply", bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2),
+                    peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", avg_ms=round(ms, 5), algorithmic_flops=flops)
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    roof["traffic"] = None
+    if os.path.exists(traffic_file):
+        try:
+            roof["traffic"] = json.load(open(traffic_file)).get(args.workload, {}).get(roof["kernel"])
+        except Exception:
+            pass
+
+    result = {
+        "metric": "concepts/sec closed-form edit (SD-1.4, 768-d)",
+        "value": round(world * N * args.steps / elapsed, 1),
+        "unit": "concepts/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 (f64 Gram/solve)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_e} erase + {inp['n_p']} preserve concepts, d={d}, "
+                               f"{len(inp['mods'])} attn2 to_k/to_v modules = one {rows}x{d} fp32 slab, "
+                               f"lambda 0.5, algo {args.algo}",
+                   "parallelism": "replicas only" if world > 1 else "single GPU"},
+        "roofline": roof,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(inp, args.cpu_budget)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

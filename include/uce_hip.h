@@ -1,0 +1,127 @@
+/*
+ * uce_hip.h - C ABI of libuce_hip.so: the MI355X (gfx950) kernels behind the UCE hot path.
+ *
+ * The reference (rohitgandikota/unified-concept-editing) is pure Python on torch/diffusers and
+ * has no FFI of its own; this ABI sits exactly where its inlined torch ops sit.  Each entry
+ * point cites the reference lines it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Every function returns int:
+ *     0 = OK, negative = error (UCE_E* below, or -(hipError_t) - 1000 for HIP failures).
+ *   - All data pointers are DEVICE pointers owned by the caller (e.g. tensor.data_ptr()).
+ *     The library owns only an opaque per-handle workspace (uce_create / uce_reserve).
+ *   - All work is enqueued on the caller's stream (pass torch.cuda.current_stream().cuda_stream
+ *     as a void*); no call synchronises the device except uce_create/uce_reserve/uce_destroy
+ *     (allocation) and uce_status (reads one int back).
+ *   - One handle per GPU per thread; calls on one handle must not overlap in time.
+ *   - Matrices are row-major and dense unless stated.  d (the text-embedding width) must be
+ *     a multiple of 64 (768 SD-1.x, 1024 SD-2.x, 2048 SDXL).
+ *
+ * Math: with C [N,d] the concept embeddings (edit rows first, then
+ * preserve rows), G [N_edit,d] the targets of the edit rows (a preserve row's target is itself),
+ * s [N] the per-row scales and lambda the regulariser, the reference's per-module
+ *     W_new = (lambda W_old + sum_i s_i v*_i c_i^T)(lambda I + sum_i s_i c_i c_i^T)^-1 ,  v*_i = W_old g_i
+ * collapses (to_k/to_v have no bias) to one module-independent update
+ *     W_new = W_old + W_old Delta ,   Delta = (G-C)_e^T S_e C_e A^-1 ,   A = lambda I + C^T S C .
+ */
+#ifndef UCE_HIP_H
+#define UCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uce_ctx* uce_handle_t;
+typedef void* uce_stream_t; /* a hipStream_t */
+
+enum {
+  UCE_OK = 0,
+  UCE_EINVAL = -22,   /* bad argument (null pointer, d not a multiple of 64, N <= 0, ...) */
+  UCE_ENOMEM = -12,   /* workspace allocation failed */
+  UCE_EDOM = -33,     /* system not positive definite (lambda <= 0 with rank-deficient C, s_i < 0) */
+  UCE_ENOSYS = -38,   /* feature not built */
+  UCE_EHIP = -1000    /* -1000 - hipError_t */
+};
+
+enum { UCE_ALGO_AUTO = 0, UCE_ALGO_PRIMAL = 1, UCE_ALGO_DUAL = 2 };
+enum { UCE_DTYPE_BF16 = 0, UCE_DTYPE_F16 = 1, UCE_DTYPE_F32 = 2 };
+
+int uce_version(void);
+const char* uce_strerror(int code);
+
+/* Lifetime.  `device` is a HIP device ordinal.  uce_reserve pre-allocates the workspace for
+ * systems up to n_max x n_max with embedding width up to d_max so that later calls never
+ * allocate (the compute calls grow the workspace on demand otherwise, which synchronises). */
+int uce_create(uce_handle_t* h, int device);
+int uce_destroy(uce_handle_t h);
+int uce_reserve(uce_handle_t h, int d_max, int n_max);
+
+/* a4 - accumulate (uce_sd_erase.py:56-79, uce_sd_debias.py:114-138; once instead of per module):
+ *   A  [d,d] f64 = lambda I + C^T S C                     (symmetric, both triangles written)
+ *   Bt [d,d] f64 = C_e^T S_e (G - C_e)   ( = B^T, B = (G-C)_e^T S_e C_e )
+ * fp32 inputs, products and sums in f64 (v_mfma_f64_16x16x4_f64). */
+int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
+             float lamb, double* A, double* Bt, uce_stream_t stream);
+
+/* a5 - solve (replaces torch.inverse(mat2.float()) of uce_sd_erase.py:82, 32x/140x identical):
+ *   DeltaT [d,d] f32 = A^-1 Bt = Delta^T  via blocked f64 Cholesky + two triangular solves.
+ * A is destroyed.  A non-positive pivot is recorded in the handle (see uce_status). */
+int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* DeltaT, uce_stream_t stream);
+
+/* a5 - apply (replaces `mat1 @ inverse` of uce_sd_erase.py:82 for ALL modules in one launch):
+ *   W_new [rows,d] = W_old + W_old Delta ; rows = sum of the modules' out_features (the host
+ *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  fp32 MFMA, exact f32 products. */
+int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,
+              uce_stream_t stream);
+
+/* Dual (N < d) form of a4+a5: with K = lambda S^-1 + C C^T (N x N, SPD),
+ *   Dm [N_edit,d] f32 = (G - C_e),   R [N_edit,d] f32 = rows 0..N_edit-1 of K^-1 C,
+ *   Delta = Dm^T R.  Rows with s_i == 0 are rejected (UCE_EINVAL). */
+int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,
+                     int d, float lamb, float* Dm, float* R, uce_stream_t stream);
+
+/* Low-rank apply: W_new = W_old + (W_old Dm^T) R, one fused HBM-bound pass (N_edit <= 256). */
+int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const float* R, float* W_new,
+                      long rows, int d, int N_edit, uce_stream_t stream);
+
+/* DeltaT [d,d] f32 from the dual factors (used when N_edit is too large for the low-rank apply). */
+int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int N_edit, int d,
+                           float* DeltaT, uce_stream_t stream);
+
+/* The whole of uce_sd_erase.py:45-82 for every module: picks dual/primal and low-rank/full by
+ * (N, N_edit, d) when algo == UCE_ALGO_AUTO.  W_new may not alias W_old. */
+int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
+             float lamb, const float* W_old, float* W_new, long rows, int algo, uce_stream_t stream);
+
+/* Synchronises `stream` and returns the status word of the last solve on this handle:
+ * *info = 0 OK, k > 0: leading minor k not positive definite (function then returns UCE_EDOM). */
+int uce_status(uce_handle_t h, int* info, uce_stream_t stream);
+
+/* a6 - debias drift (uce_sd_debias.py:122-127, cumulative over iterations):
+ *   G [N_edit,d] f32 = C_edit + Dsum [N_edit,N_debias] (f64, = sum_t direction_scale_t) @ C_debias */
+int uce_debias_targets(uce_handle_t h, const float* C_edit, const float* C_debias, const double* Dsum,
+                       int N_edit, int N_debias, int d, float* G, uce_stream_t stream);
+
+/* a8 - weight patch (generate-images-sd.py:17-19, uce_sd_debias.py:15-19): f32 -> bf16
+ * round-to-nearest-even cast of the edited slab into the U-Net's parameter storage. */
+int uce_cast_bf16(uce_handle_t h, const float* src, void* dst_bf16, long n, uce_stream_t stream);
+
+/* a10 - cross-attention at inference (diffusers AttnProcessor2_0 -> F.scaled_dot_product_attention,
+ * reached from generate-images-sd.py:37-42):  O = softmax(Q K^T * scale) V per (batch, head).
+ *   q,o: [B, Lq, H*dh]   k,v: [B, Lk, H*dh]   (diffusers' [B, L, C] layout, heads are column
+ *   slices), Lk <= 128 (77 for CLIP), dh in {40, 64, 80, 96, 128, 160}, bf16 or f16 I/O,
+ *   f32 softmax and accumulation. */
+int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H,
+                  int Lq, int Lk, int dh, float scale, int dtype, uce_stream_t stream);
+
+/* e - broadcast of the edited blob over RCCL/xGMI.  `comm` is an ncclComm_t.  librccl is
+ * dlopen()ed on first use; returns UCE_ENOSYS when it cannot be loaded. */
+int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCE_HIP_H */

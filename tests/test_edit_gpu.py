@@ -1,0 +1,297 @@
+"""GPU parity tests of the closed-form edit: every call goes through the C ABI (libuce_hip.so).
+
+Acceptance protocol:
+  eps_ref   = relF(reference fp32 output, exact64)      - what the reference itself achieves
+  eps_build = relF(build, exact64)           <= 1e-5    - ours, against the fp64 evaluation
+  relF(build, reference fp32)                <= max(1e-4, 1.5 * eps_ref)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+from tests import fakepipe
+from tests.golden_io import Case, ERASE_CASES, DEBIAS_CASES, CLI_CASES, rows
+from uce_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+EPS_BUILD = 1e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    from uce_amd import edit as E
+    return E.UceHandle.get("cuda:0")
+
+
+def _dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to(device="cuda:0", dtype=dtype).contiguous()
+
+
+def _synthetic(N, Ne, d, seed):
+    C = O.clip_like_embeddings(N + 1, d, seed)
+    Cm = C[:N]
+    G = np.repeat(C[N:N + 1], Ne, axis=0) + 0.0
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    s = rng.uniform(0.5, 1.5, size=N).astype(np.float32)
+    return Cm, G, s
+
+
+def _exact(C, G, s, lamb):
+    """float64 A, Bt, DeltaT on the host."""
+    C64, s64 = C.astype(np.float64), s.astype(np.float64)
+    Ne = G.shape[0]
+    A = lamb * np.eye(C.shape[1]) + C64.T @ (s64[:, None] * C64)
+    Dm = (G.astype(np.float32) - C[:Ne].astype(np.float32)).astype(np.float64)
+    Bt = C64[:Ne].T @ (s64[:Ne, None] * Dm)
+    DeltaT = np.linalg.solve(A, Bt)
+    return A, Bt, DeltaT
+
+
+# ------------------------------------------------------------------------------------ kernels
+
+@pytest.mark.parametrize("N,Ne,d", [(5, 2, 64), (33, 33, 128), (50, 50, 768), (700, 400, 768), (130, 100, 1024),
+                                    (1500, 1000, 768)])
+def test_gram_matches_f64(H, N, Ne, d):
+    C, G, s = _synthetic(N, Ne, d, seed=N)
+    A, Bt = H.gram(_dev(C), _dev(G), _dev(s), 0.5)
+    Ae, Bte, _ = _exact(C, G, s, 0.5)
+    assert O.rel_fro(A.cpu(), Ae) < 1e-14
+    assert O.rel_fro(Bt.cpu(), Bte) < 1e-13
+    assert torch.equal(A, A.T)
+
+
+@pytest.mark.parametrize("N,Ne,d", [(5, 2, 64), (40, 40, 128), (50, 50, 768), (900, 500, 768), (100, 64, 1024)])
+def test_solve_delta_matches_f64(H, N, Ne, d):
+    C, G, s = _synthetic(N, Ne, d, seed=N + 1)
+    Ae, Bte, DTe = _exact(C, G, s, 0.5)
+    DT = H.solve_delta(_dev(Ae, torch.float64), _dev(Bte, torch.float64))
+    H.status()
+    assert O.rel_fro(DT.cpu(), DTe) < 5e-7     # fp64 solve, fp32 store
+
+
+def test_solve_reports_indefinite_system(H):
+    d = 128
+    A = -np.eye(d)
+    with pytest.raises(L.UceError):
+        H.solve_delta(_dev(A, torch.float64), _dev(np.zeros((d, d)), torch.float64))
+        H.status()
+    # and the handle recovers
+    DT = H.solve_delta(_dev(np.eye(d), torch.float64), _dev(np.eye(d), torch.float64))
+    H.status()
+    assert O.rel_fro(DT.cpu(), np.eye(d)) < 1e-7
+
+
+@pytest.mark.parametrize("rows_,d", [(96, 64), (128, 128), (1000, 768), (24960, 768), (333, 1024)])
+def test_apply_matches_f64(H, rows_, d):
+    rng = np.random.Generator(np.random.PCG64(rows_))
+    W = O.linear_default_weight(rows_, d, rng)
+    # an asymmetric Delta so a transposed operand or output cannot pass
+    DT = (rng.standard_normal((d, d)) * (0.5 / math.sqrt(d))).astype(np.float32)
+    DT[0, 1] += 3.0
+    out = H.apply(_dev(W), _dev(DT))
+    want = W.astype(np.float64) + W.astype(np.float64) @ DT.astype(np.float64).T
+    assert O.rel_fro(out.cpu(), want) < 3e-7
+
+
+@pytest.mark.parametrize("N,Ne,d", [(5, 2, 64), (50, 50, 768), (64, 10, 128), (300, 200, 768), (40, 36, 2048),
+                                    (65, 65, 128)])
+def test_dual_factors_and_lowrank_apply(H, N, Ne, d):
+    C, G, s = _synthetic(N, Ne, d, seed=N + 2)
+    Dm, R = H.dual_factors(_dev(C), _dev(G), _dev(s), 0.5)
+    H.status()
+    C64 = C.astype(np.float64)
+    K = np.diag(0.5 / s.astype(np.float64)) + C64 @ C64.T
+    Re = np.linalg.solve(K, C64)[:Ne]
+    assert O.rel_fro(R.cpu(), Re) < 5e-7
+    assert torch.equal(Dm.cpu(), torch.from_numpy(G - C[:Ne]))
+    _, _, DTe = _exact(C, G, s, 0.5)
+    rng = np.random.Generator(np.random.PCG64(7))
+    W = O.linear_default_weight(200, d, rng)
+    want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
+    DT = H.delta_from_factors(Dm, R)
+    assert O.rel_fro(DT.cpu(), DTe) < 5e-6
+    if Ne <= 256:
+        out = H.apply_lowrank(_dev(W), Dm, R)
+        assert O.rel_fro(out.cpu(), want) < 2e-6
+
+
+def test_dual_rejects_nonpositive_scale(H):
+    C, G, s = _synthetic(6, 3, 64, seed=3)
+    s[1] = -1.0
+    with pytest.raises(L.UceError):
+        H.dual_factors(_dev(C), _dev(G), _dev(s), 0.5)
+        H.status()
+
+
+def test_cast_bf16_bit_exact(H):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(100003, generator=g) * 3
+    x[:4] = torch.tensor([float("inf"), -float("inf"), 0.0, -0.0])
+    x[4] = float("nan")
+    xd = x.cuda()
+    out = torch.empty(x.numel(), dtype=torch.bfloat16, device="cuda:0")
+    H.cast_bf16(xd, out)
+    want = xd.to(torch.bfloat16)
+    a, b = out.view(torch.int16).cpu(), want.view(torch.int16).cpu()
+    nan = torch.isnan(want.float().cpu())
+    assert torch.equal(a[~nan], b[~nan]) and bool(torch.isnan(out.float().cpu()[nan]).all())
+
+
+def test_debias_targets(H):
+    rng = np.random.Generator(np.random.PCG64(9))
+    Ce, Cd = O.clip_like_embeddings(7, 128, 1), O.clip_like_embeddings(3, 128, 2)
+    D = rng.uniform(-0.5, 0.5, size=(7, 3))
+    G = H.debias_targets(_dev(Ce), _dev(Cd), _dev(D, torch.float64))
+    want = (Ce.astype(np.float64) + D @ Cd.astype(np.float64)).astype(np.float32)
+    assert torch.equal(G.cpu(), torch.from_numpy(want))
+
+
+# ------------------------------------------------------------------------------------ goldens
+
+def _run_case(H, c, algo):
+    m = c.meta
+    Ce, Ge, Cp = c.arr("C_edit"), c.arr("G_edit"), c.arr("C_pres")
+    C = np.concatenate([Ce, Cp]) if len(Cp) else Ce
+    s = np.array([m["erase_scale"]] * len(Ce) + [m["preserve_scale"]] * len(Cp), dtype=np.float32)
+    W = torch.cat(c.w_old())
+    out = H.edit(_dev(C), _dev(Ge), _dev(s), m["lamb"], W.cuda().contiguous(), algo=algo, check=True)
+    return out.cpu()
+
+
+@pytest.mark.parametrize("algo", [L.ALGO_PRIMAL, L.ALGO_DUAL, L.ALGO_AUTO])
+@pytest.mark.parametrize("name", ERASE_CASES)
+def test_erase_golden(H, name, algo):
+    c = Case(name)
+    N = len(c.arr("C_edit")) + len(c.arr("C_pres"))
+    if algo == L.ALGO_DUAL and N > 1024:
+        pytest.skip("dual form is for N < d")
+    out = _run_case(H, c, algo)
+    ex, ref = torch.cat(c.w_exact64()), torch.cat(c.w_ref32())
+    eps_ref = O.rel_fro(ref, ex)
+    eps_build = O.rel_fro(out, ex)
+    assert eps_build < EPS_BUILD, (eps_build, eps_ref)
+    assert O.rel_fro(out, ref) < max(1e-4, 1.5 * eps_ref)
+
+
+@pytest.mark.parametrize("name", DEBIAS_CASES)
+def test_debias_golden(H, name):
+    from uce_amd import edit as E
+    c = Case(name)
+    m = c.meta
+    names = m["modules"]
+    ws = c.w_old()
+    rows_ = [w.shape[0] for w in ws]
+    offs = [0] + list(np.cumsum(rows_)[:-1])
+    slab = E.WeightSlab(names, [int(o) for o in offs], rows_, torch.cat(ws).cuda().contiguous())
+    Cp = c.arr("C_pres")
+    st = E.DebiasState(H, slab, _dev(c.arr("C_edit")), _dev(c.arr("C_debias")), _dev(Cp) if len(Cp) else None,
+                       m["edit_scale"], m["preserve_scale"], m["lamb"])
+    for ds in c.arr("direction_scales"):
+        if np.abs(ds).max() == 0:          # uce_sd_debias.py:110-112
+            break
+        st.step(ds)
+    out = st.current.data.cpu()
+    ex, ref = torch.cat(c.w_exact64()), torch.cat(c.w_ref32())
+    eps_ref = O.rel_fro(ref, ex)
+    assert O.rel_fro(out, ex) < EPS_BUILD
+    assert O.rel_fro(out, ref) < max(1e-4, 1.5 * eps_ref)
+
+
+@pytest.mark.parametrize("name", CLI_CASES)
+def test_UCE_dropin_matches_reference_cli(H, name, tmp_path):
+    """UCE() on the same fake pipe the reference CLI ran on: same keys, shapes and weights."""
+    from safetensors.torch import load_file
+    from uce_amd import edit as E
+    from uce_amd import cli
+    c = Case(name)
+    m = c.meta
+    seed = {"cli_erase_art_expand": 21, "cli_erase_object_default": 22, "cli_erase_object_expand_guided": 23}[name]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    unet = fakepipe.build_unet(O.sd14_module_table(), 768, rng)
+    pipe = fakepipe.FakePipe(unet, 768)
+    args = cli.parse_erase_args(m["argv"] + ["--save_dir", str(tmp_path), "--exp_name", name])
+    job = cli.erase_job_from_args(args)
+    E.UCE(pipe, job.edit_concepts, job.guide_concepts, job.preserve_concepts, job.erase_scale, job.preserve_scale,
+          job.lamb, job.save_dir, job.exp_name, device="cuda:0")
+    state = load_file(str(tmp_path / (name + ".safetensors")))
+    assert sorted(state) == sorted(m["st_keys"])
+    assert pipe.encode_calls == m["encode_calls"]
+    for i, (n, shp) in enumerate(zip(m["modules"], m["shapes"])):
+        got = state[n + ".weight"]
+        assert list(got.shape) == shp and got.dtype == torch.float32
+        ref = c.t(f"W_ref32_{i}")
+        w_old = c.t(f"W_old_{i}")
+        assert torch.equal(w_old, unet.get_submodule(n).weight[: w_old.shape[0]])
+        assert O.rel_fro(got[: ref.shape[0]], ref) < 2.5e-3   # the reference's own fp32 noise level (eps_ref)
+
+
+# ------------------------------------------------------------------------------------ full size
+
+@pytest.mark.parametrize("N_e,N_p", [(50, 0), (1000, 500)])
+def test_full_size_properties(H, N_e, N_p):
+    """BASELINE configs 2 and 3 at SD-1.4's full 24960 x 768 slab: size-independent properties."""
+    d, rows_ = 768, 24960
+    N = N_e + N_p
+    Call = O.clip_like_embeddings(N + 1, d, seed=N)
+    C, g = Call[:N], Call[N]
+    G = np.repeat(g[None], N_e, axis=0)
+    s = np.ones(N, dtype=np.float32)
+    rng = np.random.Generator(np.random.PCG64(N))
+    W = O.linear_default_weight(rows_, d, rng)
+    Cd, Gd, sd, Wd = _dev(C), _dev(G), _dev(s), _dev(W)
+    out = H.edit(Cd, Gd, sd, 0.5, Wd, check=True)
+    # (1) against an fp64 evaluation on the GPU by torch (independent of our kernels)
+    C64, W64 = Cd.double(), Wd.double()
+    A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda:0") + C64.T @ C64
+    Dm = (Gd - Cd[:N_e]).double()
+    Delta = torch.linalg.solve(A, C64[:N_e].T @ Dm).T
+    want = W64 + W64 @ Delta
+    assert O.rel_fro(out.cpu(), want.cpu()) < EPS_BUILD
+    # (2) both algorithms agree
+    if N < d:
+        out_p = H.edit(Cd, Gd, sd, 0.5, Wd, algo=L.ALGO_PRIMAL, check=True)
+        assert O.rel_fro(out_p.cpu(), out.cpu()) < 2e-6
+    # (3) linearity in W: edit(2 W) = 2 edit(W) exactly-ish, and row independence
+    out2 = H.edit(Cd, Gd, sd, 0.5, (2 * Wd).contiguous(), check=True)
+    assert O.rel_fro(out2.cpu(), (2 * out).cpu()) < 1e-6
+    sub = H.edit(Cd, Gd, sd, 0.5, Wd[1000:1100].contiguous(), check=True)
+    assert O.rel_fro(sub.cpu(), out[1000:1100].cpu()) < 1e-6
+    # (4) what the edit is FOR: erased concepts map near the guide's output, preserved ones stay
+    v_new = out.double() @ C64[:N_e].T
+    v_tgt = W64 @ Gd.double().T
+    v_old = W64 @ C64[:N_e].T
+    assert float((v_new - v_tgt).norm() / (v_old - v_tgt).norm()) < 0.2
+    if N_p:
+        p_new = out.double() @ C64[N_e:].T
+        p_old = W64 @ C64[N_e:].T
+        assert float((p_new - p_old).norm() / p_old.norm()) < 0.1
+    # (5) bit-repeatable
+    again = H.edit(Cd, Gd, sd, 0.5, Wd, check=True)
+    assert torch.equal(again, out)
+
+
+def test_edit_edge_cases(H):
+    from uce_amd import edit as E
+    d = 128
+    C, G, s = _synthetic(4, 2, d, seed=11)
+    rng = np.random.Generator(np.random.PCG64(3))
+    W = _dev(O.linear_default_weight(40, d, rng))
+    slab = E.WeightSlab(["m.attn2.to_k"], [0], [40], W)
+    # preserve-only edit and all-zero scales leave the weights untouched
+    out = E.edit_slab(H, slab, _dev(C), None, _dev(s), 0.5)
+    assert torch.equal(out.data, W)
+    out = E.edit_slab(H, slab, _dev(C), _dev(G), _dev(np.zeros(4, np.float32)), 0.5)
+    assert torch.equal(out.data, W)
+    # a single row, a single concept
+    one = H.edit(_dev(C[:1]), _dev(G[:1]), _dev(s[:1]), 0.5, W[:1].contiguous(), check=True)
+    c64, g64, w64 = C[0].astype(np.float64), G[0].astype(np.float64), W[:1].cpu().double().numpy()
+    A = 0.5 * np.eye(d) + s[0] * np.outer(c64, c64)
+    want = (0.5 * w64 + s[0] * np.outer(w64 @ g64, c64)) @ np.linalg.inv(A)
+    assert O.rel_fro(one.cpu(), want) < 1e-6
+    # invalid arguments are rejected, not crashed on
+    with pytest.raises(L.UceError):
+        H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, out=W)

@@ -1,0 +1,125 @@
+"""CPU: host-side logic of the drop-in (module discovery, slab packing, concept matrices,
+artifact format) - no kernels involved."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+from tests import fakepipe
+from tests.golden_io import Case
+from uce_amd import edit as E
+
+
+def _pipe(table, d=64, seed=0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    unet = fakepipe.build_unet(table, d, rng)
+    return fakepipe.FakePipe(unet, d)
+
+
+def test_module_discovery_matches_reference_topology():
+    c = Case("cli_erase_art_expand")
+    pipe = _pipe([(n, s[0]) for n, s in zip(c.meta["modules"], c.meta["shapes"])], d=768)
+    mods = E.collect_uce_modules(pipe.unet)
+    assert [n for n, _ in mods] == c.meta["modules"]
+    assert [list(m.weight.shape) for _, m in mods] == c.meta["shapes"]
+    assert len(mods) == 32
+
+
+def test_slab_roundtrip_and_artifact(tmp_path):
+    table = O.sd14_module_table()[:6]
+    pipe = _pipe(table, d=64)
+    mods = E.collect_uce_modules(pipe.unet)
+    slab = E.WeightSlab.from_modules(mods, "cpu")
+    assert slab.data.shape == (sum(o for _, o in table), 64)
+    for (n, m), v in zip(mods, slab.views()):
+        assert torch.equal(v, m.weight)
+    path = E.save_uce_state(slab, str(tmp_path), "t")
+    raw = open(path, "rb").read()
+    hdr = json.loads(raw[8:8 + int.from_bytes(raw[:8], "little")])
+    keys = [k for k in hdr if k != "__metadata__"]
+    assert sorted(keys) == sorted(n + ".weight" for n, _ in table)
+    assert {hdr[k]["dtype"] for k in keys} == {"F32"}
+    from safetensors.torch import load_file
+    back = load_file(path)
+    for (n, m) in mods:
+        assert torch.equal(back[n + ".weight"], m.weight)
+
+
+def test_last_token_embeddings_follow_reference_index():
+    pipe = _pipe(O.sd14_module_table()[:2], d=64)
+    long_prompt = " ".join(f"w{i}" for i in range(90))
+    prompts = ["Van Gogh", "", "art", "Van Gogh", long_prompt]
+    emb = E.last_token_embeddings(pipe, prompts, "cpu")
+    assert pipe.encode_calls == ["Van Gogh", "", "art", long_prompt]      # unique strings only
+    for p in set(prompts):
+        assert torch.equal(emb[p], torch.from_numpy(pipe.embedding(p)))  # idx = mask.sum()-2 (0 for '', 75 truncated)
+
+
+def test_concept_matrices_keep_duplicates_and_order():
+    d = 8
+    embeds = {k: torch.full((d,), float(i)) for i, k in enumerate(["a", "b", "g", "p"])}
+    C, G, s = E.concept_matrices(embeds, ["a", "b", "a"], ["g", "g", "g"], ["p", "a"], 2.0, 0.5, "cpu")
+    assert C[:, 0].tolist() == [0.0, 1.0, 0.0, 3.0, 0.0]
+    assert G[:, 0].tolist() == [2.0, 2.0, 2.0]
+    assert s.tolist() == [2.0, 2.0, 2.0, 0.5, 0.5]
+    with pytest.raises(ValueError):
+        E.concept_matrices(embeds, ["a"], ["g", "g"], [], 1, 1, "cpu")
+
+
+def test_drop_zero_scale_rows():
+    C = torch.arange(12.0).view(4, 3)
+    G = torch.arange(6.0).view(2, 3)
+    s = torch.tensor([0.0, 1.0, 0.0, 2.0])
+    C2, G2, s2, ne = E.drop_zero_scale_rows(C, G, s, 2)
+    assert ne == 1 and C2.shape[0] == 2 and torch.equal(G2, G[1:2]) and s2.tolist() == [1.0, 2.0]
+
+
+@pytest.mark.parametrize("name", ["cli_erase_art_expand", "cli_erase_object_default", "cli_erase_object_expand_guided"])
+def test_cli_concept_lists_match_reference_stdout(name):
+    """Our argparse + list handling vs what the reference's __main__ printed and encoded."""
+    from uce_amd import cli
+    c = Case(name)
+    args = cli.parse_erase_args(c.meta["argv"] + ["--save_dir", "/tmp/x", "--exp_name", name, "--device", "cpu"])
+    job = cli.erase_job_from_args(args)
+    ours = [ln for b in job.banner for ln in b.splitlines() if ln.strip()]
+    ref = [ln for ln in c.meta["stdout_lines"] if ln.strip() and not ln.startswith("Erased concepts")]
+    assert ours == ref
+    seen = []
+    for e in job.edit_concepts + job.guide_concepts + job.preserve_concepts:
+        if e not in seen:
+            seen.append(e)
+    assert seen == c.meta["encode_calls"]
+
+
+def test_cli_defaults_and_errors():
+    from uce_amd import cli
+    a = cli.parse_erase_args(["--edit_concepts", "x", "--concept_type", "object"])
+    assert (a.model_id, a.device, a.erase_scale, a.preserve_scale, a.lamb, a.expand_prompts, a.save_dir, a.exp_name) == \
+        ("CompVis/stable-diffusion-v1-4", "cuda:0", 1, 1, 0.5, "false", "../uce_models", None)
+    j = cli.erase_job_from_args(a)
+    assert j.guide_concepts == [""] and j.exp_name == "uce_test" and j.preserve_concepts == []
+    a = cli.parse_erase_args(["--edit_concepts", "x;y;z", "--guide_concepts", "a;b", "--concept_type", "art"])
+    with pytest.raises(Exception, match="do not match"):
+        cli.erase_job_from_args(a)
+    with pytest.raises(SystemExit):
+        cli.parse_erase_args(["--edit_concepts", "x", "--concept_type", "unsafe"])     # argparse rejects (README is wrong)
+    d = cli.parse_debias_args(["--edit_concepts", "Doctor; Nurse", "--debias_concepts", "male; female"])
+    assert (d.desired_ratios, d.max_iterations, d.max_diff, d.step_size, d.num_images_per_prompt,
+            d.num_inference_steps, d.guidance_scale) == ([0.5, 0.5], 30, 0.05, 0.1, 10, 20, 7.5)
+    assert cli.debias_job_from_args(d).debias_concepts == ["male", "female"]
+    d = cli.parse_debias_args(["--edit_concepts", "Doctor", "--debias_concepts", "a;b;c"])
+    with pytest.raises(Exception, match="do not match"):
+        cli.debias_job_from_args(d)
+    g = cli.parse_generate_args(["--prompts_path", "p.csv"])
+    assert (g.save_path, g.exp_name, g.guidance_scale, g.till_case, g.from_case, g.num_images_per_prompt,
+            g.num_inference_steps, g.uce_model_path) == ("../uce_results/", "test_images", 7.5, 1000000, 0, 1, 50, None)
+
+
+def test_product_synth_agrees_with_oracle_tables():
+    from uce_amd import synth
+    assert synth.sd14_module_table() == O.sd14_module_table()
+    assert synth.sdxl_module_table() == O.sdxl_module_table()
+    assert np.array_equal(synth.clip_like_embeddings(5, 64, 3), O.clip_like_embeddings(5, 64, 3))

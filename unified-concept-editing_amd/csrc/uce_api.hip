@@ -1,0 +1,238 @@
+// C ABI of libuce_hip.so (include/uce_hip.h): handle lifetime, argument checks, and the
+// orchestration of the edit pipeline (gram -> potrf chain -> trisolve -> apply) on one stream.
+#include "uce_common.h"
+#include <dlfcn.h>
+#include <new>
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static void free_ws(uce_ctx* h) {
+  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->DeltaT, h->Dm, h->R};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->M = h->Lmat = h->Linv = h->slabs = h->Bt = h->Yg = nullptr;
+  h->DeltaT = h->Dm = h->R = nullptr;
+  h->slabs_bytes = 0;
+  h->d_cap = h->n_cap = 0;
+}
+
+int uce_ensure(uce_ctx* h, int d, int n) {
+  if (d <= h->d_cap && n <= h->n_cap) return UCE_OK;
+  const int dc = d > h->d_cap ? d : h->d_cap;
+  const int nc = n > h->n_cap ? n : h->n_cap;
+  UCE_HIP_TRY(hipSetDevice(h->device));
+  UCE_HIP_TRY(hipDeviceSynchronize());
+  free_ws(h);
+  const size_t nn = (size_t)nc * nc, dd = (size_t)dc * dc;
+  // split-K slabs: primal needs nsplit*2*d*d (only for small d), dual nsplit*n*n with nsplit <= 256 tiles
+  size_t slabs = 0;
+  {
+    // primal: tiles >= 128 (d >= 576) -> no slabs; otherwise nsplit <= ceil(256 / tiles)
+    const int nb = dc / 64;
+    const int tiles = nb * (nb + 1) / 2 + nb * nb;
+    if (tiles < 128) slabs = (size_t)((256 + tiles - 1) / tiles) * 2 * dd * sizeof(double);
+    // dual: for every n' <= nc, nsplit(n') * n'^2 <= max(256 * 64^2 * ..): bound by tiles(n')*split <= 256+tiles
+    const int nbn = nc / 64;
+    size_t worst = 0;
+    for (int b = 1; b <= nbn; ++b) {
+      const int t = b * (b + 1) / 2;
+      const int sp = t >= 128 ? 1 : (256 + t - 1) / t;
+      const size_t need = (size_t)sp * (size_t)(b * 64) * (b * 64) * sizeof(double);
+      if (need > worst) worst = need;
+    }
+    if (worst > slabs) slabs = worst;
+  }
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16);
+  };
+  alloc((void**)&h->M, nn * sizeof(double));
+  alloc((void**)&h->Lmat, nn * sizeof(double));
+  alloc((void**)&h->Linv, (size_t)(nc / 64) * 64 * 64 * sizeof(double));
+  alloc((void**)&h->slabs, slabs);
+  alloc((void**)&h->Bt, dd * sizeof(double));
+  alloc((void**)&h->Yg, nc > 1024 ? (size_t)nc * dc * sizeof(double) : 16);
+  alloc((void**)&h->DeltaT, dd * sizeof(float));
+  alloc((void**)&h->Dm, (size_t)nc * dc * sizeof(float));
+  alloc((void**)&h->R, (size_t)nc * dc * sizeof(float));
+  if (e != hipSuccess) {
+    free_ws(h);
+    return UCE_ENOMEM;
+  }
+  h->slabs_bytes = slabs;
+  h->d_cap = dc;
+  h->n_cap = nc;
+  return UCE_OK;
+}
+
+extern "C" {
+
+int uce_version(void) { return 100; }
+
+const char* uce_strerror(int code) {
+  switch (code) {
+    case UCE_OK: return "ok";
+    case UCE_EINVAL: return "invalid argument";
+    case UCE_ENOMEM: return "workspace allocation failed";
+    case UCE_EDOM: return "system is not positive definite (check lambda > 0 and scales > 0)";
+    case UCE_ENOSYS: return "not available in this build";
+    default:
+      if (code <= UCE_EHIP) return hipGetErrorString((hipError_t)(UCE_EHIP - code));
+      return "unknown error";
+  }
+}
+
+int uce_create(uce_handle_t* out, int device) {
+  if (!out) return UCE_EINVAL;
+  int ndev = 0;
+  UCE_HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return UCE_EINVAL;
+  UCE_HIP_TRY(hipSetDevice(device));
+  uce_ctx* h = new (std::nothrow) uce_ctx();
+  if (!h) return UCE_ENOMEM;
+  *h = uce_ctx{};
+  h->device = device;
+  hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
+  if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
+  (void)hipMemset(h->status, 0, sizeof(int));
+  *out = h;
+  return UCE_OK;
+}
+
+int uce_destroy(uce_handle_t h) {
+  if (!h) return UCE_EINVAL;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  free_ws(h);
+  if (h->status) (void)hipFree(h->status);
+  delete h;
+  return UCE_OK;
+}
+
+int uce_reserve(uce_handle_t h, int d_max, int n_max) {
+  if (!h || d_max <= 0 || n_max <= 0 || d_max % 64) return UCE_EINVAL;
+  return uce_ensure(h, d_max, round_up(n_max, 64));
+}
+
+int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
+             float lamb, double* A, double* Bt, uce_stream_t stream) {
+  if (!h || !C || !s || !A || !Bt || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64) return UCE_EINVAL;
+  if (N_edit > 0 && !G) return UCE_EINVAL;
+  int rc = uce_ensure(h, d, d);
+  if (rc) return rc;
+  return launch_gram_primal(h, C, G ? G : C, s, N, N_edit, d, lamb, A, Bt, (hipStream_t)stream);
+}
+
+int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* DeltaT, uce_stream_t stream) {
+  if (!h || !A || !Bt || !DeltaT || d <= 0 || d % 64) return UCE_EINVAL;
+  int rc = uce_ensure(h, d, d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  UCE_HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int), st));
+  rc = launch_potrf(h, A, d, st);
+  if (rc) return rc;
+  return launch_trisolve(h, d, d, Bt, nullptr, d, DeltaT, d, st);
+}
+
+int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,
+              uce_stream_t stream) {
+  if (!h || !W_old || !DeltaT || !W_new || rows < 0 || d <= 0 || d % 64 || W_old == W_new) return UCE_EINVAL;
+  if (rows == 0) return UCE_OK;
+  return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
+}
+
+int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,
+                     int d, float lamb, float* Dm, float* R, uce_stream_t stream) {
+  if (!h || !C || !s || !Dm || !R || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64) return UCE_EINVAL;
+  if (N_edit > 0 && !G) return UCE_EINVAL;
+  const int n_pad = round_up(N, 64);
+  int rc = uce_ensure(h, d, n_pad);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  UCE_HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int), st));
+  rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, st);
+  if (rc) return rc;
+  rc = launch_potrf(h, h->M, n_pad, st);
+  if (rc) return rc;
+  if (N_edit == 0) return UCE_OK;
+  rc = launch_trisolve(h, n_pad, d, nullptr, C, N, R, N_edit, st);
+  if (rc) return rc;
+  return launch_sub_rows(G, C, Dm, (long)N_edit * d, st);
+}
+
+int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int N_edit, int d,
+                           float* DeltaT, uce_stream_t stream) {
+  if (!h || !DeltaT || N_edit < 0 || d <= 0 || d % 64) return UCE_EINVAL;
+  if (N_edit > 0 && (!Dm || !R)) return UCE_EINVAL;
+  return launch_delta_from_factors(Dm, R, N_edit, d, DeltaT, (hipStream_t)stream);
+}
+
+int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const float* R, float* W_new,
+                      long rows, int d, int N_edit, uce_stream_t stream) {
+  if (!h || !W_old || !W_new || rows < 0 || d <= 0 || d % 64 || N_edit < 0 || N_edit > 256 || W_old == W_new)
+    return UCE_EINVAL;
+  if (N_edit > 0 && (!Dm || !R)) return UCE_EINVAL;
+  if (rows == 0) return UCE_OK;
+  return launch_apply_lowrank(W_old, Dm, R, W_new, rows, d, N_edit, (hipStream_t)stream);
+}
+
+int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
+             float lamb, const float* W_old, float* W_new, long rows, int algo, uce_stream_t stream) {
+  if (!h || !C || !s || !W_old || !W_new || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64 ||
+      rows < 0 || W_old == W_new)
+    return UCE_EINVAL;
+  if (N_edit > 0 && !G) return UCE_EINVAL;
+  if (algo == UCE_ALGO_AUTO) algo = (round_up(N, 64) < d) ? UCE_ALGO_DUAL : UCE_ALGO_PRIMAL;
+  int rc;
+  if (algo == UCE_ALGO_PRIMAL) {
+    rc = uce_ensure(h, d, d);
+    if (rc) return rc;
+    rc = uce_gram(h, C, G, s, N, N_edit, d, lamb, h->M, h->Bt, stream);
+    if (rc) return rc;
+    rc = uce_solve_delta(h, h->M, h->Bt, d, h->DeltaT, stream);
+    if (rc) return rc;
+    return uce_apply(h, W_old, h->DeltaT, W_new, rows, d, stream);
+  }
+  if (algo != UCE_ALGO_DUAL) return UCE_EINVAL;
+  const int n_pad = round_up(N, 64);
+  rc = uce_ensure(h, d, n_pad);
+  if (rc) return rc;
+  rc = uce_dual_factors(h, C, G, s, N, N_edit, d, lamb, h->Dm, h->R, stream);
+  if (rc) return rc;
+  if (apply_lowrank_fits(d, N_edit))
+    return uce_apply_lowrank(h, W_old, h->Dm, h->R, W_new, rows, d, N_edit, stream);
+  rc = uce_delta_from_factors(h, h->Dm, h->R, N_edit, d, h->DeltaT, stream);
+  if (rc) return rc;
+  return uce_apply(h, W_old, h->DeltaT, W_new, rows, d, stream);
+}
+
+int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {
+  if (!h || !info) return UCE_EINVAL;
+  int v = 0;
+  UCE_HIP_TRY(hipMemcpyAsync(&v, h->status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  UCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  *info = v;
+  return v ? UCE_EDOM : UCE_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// RCCL broadcast: librccl is loaded lazily so that the library itself has no link dependency
+// -------------------------------------------------------------------------------------------
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void*, hipStream_t);
+
+int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream) {
+  if (!h || !buf || !comm) return UCE_EINVAL;
+  static nccl_bcast_fn fn = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib) fn = (nccl_bcast_fn)dlsym(lib, "ncclBroadcast");
+  }
+  if (!fn) return UCE_ENOSYS;
+  const int rc = fn(buf, buf, bytes, /*ncclUint8*/ 1, root, comm, (hipStream_t)stream);
+  return rc == 0 ? UCE_OK : UCE_EHIP - 999;
+}
+
+}  // extern "C"

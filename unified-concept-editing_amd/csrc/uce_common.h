@@ -1,0 +1,70 @@
+// Shared declarations for libuce_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/uce_hip.h"
+
+#define UCE_HIP_TRY(expr)                                   \
+  do {                                                      \
+    hipError_t e_ = (expr);                                 \
+    if (e_ != hipSuccess) return UCE_EHIP - (int)e_;        \
+  } while (0)
+
+#define UCE_LAUNCH_CHECK()                                  \
+  do {                                                      \
+    hipError_t e_ = hipGetLastError();                      \
+    if (e_ != hipSuccess) return UCE_EHIP - (int)e_;        \
+  } while (0)
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+
+constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solves
+
+// Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
+// width and the largest SPD system (primal: n = d, dual: n = roundup(N, 64)) seen so far.
+struct uce_ctx {
+  int device;
+  int d_cap;      // embedding width capacity
+  int n_cap;      // SPD system capacity (multiple of 64)
+  double* M;      // [n_cap, n_cap]  system matrix, trailing tiles updated in place
+  double* Lmat;   // [n_cap, n_cap]  Cholesky factor (lower blocks)
+  double* Linv;   // [n_cap/64, 64, 64] inverses of the diagonal blocks of L
+  double* slabs;  // split-K partial sums of the Gram kernels
+  size_t slabs_bytes;
+  double* Bt;     // [d_cap, d_cap] right-hand side of the primal solve
+  double* Yg;     // [n_cap, d_cap] global scratch for the triangular solves when n > 1024
+  float* DeltaT;  // [d_cap, d_cap]
+  float* Dm;      // [n_cap, d_cap]
+  float* R;       // [n_cap, d_cap]
+  int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
+};
+
+// ---- internal launchers (defined across the .hip files) -------------------------------------
+int uce_ensure(uce_ctx* h, int d, int n);
+
+int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
+                       int d, float lamb, double* A, double* Bt, hipStream_t st);
+int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, float lamb, double* K,
+                     int n_pad, hipStream_t st);
+int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st);
+// X = M^-1 RHS after launch_potrf.  RHS is f64 [n, m] (rhs64) or f32 [rhs_rows, m] (rhs32, rows
+// beyond rhs_rows are zero).  out f32 [out_rows, m] gets rows 0..out_rows-1 of X.
+int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
+                    float* out, int out_rows, hipStream_t st);
+int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
+int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, float* W_new, long rows,
+                         int d, int N_edit, hipStream_t st);
+bool apply_lowrank_fits(int d, int N_edit);
+int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d, float* DeltaT,
+                              hipStream_t st);
+int launch_sub_rows(const float* G, const float* C, float* Dm, long n, hipStream_t st);
+int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
+                 int dh, float scale, int dtype, hipStream_t st);
+
+static __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}

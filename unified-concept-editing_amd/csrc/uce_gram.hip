@@ -1,0 +1,287 @@
+// Gram accumulation for the UCE closed form (reference: uce_sd_erase.py:56-79, the rank-1
+// `mat2 += s * c c^T` / `mat1 += s * v* c^T` loops; here done ONCE for all modules).
+//
+//   primal : A  = lambda I + C^T S C          [d,d]   (TN product over the N concepts)
+//            Bt = C_e^T S_e (G - C_e)         [d,d]
+//   dual   : K  = lambda S^-1 + C C^T         [n_pad,n_pad]  (NT product over the d features)
+//
+// fp32 inputs are widened to f64 in registers (products of two fp32 values are exact in f64)
+// and accumulated with v_mfma_f64_16x16x4_f64.  One workgroup = 4 waves = one 64x64 output
+// tile, each wave a 32x32 quadrant (2x2 MFMA tiles).  Split-K partial tiles go to slabs that a
+// reduction kernel sums in a fixed order (bit-repeatable; no atomics).
+#include "uce_common.h"
+
+namespace {
+
+constexpr int KC = 32;        // K-chunk staged in LDS per iteration
+constexpr int NT_LD = 40;     // row stride (floats) of the k-contiguous NT tiles: conflict-free b128
+
+// lower-triangular tile enumeration: t -> (ti, tj) with ti >= tj
+__device__ __forceinline__ void tri_decode(int t, int& ti, int& tj) {
+  int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((a + 1) * (a + 2) / 2 <= t) ++a;
+  while (a * (a + 1) / 2 > t) --a;
+  ti = a;
+  tj = t - a * (a + 1) / 2;
+}
+
+// store one wave's 32x32 quadrant held in 2x2 f64 MFMA accumulators
+__device__ __forceinline__ void store_quadrant(double* out, int ld, int row0, int col0,
+                                               const double4_t (&acc)[2][2], int lane, bool mirror,
+                                               double diag_val, const float* inv_s, float lamb,
+                                               int n_valid, bool add_diag) {
+  const int c = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + m * 16 + rq + 4 * r;
+        const int col = col0 + n * 16 + c;
+        double v = acc[m][n][r];
+        if (add_diag && row == col) {
+          if (inv_s) {
+            // a non-positive scale makes K indefinite: poison the pivot so potrf reports it
+            const float sv = (row < n_valid) ? inv_s[row] : 1.f;
+            v += (row < n_valid) ? ((sv > 0.f) ? (double)lamb / (double)sv : __builtin_nan("")) : 1.0;
+          }
+          else v += diag_val;
+        }
+        out[(size_t)row * ld + col] = v;
+        if (mirror) out[(size_t)col * ld + row] = v;
+      }
+}
+
+// ------------------------------------------------------------------------------------------
+// primal: tiles [0, nA) are the lower-triangular tiles of A, tiles [nA, nA + nb*nb) those of Bt
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gram_primal(const float* __restrict__ C,
+                                                     const float* __restrict__ G,
+                                                     const float* __restrict__ s, int N, int N_edit,
+                                                     int d, float lamb, double* __restrict__ outA,
+                                                     double* __restrict__ outBt, int kchunk,
+                                                     size_t slab_stride) {
+  __shared__ __attribute__((aligned(16))) float Xs[KC][64];
+  __shared__ __attribute__((aligned(16))) float Ys[KC][64];
+  __shared__ float Ss[KC];
+
+  const int nb = d / 64;
+  const int nA = nb * (nb + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  int ti, tj;
+  bool isA = (int)blockIdx.x < nA;
+  if (isA) tri_decode(blockIdx.x, ti, tj);
+  else { int t = blockIdx.x - nA; ti = t / nb; tj = t % nb; }
+  const int split = blockIdx.y;
+  const int Ktot = isA ? N : N_edit;
+  const int k_begin = split * kchunk;
+  const int k_end = min(Ktot, k_begin + kchunk);
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int lrow = tid >> 4;          // 0..15
+  const int lc4 = (tid & 15) * 4;     // 0..60
+  for (int k0 = k_begin; k0 < k_end; k0 += KC) {
+    // stage X = C[:, ti tile], Y = C[:, tj tile] (A) or (G - C)[:, tj tile] (Bt)
+#pragma unroll
+    for (int p = 0; p < KC / 16; ++p) {
+      const int kk = p * 16 + lrow;
+      const int n = k0 + kk;
+      float4_t x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+      if (n < k_end) {
+        x = *(const float4_t*)(C + (size_t)n * d + ti * 64 + lc4);
+        const float4_t cy = *(const float4_t*)(C + (size_t)n * d + tj * 64 + lc4);
+        if (isA) y = cy;
+        else y = *(const float4_t*)(G + (size_t)n * d + tj * 64 + lc4) - cy;
+      }
+      *(float4_t*)&Xs[kk][lc4] = x;
+      *(float4_t*)&Ys[kk][lc4] = y;
+    }
+    if (tid < KC) Ss[tid] = (k0 + tid < k_end) ? s[k0 + tid] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < KC / 4; ++kb) {
+      const int kk = kb * 4 + (lane >> 4);
+      const double sc = (double)Ss[kk];
+      const double a0 = (double)Xs[kk][wr * 32 + (lane & 15)] * sc;
+      const double a1 = (double)Xs[kk][wr * 32 + 16 + (lane & 15)] * sc;
+      const double b0 = (double)Ys[kk][wc * 32 + (lane & 15)];
+      const double b1 = (double)Ys[kk][wc * 32 + 16 + (lane & 15)];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  double* out = (isA ? outA : outBt) + (size_t)split * slab_stride;
+  store_quadrant(out, d, ti * 64 + wr * 32, tj * 64 + wc * 32, acc, lane, isA && ti != tj,
+                 (double)lamb, nullptr, lamb, 0, isA && split == 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// dual: K = lambda S^-1 + C C^T, n_pad = roundup(N, 64); rows >= N are zero with a unit diagonal
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gram_dual(const float* __restrict__ C,
+                                                   const float* __restrict__ s, int N, int d,
+                                                   float lamb, double* __restrict__ outK, int n_pad,
+                                                   int kchunk, size_t slab_stride) {
+  __shared__ __attribute__((aligned(16))) float As[64][NT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[64][NT_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  int ti, tj;
+  tri_decode(blockIdx.x, ti, tj);
+  const int split = blockIdx.y;
+  const int k_begin = split * kchunk;
+  const int k_end = min(d, k_begin + kchunk);
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int lrow = tid >> 3;        // 0..31
+  const int lc4 = (tid & 7) * 4;    // 0..28
+  for (int k0 = k_begin; k0 < k_end; k0 += KC) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = p * 32 + lrow;
+      float4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      const int ra = ti * 64 + r, rb = tj * 64 + r;
+      if (k0 + lc4 < k_end) {  // d is a multiple of 64, chunks are multiples of 32
+        if (ra < N) a = *(const float4_t*)(C + (size_t)ra * d + k0 + lc4);
+        if (rb < N) b = *(const float4_t*)(C + (size_t)rb * d + k0 + lc4);
+      }
+      *(float4_t*)&As[r][lc4] = a;
+      *(float4_t*)&Bs[r][lc4] = b;
+    }
+    __syncthreads();
+    // k permutation: in 16-k group u, MFMA t uses k = 16u + 4*(lane>>4) + t for BOTH operands
+#pragma unroll
+    for (int u = 0; u < KC / 16; ++u) {
+      const int kofs = u * 16 + 4 * (lane >> 4);
+      const float4_t fa0 = *(const float4_t*)&As[wr * 32 + (lane & 15)][kofs];
+      const float4_t fa1 = *(const float4_t*)&As[wr * 32 + 16 + (lane & 15)][kofs];
+      const float4_t fb0 = *(const float4_t*)&Bs[wc * 32 + (lane & 15)][kofs];
+      const float4_t fb1 = *(const float4_t*)&Bs[wc * 32 + 16 + (lane & 15)][kofs];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double a0 = (double)fa0[t], a1 = (double)fa1[t];
+        const double b0 = (double)fb0[t], b1 = (double)fb1[t];
+        acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+        acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+      }
+    }
+    __syncthreads();
+  }
+  double* out = outK + (size_t)split * slab_stride;
+  store_quadrant(out, n_pad, ti * 64 + wr * 32, tj * 64 + wc * 32, acc, lane, ti != tj, 0.0, s, lamb, N,
+                 split == 0);
+}
+
+// out[i] = sum over splits of slabs[split][i], fixed order
+__global__ void k_reduce_slabs(const double* __restrict__ slabs, size_t slab_stride, int nsplit,
+                               double* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = slabs[i];
+  for (int sidx = 1; sidx < nsplit; ++sidx) v += slabs[(size_t)sidx * slab_stride + i];
+  out[i] = v;
+}
+
+// G - C rows in fp32 (the low-rank left factor)
+__global__ void k_sub_rows(const float* __restrict__ G, const float* __restrict__ C,
+                           float* __restrict__ Dm, long n4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4_t g = ((const float4_t*)G)[i], c = ((const float4_t*)C)[i];
+  ((float4_t*)Dm)[i] = g - c;
+}
+
+}  // namespace
+
+static int pick_split(int tiles, int kchunks_total) {
+  if (tiles >= 128) return 1;
+  int want = (256 + tiles - 1) / tiles;
+  if (want > kchunks_total) want = kchunks_total;
+  return want < 1 ? 1 : want;
+}
+
+int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
+                       int d, float lamb, double* A, double* Bt, hipStream_t st) {
+  const int nb = d / 64;
+  const int tiles = nb * (nb + 1) / 2 + nb * nb;
+  const int chunks = (N + KC - 1) / KC;
+  int nsplit = pick_split(tiles, chunks);
+  int kchunk = ((chunks + nsplit - 1) / nsplit) * KC;
+  nsplit = (N + kchunk - 1) / kchunk;
+  const size_t mat = (size_t)d * d;
+  if (nsplit == 1) {
+    hipLaunchKernelGGL(k_gram_primal, dim3(tiles, 1), dim3(256), 0, st, C, G, s, N, N_edit, d, lamb, A, Bt,
+                       kchunk, (size_t)0);
+    UCE_LAUNCH_CHECK();
+    return UCE_OK;
+  }
+  // slabs: [nsplit][A | Bt]
+  const size_t need = (size_t)nsplit * 2 * mat * sizeof(double);
+  if (need > h->slabs_bytes) return UCE_ENOMEM;
+  double* sA = h->slabs;
+  double* sB = h->slabs + mat;
+  hipLaunchKernelGGL(k_gram_primal, dim3(tiles, nsplit), dim3(256), 0, st, C, G, s, N, N_edit, d, lamb, sA,
+                     sB, kchunk, 2 * mat);
+  UCE_LAUNCH_CHECK();
+  // a split whose k-range is beyond N_edit still writes zeros to its Bt slab, so both reduce fully
+  const int thr = 256;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
+                     (const double*)sA, 2 * mat, nsplit, A, mat);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
+                     (const double*)sB, 2 * mat, nsplit, Bt, mat);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, float lamb, double* K,
+                     int n_pad, hipStream_t st) {
+  const int nb = n_pad / 64;
+  const int tiles = nb * (nb + 1) / 2;
+  const int chunks = d / KC;
+  int nsplit = pick_split(tiles, chunks);
+  int kchunk = ((chunks + nsplit - 1) / nsplit) * KC;
+  nsplit = (d + kchunk - 1) / kchunk;
+  const size_t mat = (size_t)n_pad * n_pad;
+  if (nsplit == 1) {
+    hipLaunchKernelGGL(k_gram_dual, dim3(tiles, 1), dim3(256), 0, st, C, s, N, d, lamb, K, n_pad, kchunk,
+                       (size_t)0);
+    UCE_LAUNCH_CHECK();
+    return UCE_OK;
+  }
+  const size_t need = (size_t)nsplit * mat * sizeof(double);
+  if (need > h->slabs_bytes) return UCE_ENOMEM;
+  hipLaunchKernelGGL(k_gram_dual, dim3(tiles, nsplit), dim3(256), 0, st, C, s, N, d, lamb, h->slabs, n_pad,
+                     kchunk, mat);
+  UCE_LAUNCH_CHECK();
+  const int thr = 256;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
+                     (const double*)h->slabs, mat, nsplit, K, mat);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+int launch_sub_rows(const float* G, const float* C, float* Dm, long n, hipStream_t st) {
+  const long n4 = n / 4;
+  const int thr = 256;
+  hipLaunchKernelGGL(k_sub_rows, dim3((unsigned)((n4 + thr - 1) / thr)), dim3(thr), 0, st, G, C, Dm, n4);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}

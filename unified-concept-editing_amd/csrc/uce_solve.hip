@@ -1,0 +1,353 @@
+// f64 blocked Cholesky + triangular solves for the UCE normal equations
+// (reference: `torch.inverse(mat2.float())` at uce_sd_erase.py:82 / uce_sd_debias.py:140, an fp32
+// LU inverse recomputed per module; here ONE f64 SPD solve shared by all modules).
+//
+// Structure (block size 64, everything f64 on v_mfma_f64_16x16x4_f64):
+//   k_potrf_first : factor diagonal block 0            -> L_00, L_00^-1
+//   k_potrf_step j: one workgroup per trailing tile (i,k), j < k <= i:
+//                     P_i = M_ij L_jj^-T (= L_ij),  P_k = M_kj L_jj^-T,  M_ik -= P_i P_k^T
+//                   tile (i, j+1) publishes L_ij; tile (j+1, j+1) then factors itself.
+//   A chain of launches on one stream replaces grid barriers (a kernel boundary is ~1.5 us on
+//   MI355X, cheaper than any software grid barrier, and needs no residency assumptions).
+//   k_trisolve    : one workgroup per 16 right-hand-side columns: forward then backward
+//                   substitution with the inverted diagonal blocks; Y lives in LDS (n <= 1024).
+#include "uce_common.h"
+
+namespace {
+
+constexpr int LD = 66;  // row stride (doubles) of the 64x64 LDS tiles: conflict-free ds_read_b64
+
+__device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
+  a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((a + 1) * (a + 2) / 2 <= t) ++a;
+  while (a * (a + 1) / 2 > t) --a;
+  b = t - a * (a + 1) / 2;
+}
+
+// In-LDS Cholesky of a 64x64 SPD block T (lower triangle used) by 256 threads; on exit the
+// lower triangle of T holds L, the upper triangle is zeroed, and X holds L^-1 (lower).
+__device__ void potrf64_lds(double (*T)[LD], double (*X)[LD], int tid, int* status, int col_base) {
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    X[i][j] = (i == j) ? 1.0 : 0.0;
+    if (j > i) T[i][j] = 0.0;
+  }
+  const int i = tid >> 2;  // row handled in the update phase
+  const int q = tid & 3;   // column residue
+  for (int k = 0; k < 64; ++k) {
+    __syncthreads();
+    double piv = T[k][k];
+    if (!(piv > 0.0)) {
+      if (tid == 0) atomicCAS(status, 0, col_base + k + 1);
+      piv = 1.0;
+    }
+    const double rinv = 1.0 / sqrt(piv);
+    __syncthreads();
+    // scale column k of L and row k of X
+    if (tid < 64) {
+      if (tid > k) T[tid][k] *= rinv;
+      else if (tid == k) T[k][k] = piv * rinv;
+    } else if (tid < 128) {
+      const int c = tid - 64;
+      if (c <= k) X[k][c] *= rinv;
+    }
+    __syncthreads();
+    if (i > k) {
+      const double lik = T[i][k];
+#pragma unroll 4
+      for (int j = q; j < 64; j += 4) {
+        if (j > k) {
+          if (j <= i) T[i][j] -= lik * T[j][k];
+        } else {
+          X[i][j] -= lik * X[k][j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_potrf_first(const double* __restrict__ M, int n,
+                                                     double* __restrict__ Lmat,
+                                                     double* __restrict__ Linv, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double (*T)[LD] = (double (*)[LD])smem_raw;
+  double (*X)[LD] = (double (*)[LD])(smem_raw + 64 * LD * 8);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    T[i][j] = M[(size_t)i * n + j];
+  }
+  __syncthreads();
+  potrf64_lds(T, X, tid, status, 0);
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    Lmat[(size_t)i * n + j] = T[i][j];
+    Linv[e] = X[i][j];
+  }
+}
+
+// one wave's 32x32 quadrant of  acc += sign * P[rows] * Q[cols]^T  (both tiles row-major in LDS,
+// contraction index contiguous)
+__device__ __forceinline__ void quad_nt(double4_t (&acc)[2][2], const double (*P)[LD],
+                                        const double (*Q)[LD], int row0, int col0, int lane,
+                                        double sign) {
+  const int r = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+  for (int kb = 0; kb < 16; ++kb) {
+    const int t = kb * 4 + kk;
+    const double a0 = sign * P[row0 + r][t], a1 = sign * P[row0 + 16 + r][t];
+    const double b0 = Q[col0 + r][t], b1 = Q[col0 + 16 + r][t];
+    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+  }
+}
+
+__device__ __forceinline__ void quad_zero(double4_t (&acc)[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+}
+
+// accumulator quadrant <-> memory (D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4r, col = lane&15)
+template <typename F>
+__device__ __forceinline__ void quad_foreach(int row0, int col0, int lane, F f) {
+  const int c = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(m, n, r, row0 + m * 16 + rq + 4 * r, col0 + n * 16 + c);
+}
+
+__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ M, int n, int j,
+                                                    double* __restrict__ Lmat,
+                                                    double* __restrict__ Linv, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double (*Li)[LD] = (double (*)[LD])smem_raw;                       // L_jj^-1
+  double (*Mi)[LD] = (double (*)[LD])(smem_raw + 64 * LD * 8);       // M_ij  -> P_i
+  double (*Mk)[LD] = (double (*)[LD])(smem_raw + 2 * 64 * LD * 8);   // M_kj  -> P_k
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+  int a, b;
+  tri_decode(blockIdx.x, a, b);
+  const int i = j + 1 + a, k = j + 1 + b;
+  const bool diag = (i == k);
+
+  const double* Linv_j = Linv + (size_t)j * 64 * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Li[r][c] = Linv_j[e];
+    Mi[r][c] = M[(size_t)(i * 64 + r) * n + j * 64 + c];
+    if (!diag) Mk[r][c] = M[(size_t)(k * 64 + r) * n + j * 64 + c];
+  }
+  __syncthreads();
+
+  // P_i = M_ij L_jj^-T ; P_k likewise
+  double4_t pi[2][2], pk[2][2];
+  quad_zero(pi);
+  quad_nt(pi, Mi, Li, wr, wc, lane, 1.0);
+  if (!diag) {
+    quad_zero(pk);
+    quad_nt(pk, Mk, Li, wr, wc, lane, 1.0);
+  }
+  __syncthreads();
+  quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pi[m][nn][r]; });
+  if (!diag)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pk[m][nn][r]; });
+  __syncthreads();
+
+  // tile (i, j+1) publishes L_ij
+  if (k == j + 1) {
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      Lmat[(size_t)(i * 64 + r) * n + j * 64 + c] = Mi[r][c];
+    }
+  }
+
+  // M_ik -= P_i P_k^T
+  double4_t acc[2][2];
+  quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+    acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
+  });
+  quad_nt(acc, Mi, diag ? Mi : Mk, wr, wc, lane, -1.0);
+
+  if (!(diag && i == j + 1)) {
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+      M[(size_t)(i * 64 + row) * n + k * 64 + col] = acc[m][nn][r];
+    });
+    return;
+  }
+  // the next diagonal block: factor it now (Li <- tile, Mk <- inverse)
+  __syncthreads();
+  quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
+  __syncthreads();
+  potrf64_lds(Li, Mk, tid, status, i * 64);
+  double* Linv_n = Linv + (size_t)i * 64 * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Lmat[(size_t)(i * 64 + r) * n + i * 64 + c] = Li[r][c];
+    Linv_n[e] = Mk[r][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// triangular solves: X = L^-T L^-1 RHS for 16 columns per workgroup
+// ------------------------------------------------------------------------------------------
+template <bool RHS32>
+__global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lmat,
+                                                  const double* __restrict__ Linv, int n, int m,
+                                                  const double* __restrict__ rhs64,
+                                                  const float* __restrict__ rhs32, int rhs_rows,
+                                                  float* __restrict__ out, int out_rows,
+                                                  double* __restrict__ Yg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double (*tmp)[16] = (double (*)[16])smem_raw;          // [64][16]
+  double* Ylds = (double*)(smem_raw + 64 * 16 * 8);      // [n][16] when it fits
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c0 = blockIdx.x * 16;
+  const int c = lane & 15, kk = lane >> 4;
+  const int nb = n / 64;
+  // Y addressing: LDS [n][16] or global scratch [n][m]
+  double* Y = Yg ? (Yg + c0) : Ylds;
+  const int ldy = Yg ? m : 16;
+
+  // ---------------- forward: Y_k = Linv_kk (RHS_k - sum_{j<k} L_kj Y_j)
+  for (int kb = 0; kb < nb; ++kb) {
+    const int r0 = kb * 64 + w * 16;  // this wave's 16 rows
+    double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + kk + 4 * r;
+      double v;
+      if (RHS32) v = (row < rhs_rows) ? (double)rhs32[(size_t)row * m + c0 + c] : 0.0;
+      else v = rhs64[(size_t)row * m + c0 + c];
+      acc0[r] = v;
+    }
+    const double* Lrow = Lmat + (size_t)(r0 + c) * n;  // A operand: row = r0 + (lane&15)
+    for (int jb = 0; jb < kb; ++jb) {
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        const int k0 = jb * 64 + t * 4 + kk;
+        const double a0 = -Lrow[k0], a1 = -Lrow[k0 + 4];
+        const double b0 = Y[(size_t)k0 * ldy + c], b1 = Y[(size_t)(k0 + 4) * ldy + c];
+        acc0 = mfma_f64(a0, b0, acc0);
+        acc1 = mfma_f64(a1, b1, acc1);
+      }
+    }
+    acc0 += acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmp[w * 16 + kk + 4 * r][c] = acc0[r];
+    __syncthreads();
+    const double* Li = Linv + (size_t)kb * 64 * 64 + (size_t)(w * 16 + c) * 64;
+    double4_t y0 = (double4_t){0.0, 0.0, 0.0, 0.0}, y1 = y0;
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      const int k0 = t * 4 + kk;
+      y0 = mfma_f64(Li[k0], tmp[k0][c], y0);
+      y1 = mfma_f64(Li[k0 + 4], tmp[k0 + 4][c], y1);
+    }
+    y0 += y1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y[(size_t)(r0 + kk + 4 * r) * ldy + c] = y0[r];
+    __syncthreads();
+  }
+
+  // ---------------- backward: X_k = Linv_kk^T (Y_k - sum_{j>k} L_jk^T X_j)
+  for (int kb = nb - 1; kb >= 0; --kb) {
+    const int r0 = kb * 64 + w * 16;
+    double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[r] = Y[(size_t)(r0 + kk + 4 * r) * ldy + c];
+    for (int jb = nb - 1; jb > kb; --jb) {
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        const int k0 = jb * 64 + t * 4 + kk;
+        // A[i][k] = L[k][r0 + i]
+        const double a0 = -Lmat[(size_t)k0 * n + r0 + c], a1 = -Lmat[(size_t)(k0 + 4) * n + r0 + c];
+        const double b0 = Y[(size_t)k0 * ldy + c], b1 = Y[(size_t)(k0 + 4) * ldy + c];
+        acc0 = mfma_f64(a0, b0, acc0);
+        acc1 = mfma_f64(a1, b1, acc1);
+      }
+    }
+    acc0 += acc1;
+    __syncthreads();  // every wave has finished reading Y_k rows of this block before tmp reuse
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmp[w * 16 + kk + 4 * r][c] = acc0[r];
+    __syncthreads();
+    const double* Li = Linv + (size_t)kb * 64 * 64;
+    double4_t x0 = (double4_t){0.0, 0.0, 0.0, 0.0}, x1 = x0;
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      const int k0 = t * 4 + kk;
+      // A[i][k] = Linv[k][w*16 + i]
+      x0 = mfma_f64(Li[(size_t)k0 * 64 + w * 16 + c], tmp[k0][c], x0);
+      x1 = mfma_f64(Li[(size_t)(k0 + 4) * 64 + w * 16 + c], tmp[k0 + 4][c], x1);
+    }
+    x0 += x1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + kk + 4 * r;
+      Y[(size_t)row * ldy + c] = x0[r];
+      if (row < out_rows) out[(size_t)row * m + c0 + c] = (float)x0[r];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
+  const int nb = n / 64;
+  const size_t smem = 3 * 64 * LD * sizeof(double);
+  const size_t smem_first = 2 * 64 * LD * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_first, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem_first));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(256), smem_first, st, (const double*)M, n, h->Lmat,
+                     h->Linv, h->status);
+  UCE_LAUNCH_CHECK();
+  for (int j = 0; j + 1 < nb; ++j) {
+    const int mt = nb - j - 1;
+    const int tiles = mt * (mt + 1) / 2;
+    hipLaunchKernelGGL(k_potrf_step, dim3(tiles), dim3(256), smem, st, M, n, j, h->Lmat, h->Linv,
+                       h->status);
+    UCE_LAUNCH_CHECK();
+  }
+  return UCE_OK;
+}
+
+int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
+                    float* out, int out_rows, hipStream_t st) {
+  const bool use_lds = n <= 1024;
+  const size_t smem = 64 * 16 * 8 + (use_lds ? (size_t)n * 16 * 8 : 0);
+  double* Yg = use_lds ? nullptr : h->Yg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int cap = 64 * 16 * 8 + 1024 * 16 * 8;
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trisolve<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trisolve<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_set = true;
+  }
+  const dim3 grid(m / 16);
+  if (rhs32)
+    hipLaunchKernelGGL(k_trisolve<true>, grid, dim3(256), smem, st, (const double*)h->Lmat,
+                       (const double*)h->Linv, n, m, rhs64, rhs32, rhs_rows, out, out_rows, Yg);
+  else
+    hipLaunchKernelGGL(k_trisolve<false>, grid, dim3(256), smem, st, (const double*)h->Lmat,
+                       (const double*)h->Linv, n, m, rhs64, rhs32, rhs_rows, out, out_rows, Yg);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}

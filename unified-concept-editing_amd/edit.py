@@ -1,0 +1,338 @@
+"""Host side of the closed-form UCE edit: the drop-in for `UCE()` of the reference's
+trainscripts/uce_sd_erase.py:12-91 and trainscripts/uce_sd_debias.py:37-149.
+
+What stays in Python (plumbing): module discovery by name, text-embedding extraction through
+whatever pipeline object is handed in, packing every attn2.to_k/to_v weight into ONE [rows, d]
+fp32 slab in HBM, the safetensors artifact.  What runs in hand-written HIP through the C ABI
+(include/uce_hip.h): everything the reference does at :45-82 - Gram accumulation, the SPD
+solve and the weight update - once for all modules instead of per module.
+
+There is no CPU fallback: without libuce_hip.so / a GPU these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+torch.set_grad_enabled(False)
+
+
+# --------------------------------------------------------------------------------------------
+# handle + thin wrappers over the C ABI (device tensors in, device tensors out)
+# --------------------------------------------------------------------------------------------
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class UceHandle:
+    """One per GPU.  Owns the library workspace (uce_create / uce_destroy)."""
+
+    _cache: Dict[int, "UceHandle"] = {}
+
+    def __init__(self, device: torch.device | str | int = "cuda:0"):
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise RuntimeError(f"uce_amd runs on an MI355X (device 'cuda:N' under ROCm), not on {self.device}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the UCE edit has no CPU path")
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.index)
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.uce_create(ctypes.byref(h), self.index), "uce_create")
+        self._h = h
+
+    @classmethod
+    def get(cls, device) -> "UceHandle":
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if idx not in cls._cache:
+            cls._cache[idx] = cls(torch.device("cuda", idx))
+        return cls._cache[idx]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.uce_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- one wrapper per entry point -------------------------------------------------------
+    def reserve(self, d_max: int, n_max: int) -> None:
+        _lib.check(self.lib.uce_reserve(self._h, d_max, n_max), "uce_reserve")
+
+    def gram(self, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor, lamb: float):
+        N, d = C.shape
+        Ne = 0 if G is None else G.shape[0]
+        A = torch.empty(d, d, dtype=torch.float64, device=self.device)
+        Bt = torch.empty(d, d, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.uce_gram(self._h, _ptr(C), _ptr(G), _ptr(s), N, Ne, d, float(lamb), _ptr(A), _ptr(Bt),
+                                     _stream_ptr(self.device)), "uce_gram")
+        return A, Bt
+
+    def solve_delta(self, A: torch.Tensor, Bt: torch.Tensor) -> torch.Tensor:
+        d = A.shape[0]
+        DeltaT = torch.empty(d, d, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_solve_delta(self._h, _ptr(A), _ptr(Bt), d, _ptr(DeltaT), _stream_ptr(self.device)),
+                   "uce_solve_delta")
+        return DeltaT
+
+    def apply(self, W_old: torch.Tensor, DeltaT: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rows, d = W_old.shape
+        out = torch.empty_like(W_old) if out is None else out
+        _lib.check(self.lib.uce_apply(self._h, _ptr(W_old), _ptr(DeltaT), _ptr(out), rows, d,
+                                      _stream_ptr(self.device)), "uce_apply")
+        return out
+
+    def dual_factors(self, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor, lamb: float):
+        N, d = C.shape
+        Ne = 0 if G is None else G.shape[0]
+        Dm = torch.empty(max(Ne, 1), d, dtype=torch.float32, device=self.device)
+        R = torch.empty(max(Ne, 1), d, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_dual_factors(self._h, _ptr(C), _ptr(G), _ptr(s), N, Ne, d, float(lamb), _ptr(Dm),
+                                             _ptr(R), _stream_ptr(self.device)), "uce_dual_factors")
+        return Dm[:Ne], R[:Ne]
+
+    def apply_lowrank(self, W_old: torch.Tensor, Dm: torch.Tensor, R: torch.Tensor,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rows, d = W_old.shape
+        out = torch.empty_like(W_old) if out is None else out
+        _lib.check(self.lib.uce_apply_lowrank(self._h, _ptr(W_old), _ptr(Dm), _ptr(R), _ptr(out), rows, d,
+                                              Dm.shape[0], _stream_ptr(self.device)), "uce_apply_lowrank")
+        return out
+
+    def delta_from_factors(self, Dm: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
+        Ne, d = Dm.shape
+        DeltaT = torch.empty(d, d, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_delta_from_factors(self._h, _ptr(Dm), _ptr(R), Ne, d, _ptr(DeltaT),
+                                                   _stream_ptr(self.device)), "uce_delta_from_factors")
+        return DeltaT
+
+    def edit(self, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor, lamb: float, W_old: torch.Tensor,
+             out: Optional[torch.Tensor] = None, algo: int = _lib.ALGO_AUTO, check: bool = False) -> torch.Tensor:
+        N, d = C.shape
+        Ne = 0 if G is None else G.shape[0]
+        rows = W_old.shape[0]
+        out = torch.empty_like(W_old) if out is None else out
+        _lib.check(self.lib.uce_edit(self._h, _ptr(C), _ptr(G), _ptr(s), N, Ne, d, float(lamb), _ptr(W_old),
+                                     _ptr(out), rows, algo, _stream_ptr(self.device)), "uce_edit")
+        if check:
+            self.status()
+        return out
+
+    def status(self) -> None:
+        info = ctypes.c_int(0)
+        rc = self.lib.uce_status(self._h, ctypes.byref(info), _stream_ptr(self.device))
+        if rc == _lib.EDOM:
+            raise _lib.UceError(rc, f"solve (leading minor {info.value} is not positive definite)")
+        _lib.check(rc, "uce_status")
+
+    def debias_targets(self, C_edit: torch.Tensor, C_debias: torch.Tensor, Dsum: torch.Tensor) -> torch.Tensor:
+        Ne, d = C_edit.shape
+        Nd = C_debias.shape[0]
+        G = torch.empty_like(C_edit)
+        _lib.check(self.lib.uce_debias_targets(self._h, _ptr(C_edit), _ptr(C_debias), _ptr(Dsum), Ne, Nd, d,
+                                               _ptr(G), _stream_ptr(self.device)), "uce_debias_targets")
+        return G
+
+    def cast_bf16(self, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+        assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+        _lib.check(self.lib.uce_cast_bf16(self._h, _ptr(src), _ptr(dst), src.numel(), _stream_ptr(self.device)),
+                   "uce_cast_bf16")
+        return dst
+
+    def xattn(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, Lq, Cc = q.shape
+        Lk = k.shape[1]
+        dh = Cc // heads
+        scale = dh ** -0.5 if scale is None else scale
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[q.dtype]
+        out = torch.empty_like(q) if out is None else out
+        _lib.check(self.lib.uce_xattn_fwd(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Lq, Lk, dh,
+                                          float(scale), dt, _stream_ptr(self.device)), "uce_xattn_fwd")
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# module discovery + the weight slab  (uce_sd_erase.py:15-22)
+# --------------------------------------------------------------------------------------------
+
+def is_uce_module(name: str) -> bool:
+    """The reference's name predicate (uce_sd_erase.py:18)."""
+    return "attn2" in name and (name.endswith("to_v") or name.endswith("to_k"))
+
+
+def collect_uce_modules(unet: torch.nn.Module) -> List[Tuple[str, torch.nn.Module]]:
+    return [(n, m) for n, m in unet.named_modules() if is_uce_module(n)]
+
+
+@dataclass
+class WeightSlab:
+    """Every edited projection's weight, concatenated along rows: [sum(o_m), d] fp32."""
+    names: List[str]
+    offsets: List[int]      # row offset of each module
+    rows: List[int]
+    data: torch.Tensor      # [sum rows, d]
+
+    @classmethod
+    def from_modules(cls, modules: Sequence[Tuple[str, torch.nn.Module]], device) -> "WeightSlab":
+        if not modules:
+            raise ValueError("no attn2.to_k / attn2.to_v modules found in the U-Net")
+        d = modules[0][1].weight.shape[1]
+        rows = [int(m.weight.shape[0]) for _, m in modules]
+        offs = [0]
+        for r in rows[:-1]:
+            offs.append(offs[-1] + r)
+        data = torch.empty(sum(rows), d, dtype=torch.float32, device=device)
+        for (n, m), o, r in zip(modules, offs, rows):
+            if m.weight.shape[1] != d:
+                raise ValueError(f"{n}: in_features {m.weight.shape[1]} != {d}")
+            data[o:o + r].copy_(m.weight.detach())
+        return cls([n for n, _ in modules], offs, rows, data)
+
+    def like(self, data: torch.Tensor) -> "WeightSlab":
+        return WeightSlab(self.names, self.offsets, self.rows, data)
+
+    def views(self) -> List[torch.Tensor]:
+        return [self.data[o:o + r] for o, r in zip(self.offsets, self.rows)]
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Keys `<module path>.weight` like uce_sd_erase.py:85-87."""
+        return {n + ".weight": v for n, v in zip(self.names, self.views())}
+
+
+def save_uce_state(slab: WeightSlab, save_dir: str, exp_name: str) -> str:
+    """safetensors artifact `{save_dir}/{exp_name}.safetensors` (uce_sd_erase.py:85-88)."""
+    from safetensors.torch import save_file
+    path = os.path.join(save_dir, exp_name + ".safetensors")
+    save_file({k: v.detach().cpu().contiguous() for k, v in slab.state_dict().items()}, path)
+    return path
+
+
+# --------------------------------------------------------------------------------------------
+# concept embeddings  (uce_sd_erase.py:25-42)
+# --------------------------------------------------------------------------------------------
+
+def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[Dict[str, torch.Tensor]] = None
+                          ) -> Dict[str, torch.Tensor]:
+    """Per UNIQUE string: text-encoder hidden state at index `attention_mask.sum() - 2`
+    (the last real token; '' -> the BOS position).  Returns {prompt: [d] fp32 on `device`}."""
+    out = {} if cache is None else cache
+    for e in prompts:
+        if e in out:
+            continue
+        t_emb = pipe.encode_prompt(prompt=e, device=device, num_images_per_prompt=1,
+                                   do_classifier_free_guidance=False)
+        mask = pipe.tokenizer(e, padding="max_length", max_length=pipe.tokenizer.model_max_length,
+                              truncation=True, return_tensors="pt")["attention_mask"]
+        idx = int(mask.sum()) - 2
+        out[e] = t_emb[0][0, idx, :].to(device=device, dtype=torch.float32)
+    return out
+
+
+def concept_matrices(embeds: Dict[str, torch.Tensor], edit: Sequence[str], guide: Sequence[str],
+                     preserve: Sequence[str], erase_scale: float, preserve_scale: float, device
+                     ) -> Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
+    """C [N,d] (edit rows in list order, then preserve rows), G [N_e,d], s [N].  The sums of
+    the reference iterate over the LISTS (uce_sd_erase.py:66,74), so duplicates stay."""
+    if len(edit) != len(guide):
+        raise ValueError("edit and guide concept lists differ in length")
+    rows = [embeds[e] for e in edit] + [embeds[p] for p in preserve]
+    C = torch.stack(rows).to(device=device, dtype=torch.float32).contiguous()
+    G = torch.stack([embeds[g] for g in guide]).to(device=device, dtype=torch.float32).contiguous() if edit else None
+    s = torch.tensor([float(erase_scale)] * len(edit) + [float(preserve_scale)] * len(preserve),
+                     dtype=torch.float32, device=device)
+    return C, G, s
+
+
+def drop_zero_scale_rows(C, G, s, n_edit: int):
+    """Rows with scale 0 contribute nothing to either sum; remove them (the dual form divides by s)."""
+    keep = (s != 0)
+    if bool(keep.all()):
+        return C, G, s, n_edit
+    ke = keep[:n_edit]
+    G2 = G[ke].contiguous() if G is not None else None
+    return C[keep].contiguous(), G2, s[keep].contiguous(), int(ke.sum())
+
+
+# --------------------------------------------------------------------------------------------
+# the drop-in entry points
+# --------------------------------------------------------------------------------------------
+
+def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor,
+              lamb: float, algo: int = _lib.ALGO_AUTO) -> WeightSlab:
+    n_edit = 0 if G is None else G.shape[0]
+    C, G, s, n_edit = drop_zero_scale_rows(C, G, s, n_edit)
+    if C.shape[0] == 0 or n_edit == 0:
+        # nothing pulls the weights anywhere: W_new = W_old exactly (Delta = 0)
+        return slab.like(slab.data.clone())
+    if G is not None and G.shape[0] == 0:
+        G = None
+    out = handle.edit(C, G, s, lamb, slab.data, algo=algo, check=True)
+    return slab.like(out)
+
+
+def UCE(pipe, edit_concepts, guide_concepts, preserve_concepts, erase_scale, preserve_scale, lamb, save_dir,
+        exp_name, device: str = "cuda:0", algo: int = _lib.ALGO_AUTO, return_slab: bool = False):
+    """Same positional signature and artifact as the reference's UCE() (uce_sd_erase.py:12);
+    `device` replaces the module global the reference reads."""
+    start_time = time.time()
+    dev = torch.device(device)
+    handle = UceHandle.get(dev)
+    modules = collect_uce_modules(pipe.unet)
+    slab = WeightSlab.from_modules(modules, handle.device)
+    embeds = last_token_embeddings(pipe, list(edit_concepts) + list(guide_concepts) + list(preserve_concepts),
+                                   handle.device)
+    C, G, s = concept_matrices(embeds, edit_concepts, guide_concepts, preserve_concepts, erase_scale,
+                               preserve_scale, handle.device)
+    new = edit_slab(handle, slab, C, G, s, lamb, algo)
+    path = save_uce_state(new, save_dir, exp_name)
+    end_time = time.time()
+    print(f"\n\nErased concepts using UCE\nModel edited in {end_time - start_time} seconds\n")
+    return (new, path) if return_slab else None
+
+
+class DebiasState:
+    """Iteration state of the debias loop (uce_sd_debias.py:95-141) in closed form: the drift
+    the reference adds in place to its cached guide outputs accumulates, and every iteration
+    re-solves from W_old, so the weights after iteration t depend only on sum_{t'<=t} D_t'."""
+
+    def __init__(self, handle: UceHandle, slab: WeightSlab, C_edit: torch.Tensor, C_debias: torch.Tensor,
+                 C_pres: Optional[torch.Tensor], edit_scale: float, preserve_scale: float, lamb: float):
+        self.handle, self.slab, self.lamb = handle, slab, lamb
+        self.C_edit, self.C_debias = C_edit, C_debias
+        n_e = C_edit.shape[0]
+        n_p = 0 if C_pres is None else C_pres.shape[0]
+        self.C = torch.cat([C_edit] + ([C_pres] if n_p else [])).contiguous()
+        self.s = torch.tensor([float(edit_scale)] * n_e + [float(preserve_scale)] * n_p, dtype=torch.float32,
+                              device=handle.device)
+        self.Dsum = torch.zeros(n_e, C_debias.shape[0], dtype=torch.float64, device=handle.device)
+        self.current = slab.like(slab.data.clone())
+
+    def step(self, direction_scale: np.ndarray) -> WeightSlab:
+        self.Dsum += torch.as_tensor(np.asarray(direction_scale, dtype=np.float64), device=self.handle.device)
+        G = self.handle.debias_targets(self.C_edit, self.C_debias, self.Dsum)
+        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb)
+        return self.current

@@ -1,0 +1,52 @@
+"""Synthetic inputs of the right shape and geometry for benchmarks and self-checks: there are
+no model weights, tokenizer vocabularies or datasets on the machines this runs on."""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import numpy as np
+
+
+def sd14_module_table() -> List[Tuple[str, int]]:
+    """(module path, out_features) of SD-1.x's 32 cross-attention K/V projections
+    (in_features 768), in `unet.named_modules()` order: down, up, mid."""
+    spec = [("down_blocks.0", 2, 320), ("down_blocks.1", 2, 640), ("down_blocks.2", 2, 1280),
+            ("up_blocks.1", 3, 1280), ("up_blocks.2", 3, 640), ("up_blocks.3", 3, 320), ("mid_block", 1, 1280)]
+    rows = []
+    for prefix, n_attn, width in spec:
+        for a in range(n_attn):
+            for proj in ("to_k", "to_v"):
+                rows.append((f"{prefix}.attentions.{a}.transformer_blocks.0.attn2.{proj}", width))
+    return rows
+
+
+def sdxl_module_table() -> List[Tuple[str, int]]:
+    """SDXL-base: 70 transformer blocks -> 140 projections (in_features 2048)."""
+    spec = [("down_blocks.1", 2, 2, 640), ("down_blocks.2", 2, 10, 1280), ("up_blocks.0", 3, 10, 1280),
+            ("up_blocks.1", 3, 2, 640), ("mid_block", 1, 10, 1280)]
+    rows = []
+    for prefix, n_attn, depth, width in spec:
+        for a in range(n_attn):
+            for t in range(depth):
+                for proj in ("to_k", "to_v"):
+                    rows.append((f"{prefix}.attentions.{a}.transformer_blocks.{t}.attn2.{proj}", width))
+    return rows
+
+
+def clip_like_embeddings(n: int, d: int, seed: int, norm: float = 28.0, cosine: float = 0.64) -> np.ndarray:
+    """Last-token text embeddings with CLIP-like geometry: a shared direction plus isotropic
+    noise, all rows of norm `norm`, mean pairwise cosine ~ `cosine`."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u = rng.standard_normal(d)
+    u /= np.linalg.norm(u)
+    z = rng.standard_normal((n, d))
+    z -= np.outer(z @ u, u)
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    return (norm * (math.sqrt(cosine) * u[None, :] + math.sqrt(1.0 - cosine) * z)).astype(np.float32)
+
+
+def linear_default_weight(o: int, d: int, rng: np.random.Generator) -> np.ndarray:
+    """nn.Linear's default init range U(-1/sqrt(d), 1/sqrt(d))."""
+    bound = 1.0 / math.sqrt(d)
+    return rng.uniform(-bound, bound, size=(o, d)).astype(np.float32)
