@@ -94,7 +94,7 @@ def test_apply_matches_f64(H, rows_, d):
     DT[0, 1] += 3.0
     out = H.apply(_dev(W), _dev(DT))
     want = W.astype(np.float64) + W.astype(np.float64) @ DT.astype(np.float64).T
-    assert O.rel_fro(out.cpu(), want) < 3e-7
+    assert O.rel_fro(out.cpu(), want) < 2e-6      # 768-term f32 fmaf chains
 
 
 @pytest.mark.parametrize("N,Ne,d", [(5, 2, 64), (50, 50, 768), (64, 10, 128), (300, 200, 768), (40, 36, 2048),
@@ -264,7 +264,8 @@ def test_full_size_properties(H, N_e, N_p):
     v_new = out.double() @ C64[:N_e].T
     v_tgt = W64 @ Gd.double().T
     v_old = W64 @ C64[:N_e].T
-    assert float((v_new - v_tgt).norm() / (v_old - v_tgt).norm()) < 0.2
+    # (1000 concepts cannot all be moved exactly in a 768-d space: the bound is looser there)
+    assert float((v_new - v_tgt).norm() / (v_old - v_tgt).norm()) < (0.2 if N < d else 0.5)
     if N_p:
         p_new = out.double() @ C64[N_e:].T
         p_old = W64 @ C64[N_e:].T
