@@ -149,15 +149,15 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
   int rc = uce_ensure(h, d, n_pad);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  UCE_HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int), st));
-  rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, st);
+  int nsplit = 1;
+  size_t slab_stride = 0;
+  rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, G, Dm, N_edit, &nsplit, &slab_stride, st);
   if (rc) return rc;
-  rc = launch_potrf(h, h->M, n_pad, st);
+  rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
+                    : launch_potrf(h, h->M, n_pad, st);
   if (rc) return rc;
   if (N_edit == 0) return UCE_OK;
-  rc = launch_trisolve(h, n_pad, d, nullptr, C, N, R, N_edit, st);
-  if (rc) return rc;
-  return launch_sub_rows(G, C, Dm, (long)N_edit * d, st);
+  return launch_trisolve(h, n_pad, d, nullptr, C, N, R, N_edit, st);
 }
 
 int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int N_edit, int d,

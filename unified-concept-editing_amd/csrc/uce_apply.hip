@@ -250,7 +250,7 @@ namespace {
 
 constexpr int LR_BM = 16;
 
-__global__ __launch_bounds__(256, 2) void k_apply_lowrank(const float* __restrict__ W_old,
+__global__ __launch_bounds__(256, 2) void k_apply_lowrank_generic(const float* __restrict__ W_old,
                                                           const float* __restrict__ Dm,
                                                           const float* __restrict__ R,
                                                           float* __restrict__ W_new, long rows, int d,
@@ -276,42 +276,61 @@ __global__ __launch_bounds__(256, 2) void k_apply_lowrank(const float* __restric
   }
   __syncthreads();
 
-  // ---- phase 1: this wave's K quarter for every 16-column tile of T
+  // ---- phase 1: this wave's K quarter for every 16-column tile of T.
+  // Work units u = (column tile ct, chunk of 4 16-k groups); the Dm fragments of unit u+1 are
+  // fetched (L2 latency ~1-2k cycles) while the MFMAs of unit u run.
   const int kq = d >> 2;               // floats per K quarter (multiple of 16)
   const int kbeg = w * kq;
+  const int ngrp1 = kq >> 4;           // 16-k groups in the quarter
+  const int nchunk = (ngrp1 + 3) >> 2;
   const int nct = NEP >> 4;
-  for (int ct = 0; ct < nct; ++ct) {
-    float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  const int nunit = nct * nchunk;
+  const float* wrow = Ws + li * wld + kbeg + 4 * lk;
+
+  auto load_unit = [&](int u, float4_t (&b)[4]) {
+    const int ct = u / nchunk, g0 = (u - ct * nchunk) << 2;
     const int e_row = ct * 16 + li;
-    const bool valid = e_row < Ne;
-    const float* drow = Dm + (size_t)(valid ? e_row : 0) * d + kbeg + 4 * lk;
-    const float* wrow = Ws + li * wld + kbeg + 4 * lk;
-    int u = 0;
-#pragma unroll 2
-    for (; u + 32 <= kq; u += 32) {
-      // k permutation: MFMA t of 16-k group g uses k = 16g + 4*(lane>>4) + t on both operands
-      float4_t b0 = *(const float4_t*)(drow + u);
-      float4_t b1 = *(const float4_t*)(drow + u + 16);
-      if (!valid) { b0 = (float4_t){0.f, 0.f, 0.f, 0.f}; b1 = b0; }
-      const float4_t a0 = *(const float4_t*)(wrow + u);
-      const float4_t a1 = *(const float4_t*)(wrow + u + 16);
+    const float* drow = Dm + (size_t)(e_row < Ne ? e_row : 0) * d + kbeg + 4 * lk;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b1[t], acc1, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      b[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      if (e_row < Ne && g0 + t < ngrp1) b[t] = *(const float4_t*)(drow + (g0 + t) * 16);
+    }
+  };
+  float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  auto compute_unit = [&](int u, const float4_t (&b)[4]) {
+    const int ct = u / nchunk, ch = u - ct * nchunk, g0 = ch << 2;
+    if (ch == 0) { acc0 = (float4_t){0.f, 0.f, 0.f, 0.f}; acc1 = acc0; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (g0 + t < ngrp1) {   // wave-uniform
+        // k permutation: MFMA q of 16-k group g uses k = 16g + 4*(lane>>4) + q on both operands
+        const float4_t a = *(const float4_t*)(wrow + (g0 + t) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (t & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[t][q], acc1, 0, 0, 0);
+          else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[t][q], acc0, 0, 0, 0);
+        }
       }
     }
-    if (u < kq) {  // one odd 16-k group (d = 64 * odd)
-      float4_t b0 = *(const float4_t*)(drow + u);
-      if (!valid) b0 = (float4_t){0.f, 0.f, 0.f, 0.f};
-      const float4_t a0 = *(const float4_t*)(wrow + u);
+    if (ch == nchunk - 1) {
+      const float4_t sum = acc0 + acc1;
+      // D layout: col = lane & 15 (column of T), row = 4*(lane>>4) + r
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], acc0, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) Tp[(w * 16 + 4 * lk + r) * tld + ct * 16 + li] = sum[r];
     }
-    acc0 += acc1;
-    // D layout: col = lane & 15 (column of T), row = 4*(lane>>4) + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Tp[(w * 16 + 4 * lk + r) * tld + ct * 16 + li] = acc0[r];
+  };
+  {
+    float4_t bA[4], bB[4];
+    load_unit(0, bA);
+    int u = 0;
+    for (; u + 1 < nunit; u += 2) {
+      load_unit(u + 1, bB);
+      compute_unit(u, bA);
+      if (u + 2 < nunit) load_unit(u + 2, bA);
+      compute_unit(u + 1, bB);
+    }
+    if (u < nunit) compute_unit(u, bA);
   }
   __syncthreads();
   for (int e = tid; e < LR_BM * NEP; e += 256) {
@@ -321,33 +340,264 @@ __global__ __launch_bounds__(256, 2) void k_apply_lowrank(const float* __restric
   }
   __syncthreads();
 
-  // ---- phase 2: out = Ws + Ts * R, 64-column groups round-robin over the waves
+  // ---- phase 2: out = Ws + Ts * R.  Units = (64-column group g, chunk of 16 e-rows x 4 lanes-k);
+  // the R fragments of the next unit are in flight during the MFMAs of the current one.
   const int ngrp = d >> 6;
-  for (int g = w; g < ngrp; g += 4) {
-    const int c0 = g * 64 + 4 * li;   // this lane's 4 consecutive output columns
-    float4_t acc[4];                  // acc[q][r]: row 4*lk + r, column c0 + q
+  const int ne4 = (Ne + 3) & ~3;                 // contraction length actually needed
+  const int nech = (ne4 + 31) >> 5;              // chunks of 32 e-rows (8 MFMA k-steps)
+  const int my_groups = (ngrp - w + 3) >> 2;     // groups w, w+4, ...
+  const int nunit2 = my_groups * nech;
+  auto load_unit2 = [&](int u, float4_t (&b)[8]) {
+    const int gi = u / nech, e0 = (u - gi * nech) << 5;
+    const int c0 = (w + 4 * gi) * 64 + 4 * li;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4_t wv = *(const float4_t*)&Ws[(4 * lk + r) * wld + c0];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q][r] = wv[q];
+    for (int t = 0; t < 8; ++t) {
+      const int e_row = e0 + 4 * t + lk;
+      b[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      if (e_row < Ne) b[t] = *(const float4_t*)(R + (size_t)e_row * d + c0);
     }
-    for (int kb = 0; kb < NEP; kb += 4) {
-      const int e_row = kb + lk;
-      const float a = Ts[li * tld + e_row];
-      float4_t b = {0.f, 0.f, 0.f, 0.f};
-      if (e_row < Ne) b = *(const float4_t*)(R + (size_t)e_row * d + c0);
+  };
+  float4_t acc[4];                               // acc[q][r]: row 4*lk + r, column c0 + q
+  auto compute_unit2 = [&](int u, const float4_t (&b)[8]) {
+    const int gi = u / nech, ch = u - gi * nech, e0 = ch << 5;
+    const int c0 = (w + 4 * gi) * 64 + 4 * li;
+    if (ch == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[q], acc[q], 0, 0, 0);
-    }
+      for (int r = 0; r < 4; ++r) {
+        const float4_t wv = *(const float4_t*)&Ws[(4 * lk + r) * wld + c0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long gr = r0 + 4 * lk + r;
-      if (gr < rows) {
-        const float4_t o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        *(float4_t*)(W_new + gr * d + c0) = o;
+        for (int q = 0; q < 4; ++q) acc[q][r] = wv[q];
       }
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (e0 + 4 * t < ne4) {   // wave-uniform
+        const float a = Ts[li * tld + e0 + 4 * t + lk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t][q], acc[q], 0, 0, 0);
+      }
+    }
+    if (ch == nech - 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long gr = r0 + 4 * lk + r;
+        if (gr < rows) {
+          const float4_t o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+          *(float4_t*)(W_new + gr * d + c0) = o;
+        }
+      }
+    }
+  };
+  {
+    float4_t bA[8], bB[8];
+    if (nunit2 > 0) load_unit2(0, bA);
+    int u = 0;
+    for (; u + 1 < nunit2; u += 2) {
+      load_unit2(u + 1, bB);
+      compute_unit2(u, bA);
+      if (u + 2 < nunit2) load_unit2(u + 2, bA);
+      compute_unit2(u + 1, bB);
+    }
+    if (u < nunit2) compute_unit2(u, bA);
+  }
+}
+
+// Streaming variant for the embedding widths that matter (768 / 1024 / 2048): NO weight tile in
+// LDS.  A 16-row tile per workgroup, 4 waves:
+//   phase 1  T = W_tile Dm^T.  Wave w owns K quarter w; per pipeline unit it loads 2 16-k groups
+//            of its W rows (A fragments, straight from HBM) and of 4 x 16 Dm rows (B fragments,
+//            L2) and issues 32 MFMAs (16x16x4 f32) into 4 accumulators (one per 16-concept tile).
+//            Partial T's meet in LDS (the only LDS use: ~20 KB, so occupancy is VGPR-bound).
+//   phase 2  out = W_tile + T R.  Wave w owns column groups w, w+4, ...; lane j of a group owns 4
+//            consecutive columns, so the residual (re-read of the W tile, an L2 hit), the R
+//            fragments and the output are all 16 B per lane.  k-step-major MFMA order: one LDS
+//            read of T feeds every group.  Results stay in registers and are stored at the very
+//            end, so no load ever queues behind a store (vmcnt retires in order on gfx950).
+// Every global load is unconditional (clamped address, zero applied afterwards) and issued two
+// units ahead of its MFMAs, pinned with sched_barrier: hipcc then emits counted vmcnt waits.
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_apply_lowrank(
+    const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ R,
+    float* __restrict__ W_new, long rows, int Ne, int NEP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int d = D;
+  const int tld = NEP + 2;
+  float* Ts = (float*)smem_raw;                 // [16][tld]
+  float* Tp = Ts + LR_BM * tld;                 // [4][16][tld] per-wave partials of phase 1
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long r0 = (long)blockIdx.x * LR_BM;
+
+  // ---------------- phase 1
+  constexpr int KQ = D / 4;          // floats per K quarter
+  constexpr int NG = KQ / 16;        // 16-k groups per quarter (12 / 16 / 32)
+  constexpr int GRP = 2;             // groups per pipeline unit
+  constexpr int NU = NG / GRP;       // units per batch of 4 concept tiles
+  const int kbeg = w * KQ;
+  long arow = r0 + li;
+  arow = arow < rows ? arow : rows - 1;
+  const float* aptr = W_old + arow * d + kbeg + 4 * lk;
+  const int nbatch = (NEP + 63) >> 6;
+  const int nunit = nbatch * NU;
+
+  struct Frag1 { float4_t a[GRP]; float4_t b[4][GRP]; };
+  auto load1 = [&](int u, Frag1& f) {
+    const int bt = u / NU, uu = u - bt * NU;
+#pragma unroll
+    for (int g = 0; g < GRP; ++g) f.a[g] = *(const float4_t*)(aptr + (uu * GRP + g) * 16);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int e_row = (bt * 4 + ct) * 16 + li;
+      const int e_cl = e_row < Ne ? e_row : Ne - 1;
+      const float* drow = Dm + (size_t)e_cl * d + kbeg + 4 * lk + uu * GRP * 16;
+#pragma unroll
+      for (int g = 0; g < GRP; ++g) f.b[ct][g] = *(const float4_t*)(drow + g * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the whole batch is issued HERE, two units ahead of its use
+  };
+  float4_t acc1[4];
+  auto comp1 = [&](int u, const Frag1& f) {
+    const int bt = u / NU, uu = u - bt * NU;
+    if (uu == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc1[ct] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const int nct_b = min(4, (NEP >> 4) - bt * 4);   // concept tiles that exist in this batch (uniform)
+    // k permutation: MFMA q of group g uses k = 16g + 4*(lane>>4) + q on both operands
+    if (nct_b == 4) {
+#pragma unroll
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const float bv = ((bt * 4 + ct) * 16 + li < Ne) ? f.b[ct][g][q] : 0.f;
+            acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[g][q], bv, acc1[ct], 0, 0, 0);
+          }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        if (ct < nct_b) {
+#pragma unroll
+          for (int g = 0; g < GRP; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float bv = ((bt * 4 + ct) * 16 + li < Ne) ? f.b[ct][g][q] : 0.f;
+              acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[g][q], bv, acc1[ct], 0, 0, 0);
+            }
+        }
+    }
+    if (uu == NU - 1) {
+      // D layout: col = lane & 15 (concept within the tile), row = 4*(lane>>4) + r
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        if (ct < nct_b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Tp[(w * 16 + 4 * lk + r) * tld + (bt * 4 + ct) * 16 + li] = acc1[ct][r];
+        }
+    }
+  };
+  {
+    Frag1 fA, fB, fC;
+    load1(0, fA);
+    load1(nunit > 1 ? 1 : 0, fB);
+    int u = 0;
+    for (; u + 2 < nunit; u += 3) {
+      load1(u + 2, fC);
+      comp1(u, fA);
+      load1(u + 3 < nunit ? u + 3 : u + 2, fA);
+      comp1(u + 1, fB);
+      load1(u + 4 < nunit ? u + 4 : u + 2, fB);
+      comp1(u + 2, fC);
+    }
+    if (u < nunit) comp1(u, fA);
+    if (u + 1 < nunit) comp1(u + 1, fB);
+  }
+  __syncthreads();
+  for (int e = tid; e < LR_BM * NEP; e += 256) {
+    const int r = e / NEP, c = e - r * NEP;
+    Ts[r * tld + c] = (Tp[(0 * 16 + r) * tld + c] + Tp[(1 * 16 + r) * tld + c]) +
+                      (Tp[(2 * 16 + r) * tld + c] + Tp[(3 * 16 + r) * tld + c]);
+  }
+  __syncthreads();
+
+  // ---------------- phase 2
+  constexpr int MG = D / 256;                  // column groups per wave (3 / 4 / 8)
+  constexpr int GP = MG > 4 ? 4 : MG;          // groups per pass (accumulators live in registers)
+  const int nks = (Ne + 3) >> 2;               // k-steps that carry concepts
+  const int nu2 = (nks + 1) >> 1;              // pipeline units of 2 k-steps
+  struct Frag2 { float4_t b[2][GP]; };
+#pragma unroll 1
+  for (int pass = 0; pass < MG / GP; ++pass) {
+    const int gbase = w + 4 * pass * GP;       // groups gbase, gbase + 4, ...
+    auto load2 = [&](int u, Frag2& f) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int e_row = 8 * u + 4 * t + lk;
+        const int e_cl = e_row < Ne ? e_row : Ne - 1;
+        const float* rrow = R + (size_t)e_cl * d + 4 * li;
+#pragma unroll
+        for (int g = 0; g < GP; ++g) f.b[t][g] = *(const float4_t*)(rrow + (gbase + 4 * g) * 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    float4_t acc[GP][4];                       // acc[g][q][r]: row 4*lk + r, column (gbase+4g)*64 + 4*li + q
+    Frag2 fA, fB, fC;
+    load2(0, fA);
+    load2(nu2 > 1 ? 1 : 0, fB);
+    {
+      // residual: the W tile again (L2), already in the accumulator layout
+      float4_t wv[GP][4];
+#pragma unroll
+      for (int g = 0; g < GP; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          long gr = r0 + 4 * lk + r;
+          gr = gr < rows ? gr : rows - 1;
+          wv[g][r] = *(const float4_t*)(W_old + gr * d + (gbase + 4 * g) * 64 + 4 * li);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < GP; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[g][q][r] = wv[g][r][q];
+    }
+    auto comp2 = [&](int u, const Frag2& f) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int e_row = 8 * u + 4 * t + lk;
+        const float a = (e_row < Ne) ? Ts[li * tld + e_row] : 0.f;   // zero A also kills clamped R rows
+#pragma unroll
+        for (int g = 0; g < GP; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f.b[t][g][q], acc[g][q], 0, 0, 0);
+      }
+    };
+    int u = 0;
+    for (; u + 2 < nu2; u += 3) {
+      load2(u + 2, fC);
+      comp2(u, fA);
+      load2(u + 3 < nu2 ? u + 3 : u + 2, fA);
+      comp2(u + 1, fB);
+      load2(u + 4 < nu2 ? u + 4 : u + 2, fB);
+      comp2(u + 2, fC);
+    }
+    if (u < nu2) comp2(u, fA);
+    if (u + 1 < nu2) comp2(u + 1, fB);
+#pragma unroll
+    for (int g = 0; g < GP; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long gr = r0 + 4 * lk + r;
+        if (gr < rows) {
+          const float4_t o = {acc[g][0][r], acc[g][1][r], acc[g][2][r], acc[g][3][r]};
+          *(float4_t*)(W_new + gr * d + (gbase + 4 * g) * 64 + 4 * li) = o;
+        }
+      }
   }
 }
 
@@ -383,16 +633,27 @@ int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, fl
   if (NEP == 0) NEP = 16;
   const size_t smem = ((size_t)LR_BM * (d + 8) + (size_t)5 * LR_BM * (NEP + 2)) * sizeof(float);
   if (smem > 160 * 1024) return UCE_EINVAL;
-  static size_t attr_smem = 0;
-  if (smem > attr_smem) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem));
-    attr_smem = smem;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int cap = 160 * 1024;
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank<768>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank_generic, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_set = true;
   }
   const long nwg = (rows + LR_BM - 1) / LR_BM;
   if (nwg > 0x7fffffffL) return UCE_EINVAL;
-  hipLaunchKernelGGL(k_apply_lowrank, dim3((unsigned)nwg), dim3(256), smem, st, W_old, Dm, R, W_new, rows, d,
-                     N_edit, NEP);
+  const dim3 grid((unsigned)nwg), block(256);
+  const size_t smem_s = (size_t)5 * LR_BM * (NEP + 2) * sizeof(float);   // streaming kernels: T only
+  if (N_edit > 0 && d == 768)
+    hipLaunchKernelGGL(k_apply_lowrank<768>, grid, block, smem_s, st, W_old, Dm, R, W_new, rows, N_edit, NEP);
+  else if (N_edit > 0 && d == 1024)
+    hipLaunchKernelGGL(k_apply_lowrank<1024>, grid, block, smem_s, st, W_old, Dm, R, W_new, rows, N_edit, NEP);
+  else if (N_edit > 0 && d == 2048)
+    hipLaunchKernelGGL(k_apply_lowrank<2048>, grid, block, smem_s, st, W_old, Dm, R, W_new, rows, N_edit, NEP);
+  else
+    hipLaunchKernelGGL(k_apply_lowrank_generic, grid, block, smem, st, W_old, Dm, R, W_new, rows, d, N_edit, NEP);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

@@ -48,8 +48,13 @@ int uce_ensure(uce_ctx* h, int d, int n);
 
 int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
                        int d, float lamb, double* A, double* Bt, hipStream_t st);
+// Also writes Dm = G - C_e and resets h->status.  When the system is a single 64-block and the
+// Gram was split over K, the slabs are left unreduced: *nsplit_out > 1 and the matrix to factor
+// is h->slabs with *slab_stride_out (k_potrf_first sums them).
 int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, float lamb, double* K,
-                     int n_pad, hipStream_t st);
+                     int n_pad, const float* G, float* Dm, int N_edit, int* nsplit_out,
+                     size_t* slab_stride_out, hipStream_t st);
+int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st);
 int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st);
 // X = M^-1 RHS after launch_potrf.  RHS is f64 [n, m] (rhs64) or f32 [rhs_rows, m] (rhs32, rows
 // beyond rhs_rows are zero).  out f32 [out_rows, m] gets rows 0..out_rows-1 of X.

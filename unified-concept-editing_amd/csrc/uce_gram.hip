@@ -128,10 +128,24 @@ __global__ __launch_bounds__(256) void k_gram_primal(const float* __restrict__ C
 // ------------------------------------------------------------------------------------------
 // dual: K = lambda S^-1 + C C^T, n_pad = roundup(N, 64); rows >= N are zero with a unit diagonal
 // ------------------------------------------------------------------------------------------
+// Blocks with blockIdx.x >= n_tiles do the side jobs of the dual path so that they cost no
+// launch of their own: Dm = G - C_e (fp32) and the reset of the solver's status word.
 __global__ __launch_bounds__(256) void k_gram_dual(const float* __restrict__ C,
                                                    const float* __restrict__ s, int N, int d,
                                                    float lamb, double* __restrict__ outK, int n_pad,
-                                                   int kchunk, size_t slab_stride) {
+                                                   int kchunk, size_t slab_stride, int n_tiles,
+                                                   const float* __restrict__ G, float* __restrict__ Dm,
+                                                   long dm_f4, int* __restrict__ status) {
+  if ((int)blockIdx.x >= n_tiles) {
+    if (blockIdx.y != 0) return;
+    const int nside = gridDim.x - n_tiles;
+    if (blockIdx.x == (unsigned)n_tiles && threadIdx.x == 0 && status) *status = 0;
+    for (long i = (long)(blockIdx.x - n_tiles) * 256 + threadIdx.x; i < dm_f4; i += (long)nside * 256) {
+      const float4_t g = ((const float4_t*)G)[i], c = ((const float4_t*)C)[i];
+      ((float4_t*)Dm)[i] = g - c;
+    }
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float As[64][NT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[64][NT_LD];
 
@@ -252,25 +266,37 @@ int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* 
 }
 
 int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, float lamb, double* K,
-                     int n_pad, hipStream_t st) {
+                     int n_pad, const float* G, float* Dm, int N_edit, int* nsplit_out,
+                     size_t* slab_stride_out, hipStream_t st) {
   const int nb = n_pad / 64;
   const int tiles = nb * (nb + 1) / 2;
   const int chunks = d / KC;
   int nsplit = pick_split(tiles, chunks);
+  if (nb == 1 && nsplit > 8) nsplit = 8;   // k_potrf_first sums the slabs itself: keep that short
   int kchunk = ((chunks + nsplit - 1) / nsplit) * KC;
   nsplit = (d + kchunk - 1) / kchunk;
   const size_t mat = (size_t)n_pad * n_pad;
+  const long dm_f4 = (Dm && N_edit > 0) ? (long)N_edit * d / 4 : 0;
+  int nside = dm_f4 ? (int)((dm_f4 + 1023) / 1024) : 1;   // 4 float4 per thread
+  if (nside > 64) nside = 64;
+  *nsplit_out = 1;
+  *slab_stride_out = 0;
   if (nsplit == 1) {
-    hipLaunchKernelGGL(k_gram_dual, dim3(tiles, 1), dim3(256), 0, st, C, s, N, d, lamb, K, n_pad, kchunk,
-                       (size_t)0);
+    hipLaunchKernelGGL(k_gram_dual, dim3(tiles + nside, 1), dim3(256), 0, st, C, s, N, d, lamb, K, n_pad,
+                       kchunk, (size_t)0, tiles, G, Dm, dm_f4, h->status);
     UCE_LAUNCH_CHECK();
     return UCE_OK;
   }
   const size_t need = (size_t)nsplit * mat * sizeof(double);
   if (need > h->slabs_bytes) return UCE_ENOMEM;
-  hipLaunchKernelGGL(k_gram_dual, dim3(tiles, nsplit), dim3(256), 0, st, C, s, N, d, lamb, h->slabs, n_pad,
-                     kchunk, mat);
+  hipLaunchKernelGGL(k_gram_dual, dim3(tiles + nside, nsplit), dim3(256), 0, st, C, s, N, d, lamb, h->slabs,
+                     n_pad, kchunk, mat, tiles, G, Dm, dm_f4, h->status);
   UCE_LAUNCH_CHECK();
+  if (nb == 1) {  // single block: k_potrf_first sums the slabs itself
+    *nsplit_out = nsplit;
+    *slab_stride_out = mat;
+    return UCE_OK;
+  }
   const int thr = 256;
   hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
                      (const double*)h->slabs, mat, nsplit, K, mat);

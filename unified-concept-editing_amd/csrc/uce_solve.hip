@@ -24,67 +24,138 @@ __device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
   b = t - a * (a + 1) / 2;
 }
 
-// In-LDS Cholesky of a 64x64 SPD block T (lower triangle used) by 256 threads; on exit the
-// lower triangle of T holds L, the upper triangle is zeroed, and X holds L^-1 (lower).
-__device__ void potrf64_lds(double (*T)[LD], double (*X)[LD], int tid, int* status, int col_base) {
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    X[i][j] = (i == j) ? 1.0 : 0.0;
-    if (j > i) T[i][j] = 0.0;
+// ---------------------------------------------------------------------------------------------
+// Register-tiled Cholesky + inverse of one 64x64 SPD block by 256 threads.
+// Thread (ti, tj) = (tid >> 4, tid & 15) owns the 4x4 sub-block rows 4ti.., cols 4tj.. of the
+// matrix (a) and of X (x, starts as I, ends as L^-1).  Right-looking and fully unrolled over the
+// 64 pivots with ONE barrier per pivot: at pivot k the owners publish column k of the matrix and
+// row k of X (both still unscaled) into line k of two LDS arrays; everybody then reads the pivot
+// and its own row/column entries and updates  a_ij -= a_ik a_jk / a_kk,  x_ij -= a_ik x_kj / a_kk.
+// Line k is final the moment it is published (later register updates of already-eliminated
+// rows/columns are harmless garbage that is never read), so no masking is needed; L's columns and
+// X's rows are scaled by 1/sqrt(a_kk) in one pass at the end.
+// ---------------------------------------------------------------------------------------------
+struct Potrf64Scratch {
+  double col[64][64];   // col[k][i] = a_ik^(k)   (column k of the Schur complement at step k)
+  double row[64][64];   // row[k][j] = x_kj^(k)   (row k of the partial inverse at step k)
+  double rs[64];        // 1 / a_kk^(k), later 1 / sqrt(a_kk)
+};
+
+__device__ __forceinline__ double rcp_f64(double v) {
+  double r = __builtin_amdgcn_rcp(v);
+  r = fma(fma(-v, r, 1.0), r, r);
+  r = fma(fma(-v, r, 1.0), r, r);
+  return r;
+}
+
+template <int K>
+__device__ __forceinline__ void potrf64_pivot(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
+                                              int ti, int tj) {
+  constexpr int kb = K >> 2, kr = K & 3;
+  if (tj == kb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc->col[K][4 * ti + r] = a[r][kr];
   }
-  const int i = tid >> 2;  // row handled in the update phase
-  const int q = tid & 3;   // column residue
-  for (int k = 0; k < 64; ++k) {
-    __syncthreads();
-    double piv = T[k][k];
-    if (!(piv > 0.0)) {
-      if (tid == 0) atomicCAS(status, 0, col_base + k + 1);
-      piv = 1.0;
+  if (ti == kb) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sc->row[K][4 * tj + c] = x[kr][c];
+  }
+  __syncthreads();
+  const double inv = rcp_f64(sc->col[K][K]);
+  double ci[4], cj[4], xr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ci[r] = sc->col[K][4 * ti + r] * inv;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cj[c] = sc->col[K][4 * tj + c];
+    xr[c] = sc->row[K][4 * tj + c];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a[r][c] = fma(-ci[r], cj[c], a[r][c]);
+      x[r][c] = fma(-ci[r], xr[c], x[r][c]);
     }
-    const double rinv = 1.0 / sqrt(piv);
-    __syncthreads();
-    // scale column k of L and row k of X
-    if (tid < 64) {
-      if (tid > k) T[tid][k] *= rinv;
-      else if (tid == k) T[k][k] = piv * rinv;
-    } else if (tid < 128) {
-      const int c = tid - 64;
-      if (c <= k) X[k][c] *= rinv;
+  if constexpr (K + 1 < 64) potrf64_pivot<K + 1>(a, x, sc, ti, tj);
+}
+
+// a[][] holds this thread's 4x4 sub-block of the SPD tile on entry (lower triangle is what
+// matters); on exit a = sub-block of L (zero above the diagonal), x = sub-block of L^-1.
+__device__ __forceinline__ void potrf64_reg(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
+                                            int tid, int* status, int col_base) {
+  const int ti = tid >> 4, tj = tid & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
+  potrf64_pivot<0>(a, x, sc, ti, tj);
+  __syncthreads();
+  if (tid < 64) {
+    const double piv = sc->col[tid][tid];
+    // first non-positive (or NaN) pivot wins; everything after it is garbage anyway
+    const unsigned long long bad = __ballot(!(piv > 0.0));
+    if (bad && tid == 0) atomicCAS(status, 0, col_base + __builtin_ctzll(bad) + 1);
+    sc->rs[tid] = 1.0 / sqrt(piv);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = 4 * ti + r, col = 4 * tj + c;
+      a[r][c] = (col <= row) ? sc->col[col][row] * sc->rs[col] : 0.0;
+      x[r][c] = (col <= row) ? sc->row[row][col] * sc->rs[row] : 0.0;
     }
-    __syncthreads();
-    if (i > k) {
-      const double lik = T[i][k];
-#pragma unroll 4
-      for (int j = q; j < 64; j += 4) {
-        if (j > k) {
-          if (j <= i) T[i][j] -= lik * T[j][k];
-        } else {
-          X[i][j] -= lik * X[k][j];
-        }
+}
+
+// Factors diagonal block 0.  With nsplit > 1 the block is first summed from the split-K slabs of
+// the Gram kernel (single-block systems skip the separate reduction launch).
+__global__ __launch_bounds__(256) void k_potrf_first(const double* __restrict__ M, int n, int nsplit,
+                                                     size_t slab_stride, double* __restrict__ Lmat,
+                                                     double* __restrict__ Linv, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double a[4][4], x[4][4];
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[r][c] = 0.0;
+  // slabs summed in index order (bit-repeatable); 2 slabs = 16 independent 16-byte loads per batch
+  for (int sp = 0; sp < nsplit; sp += 2) {
+    double2_t v[2][4][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int sq = (sp + q < nsplit) ? sp + q : sp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          v[q][r][hh] = *(const double2_t*)(M + (size_t)sq * slab_stride + (size_t)(4 * ti + r) * n + 4 * tj + 2 * hh);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (sp + q < nsplit) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            a[r][2 * hh] += v[q][r][hh][0];
+            a[r][2 * hh + 1] += v[q][r][hh][1];
+          }
       }
     }
   }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_potrf_first(const double* __restrict__ M, int n,
-                                                     double* __restrict__ Lmat,
-                                                     double* __restrict__ Linv, int* status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double (*T)[LD] = (double (*)[LD])smem_raw;
-  double (*X)[LD] = (double (*)[LD])(smem_raw + 64 * LD * 8);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    T[i][j] = M[(size_t)i * n + j];
-  }
-  __syncthreads();
-  potrf64_lds(T, X, tid, status, 0);
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    Lmat[(size_t)i * n + j] = T[i][j];
-    Linv[e] = X[i][j];
-  }
+  potrf64_reg(a, x, sc, tid, status, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Lmat[(size_t)(4 * ti + r) * n + 4 * tj + c] = a[r][c];
+      Linv[(4 * ti + r) * 64 + 4 * tj + c] = x[r][c];
+    }
 }
 
 // one wave's 32x32 quadrant of  acc += sign * P[rows] * Q[cols]^T  (both tiles row-major in LDS,
@@ -134,9 +205,9 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ M, int 
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-  int a, b;
-  tri_decode(blockIdx.x, a, b);
-  const int i = j + 1 + a, k = j + 1 + b;
+  int ta, tb;
+  tri_decode(blockIdx.x, ta, tb);
+  const int i = j + 1 + ta, k = j + 1 + tb;
   const bool diag = (i == k);
 
   const double* Linv_j = Linv + (size_t)j * 64 * 64;
@@ -183,17 +254,26 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ M, int 
     });
     return;
   }
-  // the next diagonal block: factor it now (Li <- tile, Mk <- inverse)
+  // the next diagonal block: factor it now (accumulators -> LDS tile -> 4x4 register sub-blocks)
   __syncthreads();
   quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
   __syncthreads();
-  potrf64_lds(Li, Mk, tid, status, i * 64);
+  Potrf64Scratch* sc = (Potrf64Scratch*)&Mi[0][0];   // P_i / P_k regions (66 KB) are dead now
+  const int ti = tid >> 4, tj = tid & 15;
+  double a[4][4], x[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[r][c] = Li[4 * ti + r][4 * tj + c];
+  potrf64_reg(a, x, sc, tid, status, i * 64);
   double* Linv_n = Linv + (size_t)i * 64 * 64;
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Lmat[(size_t)(i * 64 + r) * n + i * 64 + c] = Li[r][c];
-    Linv_n[e] = Mk[r][c];
-  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Lmat[(size_t)(i * 64 + 4 * ti + r) * n + i * 64 + 4 * tj + c] = a[r][c];
+      Linv_n[(4 * ti + r) * 64 + 4 * tj + c] = x[r][c];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -302,10 +382,11 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
 
 }  // namespace
 
-int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
+int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st) {
   const int nb = n / 64;
   const size_t smem = 3 * 64 * LD * sizeof(double);
-  const size_t smem_first = 2 * 64 * LD * sizeof(double);
+  const size_t smem_first = sizeof(Potrf64Scratch);
+  static_assert(sizeof(Potrf64Scratch) <= 2 * 64 * LD * sizeof(double), "scratch must fit the P_i/P_k regions");
   static bool attr_set = false;
   if (!attr_set) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -314,8 +395,8 @@ int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
                                     (int)smem_first));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(256), smem_first, st, (const double*)M, n, h->Lmat,
-                     h->Linv, h->status);
+  hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(256), smem_first, st, (const double*)M, n, nsplit,
+                     slab_stride, h->Lmat, h->Linv, h->status);
   UCE_LAUNCH_CHECK();
   for (int j = 0; j + 1 < nb; ++j) {
     const int mt = nb - j - 1;
@@ -325,6 +406,10 @@ int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
     UCE_LAUNCH_CHECK();
   }
   return UCE_OK;
+}
+
+int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
+  return launch_potrf_slabs(h, M, n, 1, 0, st);
 }
 
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
