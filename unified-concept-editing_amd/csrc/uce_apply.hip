@@ -7,6 +7,7 @@
 // k_delta_factors : DeltaT = R^T Dm  (small TN GEMM, f32 MFMA) for the dual path with large N_edit.
 // k_cast_bf16     : f32 -> bf16 RNE cast of the edited slab into the U-Net's parameters.
 #include "uce_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -601,6 +602,251 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// =============================================================================================
+// Super-tile low-rank apply (49 <= N_edit <= 256): one workgroup = MT 16-row tiles (MT*16 rows),
+// 4 waves, one per SIMD.  Both GEMMs re-use every fetched operand MT times, which is what the
+// 16-row kernels above cannot do (their Dm / R fragments feed a single MFMA and the L1/TA path,
+// not the MFMA pipe, sets their speed):
+//   phase 1  T = W_st Dm^T: wave w owns concept tile (16 columns of T) 4*batch + w.  The W
+//            k-chunk (MT*16 rows x 64 floats, full 256 B row segments) is staged once in LDS
+//            (double buffered, register prefetch one chunk ahead) and shared by the 4 waves; each
+//            wave's Dm fragments come straight from L2 and feed MT MFMAs each.
+//   phase 2  out = W_st + T R: wave w owns 64-column groups w, w+4, ...; for a group it keeps
+//            MT x 4 accumulators (initialised with the residual, an L2 re-read of W) and walks the
+//            concept k-steps: one 16 B R fragment per lane feeds 4*MT MFMAs; T comes from LDS.
+// MFMA-bound by construction (f32 16x16x4): MT*16 rows cost 32 cycles * MT*(NEP*D/64 + nks*D/64)/...
+// =============================================================================================
+
+constexpr int ST_KC = 64;    // floats per W k-chunk
+constexpr int ST_LD = 72;    // LDS row stride of the chunk (floats): conflict-free b128 fragment reads
+
+// 8 waves: wave = (concept tile / column-group class c4 = w & 3, M half = w >> 2).  The two waves
+// that share a SIMD split the MT row tiles between them, so one wave's LDS reads, address math and
+// waits overlap the other's MFMAs (the matrix pipe is per SIMD and shared by its waves).
+template <int D, int MT, int NMT>
+struct StBody {
+  // phase 1 for NMT row tiles starting at mbase; returns nothing, writes T into Ts
+  static __device__ __forceinline__ void run(const float* __restrict__ W_old, const float* __restrict__ Dm,
+                                             const float* __restrict__ R, float* __restrict__ W_new,
+                                             long rows, int Ne, int NEP, float* Wc, float* Ts, int mbase, int mode) {
+    constexpr int d = D;
+    constexpr int SR = MT * 16;
+    const int tld = NEP + 2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c4 = w & 3;
+    const int li = lane & 15, lk = lane >> 4;
+    const long R0 = (long)blockIdx.x * SR;
+
+    constexpr int NC = D / ST_KC;                       // k-chunks (12 / 16 / 32), even
+    constexpr int F4 = SR * (ST_KC / 4);                // float4 per chunk
+    constexpr int NLD = (F4 + 511) / 512;               // per thread
+    auto load_chunk = [&](int kc, float4_t (&v)[NLD]) {
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) {
+        const int e = tid + 512 * p;
+        const int r = (e >> 4) < SR ? (e >> 4) : SR - 1, cc = (e & 15) << 2;
+        long gr = R0 + r;
+        gr = gr < rows ? gr : rows - 1;
+        v[p] = *(const float4_t*)(W_old + gr * d + kc * ST_KC + cc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto park_chunk = [&](int buf, const float4_t (&v)[NLD]) {
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) {
+        const int e = tid + 512 * p;
+        if (e < F4) *(float4_t*)&Wc[(buf * SR + (e >> 4)) * ST_LD + ((e & 15) << 2)] = v[p];
+      }
+    };
+    const int nbatch = NEP >> 6;
+#pragma unroll 1
+    for (int bt = 0; bt < nbatch; ++bt) {
+      const int e_row = (bt * 4 + c4) * 16 + li;        // this lane's concept (B operand column)
+      const float bmask = e_row < Ne ? 1.f : 0.f;
+      const float* dptr = Dm + (size_t)(e_row < Ne ? e_row : Ne - 1) * d + 4 * lk;
+      auto load_dm = [&](int kc, float4_t (&b)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *(const float4_t*)(dptr + kc * ST_KC + g * 16);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      float4_t acc[NMT];
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) acc[m] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      auto compute = [&](int buf, const float4_t (&b)[4]) {
+        // k permutation: MFMA q of 16-k group g uses k = 16g + 4*(lane>>4) + q on both operands
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4_t a[NMT];
+#pragma unroll
+          for (int m = 0; m < NMT; ++m)
+            a[m] = *(const float4_t*)&Wc[(buf * SR + (mbase + m) * 16 + li) * ST_LD + g * 16 + 4 * lk];
+          const float4_t bb = b[g] * bmask;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], bb[q], acc[m], 0, 0, 0);
+        }
+      };
+      // W chunk c: loaded (HBM) during iteration c-2 into register set c&1, parked in LDS buffer
+      // c&1 during iteration c-1, consumed in iteration c.
+      float4_t wA[NLD], wB[NLD], dmA[4], dmB[4];
+      __syncthreads();                                  // previous batch is done with Wc
+      load_chunk(0, wA);
+      load_chunk(1, wB);
+      load_dm(0, dmA);
+      load_dm(1, dmB);
+      park_chunk(0, wA);
+      load_chunk(2 < NC ? 2 : 0, wA);
+      __syncthreads();
+#pragma unroll 1
+      for (int kc = 0; kc < ((mode & 1) ? 2 : NC); kc += 2) {
+        park_chunk(1, wB);                              // chunk kc + 1
+        load_chunk(kc + 3 < NC ? kc + 3 : kc, wB);
+        compute(0, dmA);                                // chunk kc
+        load_dm(kc + 2 < NC ? kc + 2 : kc, dmA);
+        __syncthreads();
+        if (kc + 2 < NC) park_chunk(0, wA);             // chunk kc + 2
+        load_chunk(kc + 4 < NC ? kc + 4 : kc, wA);
+        compute(1, dmB);                                // chunk kc + 1
+        load_dm(kc + 3 < NC ? kc + 3 : kc, dmB);
+        __syncthreads();
+      }
+      // D layout: col = lane & 15 (concept), row = 4*(lane>>4) + r
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Ts[((mbase + m) * 16 + 4 * lk + r) * tld + (bt * 4 + c4) * 16 + li] = acc[m][r];
+    }
+
+    // ---------------- phase 2 (its first loads are issued before the barrier that publishes T)
+    constexpr int MG = D / 256;                         // column groups per class (3 / 4 / 8)
+    constexpr int RD = 4;                               // R fragments in flight
+    const int nks = (Ne + 3) >> 2;                      // k-steps that carry concepts
+    int rl_g = 0, rl_t = 0;                             // (group, k-step) of the next R fragment to fetch
+    auto r_next = [&]() -> float4_t {
+      const int e = 4 * rl_t + lk;
+      const float4_t v = *(const float4_t*)(R + (size_t)(e < Ne ? e : Ne - 1) * d + (c4 + 4 * rl_g) * 64 + 4 * li);
+      if (++rl_t == nks) { rl_t = 0; rl_g = rl_g + 1 < MG ? rl_g + 1 : rl_g; }
+      return v;
+    };
+    auto res_load = [&](int gi, float4_t (&x)[NMT][4]) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          long gr = R0 + (mbase + m) * 16 + 4 * lk + r;
+          gr = gr < rows ? gr : rows - 1;
+          x[m][r] = *(const float4_t*)(W_old + gr * d + (c4 + 4 * gi) * 64 + 4 * li);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    float4_t ring[RD];
+#pragma unroll
+    for (int i = 0; i < RD; ++i) ring[i] = r_next();
+    float4_t res[NMT][4];
+    res_load(0, res);
+    __syncthreads();
+#pragma unroll
+    for (int gi = 0; gi < MG; ++gi) {
+      float4_t acc[NMT][4];                             // acc[m][q][r]: row (mbase+m)*16 + 4*lk + r, column 4*li + q
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[m][q][r] = res[m][r][q];
+      if (gi + 1 < MG) res_load(gi + 1, res);           // next group's residual, ahead of this group's stores
+#pragma unroll 1
+      for (int t = 0; t < ((mode & 2) ? 1 : nks); ++t) {
+        const float4_t b = ring[0];
+#pragma unroll
+        for (int i = 0; i + 1 < RD; ++i) ring[i] = ring[i + 1];
+        ring[RD - 1] = r_next();
+        const int e = 4 * t + lk;
+        float a[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) a[m] = (e < Ne) ? Ts[((mbase + m) * 16 + li) * tld + e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int m = 0; m < NMT; ++m)
+            acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[q], acc[m][q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long gr = R0 + (mbase + m) * 16 + 4 * lk + r;
+          if (gr < rows) {
+            const float4_t o = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+            // streaming store: keep W_old (re-read as the residual) rather than W_new in L2 / MALL
+            __builtin_nontemporal_store(o, (float4_t*)(W_new + gr * d + (c4 + 4 * gi) * 64 + 4 * li));
+          }
+        }
+    }
+  }
+};
+
+template <int D, int MT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_lowrank_st(
+    const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ R,
+    float* __restrict__ W_new, long rows, int Ne, int NEP, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Wc = (float*)smem_raw;                       // [2][MT*16][ST_LD]
+  float* Ts = Wc + 2 * MT * 16 * ST_LD;               // [MT*16][NEP + 2]
+  constexpr int M0 = (MT + 1) / 2;
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
+    StBody<D, MT, M0>::run(W_old, Dm, R, W_new, rows, Ne, NEP, Wc, Ts, 0, mode);
+  else
+    StBody<D, MT, MT - M0>::run(W_old, Dm, R, W_new, rows, Ne, NEP, Wc, Ts, M0, mode);
+}
+
+template <int D, int MT>
+int launch_st(const float* W_old, const float* Dm, const float* R, float* W_new, long rows, int N_edit,
+              int NEP64, hipStream_t st) {
+  const size_t smem = ((size_t)2 * MT * 16 * ST_LD + (size_t)MT * 16 * (NEP64 + 2)) * sizeof(float);
+  if (smem > 160 * 1024) return UCE_ENOMEM;   // caller falls back to the 16-row kernels
+  static bool attr_set = false;
+  if (!attr_set) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank_st<D, MT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16);
+  hipLaunchKernelGGL((k_apply_lowrank_st<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, R, W_new,
+                     rows, N_edit, NEP64, getenv("UCE_LR_MODE") ? atoi(getenv("UCE_LR_MODE")) : 0);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+// rows / 16 tiles over 256 CUs with MT tiles per workgroup: time ~ ceil(workgroups / 256) * MT
+int pick_mt(long rows) {
+  const long t16 = (rows + 15) / 16;
+  int best = 8;
+  long best_cost = -1;
+  for (int mt = 8; mt >= 5; --mt) {
+    const long wgs = (t16 + mt - 1) / mt;
+    const long cost = ((wgs + 255) / 256) * mt;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt; }
+  }
+  return best;
+}
+
+template <int D>
+int launch_st_d(const float* W_old, const float* Dm, const float* R, float* W_new, long rows, int N_edit,
+                int NEP64, hipStream_t st) {
+  if (D >= 2048) return launch_st<D, 5>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);   // register budget
+  switch (pick_mt(rows)) {
+    case 5: return launch_st<D, 5>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+    case 6: return launch_st<D, 6>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+    case 7: return launch_st<D, 7>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+    default: return launch_st<D, 8>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+  }
+}
+
+
 // G = C_edit + Dsum @ C_debias  (f64 accumulate, one thread per 4 output floats)
 __global__ void k_debias_targets(const float* __restrict__ Ce, const float* __restrict__ Cd,
                                  const double* __restrict__ Dsum, int Ne, int Nd, int d,
@@ -644,6 +890,15 @@ int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, fl
   }
   const long nwg = (rows + LR_BM - 1) / LR_BM;
   if (nwg > 0x7fffffffL) return UCE_EINVAL;
+  static const int variant = getenv("UCE_LOWRANK_VARIANT") ? atoi(getenv("UCE_LOWRANK_VARIANT")) : 0;
+  if (variant != 1 && N_edit > 48 && rows >= 16 * 5 * 64 && (d == 768 || d == 1024 || d == 2048)) {
+    const int NEP64 = (N_edit + 63) / 64 * 64;
+    int rc = UCE_ENOMEM;
+    if (d == 768) rc = launch_st_d<768>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+    else if (d == 1024) rc = launch_st_d<1024>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+    else rc = launch_st_d<2048>(W_old, Dm, R, W_new, rows, N_edit, NEP64, st);
+    if (rc != UCE_ENOMEM) return rc;
+  }
   const dim3 grid((unsigned)nwg), block(256);
   const size_t smem_s = (size_t)5 * LR_BM * (NEP + 2) * sizeof(float);   // streaming kernels: T only
   if (N_edit > 0 && d == 768)

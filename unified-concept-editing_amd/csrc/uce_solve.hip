@@ -27,18 +27,21 @@ __device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
 // ---------------------------------------------------------------------------------------------
 // Register-tiled Cholesky + inverse of one 64x64 SPD block by 256 threads.
 // Thread (ti, tj) = (tid >> 4, tid & 15) owns the 4x4 sub-block rows 4ti.., cols 4tj.. of the
-// matrix (a) and of X (x, starts as I, ends as L^-1).  Right-looking and fully unrolled over the
-// 64 pivots with ONE barrier per pivot: at pivot k the owners publish column k of the matrix and
-// row k of X (both still unscaled) into line k of two LDS arrays; everybody then reads the pivot
-// and its own row/column entries and updates  a_ij -= a_ik a_jk / a_kk,  x_ij -= a_ik x_kj / a_kk.
-// Line k is final the moment it is published (later register updates of already-eliminated
-// rows/columns are harmless garbage that is never read), so no masking is needed; L's columns and
-// X's rows are scaled by 1/sqrt(a_kk) in one pass at the end.
+// matrix (a) and of X (x, starts as I, ends as L^-1).  Right-looking block elimination, TWO pivots
+// per step (32 steps, one barrier each): at step (k, k+1) the owners publish
+// columns k, k+1 of the current Schur complement and rows k, k+1 of X into LDS lines; everybody
+// reads the 2x2 pivot block P, inverts it, and applies the rank-2 update
+//     a_ij -= [a_ik a_i,k+1] P^-1 [a_jk a_j,k+1]^T ,   x_ij -= [a_ik a_i,k+1] P^-1 [x_kj x_k+1,j]^T .
+// The published lines are final as published (later register updates of eliminated rows/columns
+// are harmless garbage that is never read), so nothing is masked.  L and L^-1 are assembled from
+// the lines in one pass at the end: an even column is scaled by 1/sqrt(p00); an odd one first
+// gets the pivot-k elimination it skipped:  (c1 - c0 p01/p00) / sqrt(p11 - p01^2/p00).
 // ---------------------------------------------------------------------------------------------
 struct Potrf64Scratch {
-  double col[64][64];   // col[k][i] = a_ik^(k)   (column k of the Schur complement at step k)
-  double row[64][64];   // row[k][j] = x_kj^(k)   (row k of the partial inverse at step k)
-  double rs[64];        // 1 / a_kk^(k), later 1 / sqrt(a_kk)
+  double col[64][64];   // col[k][i]: column k of the Schur complement when it was published
+  double row[64][64];   // row[k][j]: row k of the partial inverse when it was published
+  double rs[64];        // 1/sqrt(effective pivot k)
+  double g[64];         // odd k: p01/p00 of its pair
 };
 
 __device__ __forceinline__ double rcp_f64(double v) {
@@ -48,36 +51,53 @@ __device__ __forceinline__ double rcp_f64(double v) {
   return r;
 }
 
-template <int K>
-__device__ __forceinline__ void potrf64_pivot(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
-                                              int ti, int tj) {
-  constexpr int kb = K >> 2, kr = K & 3;
+// One pair of pivots K = 4*kb + KR, K + 1 (KR in {0, 2} is static so register indices are static;
+// kb is a loop variable: the 32 steps are a 16-trip loop of two bodies, ~3 KB of code.  A fully
+// unrolled version of this loop is instruction-fetch bound: 50 KB of run-once straight-line code
+// took 31-38 us regardless of how many barriers it contained).
+template <int KR>
+__device__ __forceinline__ void potrf64_pair(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
+                                             int ti, int tj, int kb) {
+  const int K = 4 * kb + KR;
   if (tj == kb) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc->col[K][4 * ti + r] = a[r][kr];
+    for (int r = 0; r < 4; ++r) {
+      sc->col[K][4 * ti + r] = a[r][KR];
+      sc->col[K + 1][4 * ti + r] = a[r][KR + 1];
+    }
   }
   if (ti == kb) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sc->row[K][4 * tj + c] = x[kr][c];
+    for (int c = 0; c < 4; ++c) {
+      sc->row[K][4 * tj + c] = x[KR][c];
+      sc->row[K + 1][4 * tj + c] = x[KR + 1][c];
+    }
   }
   __syncthreads();
-  const double inv = rcp_f64(sc->col[K][K]);
-  double ci[4], cj[4], xr[4];
+  const double p00 = sc->col[K][K], p01 = sc->col[K][K + 1], p11 = sc->col[K + 1][K + 1];
+  const double idet = rcp_f64(fma(p00, p11, -p01 * p01));
+  const double q00 = p11 * idet, q01 = -p01 * idet, q11 = p00 * idet;
+  double u[4], v[4], c0[4], c1[4], x0[4], x1[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ci[r] = sc->col[K][4 * ti + r] * inv;
+  for (int r = 0; r < 4; ++r) {
+    const double a0 = sc->col[K][4 * ti + r], a1 = sc->col[K + 1][4 * ti + r];
+    u[r] = fma(a0, q00, a1 * q01);
+    v[r] = fma(a0, q01, a1 * q11);
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    cj[c] = sc->col[K][4 * tj + c];
-    xr[c] = sc->row[K][4 * tj + c];
+    c0[c] = sc->col[K][4 * tj + c];
+    c1[c] = sc->col[K + 1][4 * tj + c];
+    x0[c] = sc->row[K][4 * tj + c];
+    x1[c] = sc->row[K + 1][4 * tj + c];
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      a[r][c] = fma(-ci[r], cj[c], a[r][c]);
-      x[r][c] = fma(-ci[r], xr[c], x[r][c]);
+      a[r][c] = fma(-u[r], c0[c], fma(-v[r], c1[c], a[r][c]));
+      x[r][c] = fma(-u[r], x0[c], fma(-v[r], x1[c], x[r][c]));
     }
-  if constexpr (K + 1 < 64) potrf64_pivot<K + 1>(a, x, sc, ti, tj);
 }
 
 // a[][] holds this thread's 4x4 sub-block of the SPD tile on entry (lower triangle is what
@@ -89,14 +109,27 @@ __device__ __forceinline__ void potrf64_reg(double (&a)[4][4], double (&x)[4][4]
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) x[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
-  potrf64_pivot<0>(a, x, sc, ti, tj);
+#pragma unroll 1
+  for (int kb = 0; kb < 16; ++kb) {
+    potrf64_pair<0>(a, x, sc, ti, tj, kb);
+    potrf64_pair<2>(a, x, sc, ti, tj, kb);
+  }
   __syncthreads();
-  if (tid < 64) {
-    const double piv = sc->col[tid][tid];
+  if (tid < 32) {
+    const int k = 2 * tid;
+    const double p00 = sc->col[k][k], p01 = sc->col[k][k + 1], p11 = sc->col[k + 1][k + 1];
+    const double g = p01 / p00;
+    const double p11e = fma(-g, p01, p11);           // pivot k+1 after eliminating pivot k
     // first non-positive (or NaN) pivot wins; everything after it is garbage anyway
-    const unsigned long long bad = __ballot(!(piv > 0.0));
-    if (bad && tid == 0) atomicCAS(status, 0, col_base + __builtin_ctzll(bad) + 1);
-    sc->rs[tid] = 1.0 / sqrt(piv);
+    const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
+    if ((bad0 | bad1) && tid == 0) {
+      const int f0 = bad0 ? 2 * __builtin_ctzll(bad0) : 128, f1 = bad1 ? 2 * __builtin_ctzll(bad1) + 1 : 128;
+      atomicCAS(status, 0, col_base + (f0 < f1 ? f0 : f1) + 1);
+    }
+    sc->rs[k] = 1.0 / sqrt(p00);
+    sc->rs[k + 1] = 1.0 / sqrt(p11e);
+    sc->g[k] = 0.0;
+    sc->g[k + 1] = g;
   }
   __syncthreads();
 #pragma unroll
@@ -104,8 +137,17 @@ __device__ __forceinline__ void potrf64_reg(double (&a)[4][4], double (&x)[4][4]
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = 4 * ti + r, col = 4 * tj + c;
-      a[r][c] = (col <= row) ? sc->col[col][row] * sc->rs[col] : 0.0;
-      x[r][c] = (col <= row) ? sc->row[row][col] * sc->rs[row] : 0.0;
+      double lv = 0.0, xv = 0.0;
+      if (col <= row) {
+        lv = sc->col[col][row];
+        if (col & 1) lv = fma(-sc->g[col], sc->col[col - 1][row], lv);
+        lv *= sc->rs[col];
+        xv = sc->row[row][col];
+        if (row & 1) xv = fma(-sc->g[row], sc->row[row - 1][col], xv);
+        xv *= sc->rs[row];
+      }
+      a[r][c] = lv;
+      x[r][c] = xv;
     }
 }
 

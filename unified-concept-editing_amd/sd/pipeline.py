@@ -1,0 +1,348 @@
+"""Minimal Stable-Diffusion inference pipeline with the surface the reference scripts use:
+    pipe.unet, pipe.tokenizer, pipe.encode_prompt(...), pipe.to(...), pipe(prompt, ...).images
+(trainscripts/uce_sd_erase.py:29-39,197-200; evalscripts/generate-images-sd.py:13-19,37-42).
+
+Weights: a local diffusers-format directory (`--model_dir`) when one exists, otherwise
+seeded-random weights of the named architecture (`--synthetic_model`): the machines this runs on
+have no network, no checkpoints and no tokenizer vocabulary, so throughput is measured on
+synthetic weights and says so.  Numerical parity of full images with a real diffusers run is
+UNPINNED; the pieces that are pinned are the closed-form edit (golden fixtures from
+the reference itself) and the cross-attention kernel (torch SDPA goldens).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import zlib
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .scheduler import PNDMScheduler
+from .unet import UNet2DConditionModel, UNetConfig
+
+MAX_LEN = 77
+BOS, EOS = 49406, 49407
+
+
+# ------------------------------------------------------------------------------------ tokenizer
+
+class SyntheticTokenizer:
+    """Stand-in for CLIPTokenizer when no vocabulary is on disk: one id per whitespace word
+    (crc32 hash), BOS/EOS framing, EOS padding, truncation at 77 - the same call signature and the
+    same attention_mask semantics the reference relies on (uce_sd_erase.py:34-39)."""
+    model_max_length = MAX_LEN
+
+    def __call__(self, text, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
+        texts = [text] if isinstance(text, str) else list(text)
+        L = max_length or MAX_LEN
+        ids = torch.full((len(texts), L), EOS, dtype=torch.long)
+        mask = torch.zeros(len(texts), L, dtype=torch.long)
+        for i, t in enumerate(texts):
+            toks = [BOS] + [zlib.crc32(w.lower().encode("utf-8")) % 49000 + 256 for w in t.split()][: L - 2] + [EOS]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+def load_tokenizer(model_dir: Optional[str]):
+    if model_dir and os.path.isdir(os.path.join(model_dir, "tokenizer")):
+        from transformers import CLIPTokenizer
+        return CLIPTokenizer.from_pretrained(os.path.join(model_dir, "tokenizer"))
+    return SyntheticTokenizer()
+
+
+# ------------------------------------------------------------------------------------ text encoder
+
+@dataclass
+class TextConfig:
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+
+    @classmethod
+    def tiny(cls, hidden: int = 64):
+        return cls(hidden, hidden * 2, 2, 2)
+
+
+def build_text_encoder(cfg: TextConfig, model_dir: Optional[str] = None):
+    from transformers import CLIPTextConfig, CLIPTextModel
+    if model_dir and os.path.isdir(os.path.join(model_dir, "text_encoder")):
+        return CLIPTextModel.from_pretrained(os.path.join(model_dir, "text_encoder"))
+    c = CLIPTextConfig(vocab_size=49408, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                       num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                       max_position_embeddings=MAX_LEN, hidden_act="quick_gelu")
+    return CLIPTextModel(c)
+
+
+# ------------------------------------------------------------------------------------ VAE decoder
+
+class _VaeResnet(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(32, cout, eps=1e-6)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        h = self.conv2(F.silu(self.norm2(self.conv1(F.silu(self.norm1(x))))))
+        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+
+class _VaeAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, c, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        h = self.group_norm(x).view(B, C, H * W).transpose(1, 2)
+        o = F.scaled_dot_product_attention(self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None])[:, 0]
+        return x + self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W)
+
+
+class _VaeUp(nn.Module):
+    def __init__(self, cin, cout, add_up):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VaeResnet(cin if i == 0 else cout, cout) for i in range(3)])
+        self.upsamplers = nn.ModuleList([_UpConv(cout)]) if add_up else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return x if self.upsamplers is None else self.upsamplers[0](x)
+
+
+class _UpConv(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class _VaeMid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attentions = nn.ModuleList([_VaeAttention(c)])
+        self.resnets = nn.ModuleList([_VaeResnet(c, c), _VaeResnet(c, c)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class _Decoder(nn.Module):
+    def __init__(self, ch=(128, 256, 512, 512), latent=4):
+        super().__init__()
+        rev = list(reversed(ch))
+        self.conv_in = nn.Conv2d(latent, rev[0], 3, padding=1)
+        self.up_blocks = nn.ModuleList([])
+        self.mid_block = _VaeMid(rev[0])
+        prev = rev[0]
+        for i, c in enumerate(rev):
+            self.up_blocks.append(_VaeUp(prev, c, add_up=i < len(rev) - 1))
+            prev = c
+        self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[0], 3, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for u in self.up_blocks:
+            x = u(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class VaeDecoder(nn.Module):
+    """AutoencoderKL's decode path (post_quant_conv + decoder), scaling factor 0.18215."""
+    scaling_factor = 0.18215
+
+    def __init__(self, ch=(128, 256, 512, 512)):
+        super().__init__()
+        self.post_quant_conv = nn.Conv2d(4, 4, 1)
+        self.decoder = _Decoder(ch)
+
+    def decode(self, latents):
+        return self.decoder(self.post_quant_conv(latents / self.scaling_factor))
+
+
+# ------------------------------------------------------------------------------------ pipeline
+
+@dataclass
+class PipeOutput:
+    images: list
+    latents: torch.Tensor
+
+
+class StableDiffusionPipeline:
+    def __init__(self, unet: UNet2DConditionModel, text_encoder, tokenizer, vae: Optional[VaeDecoder],
+                 scheduler: Optional[PNDMScheduler] = None):
+        self.unet, self.text_encoder, self.tokenizer, self.vae = unet, text_encoder, tokenizer, vae
+        self.scheduler = scheduler or PNDMScheduler()
+        self.device = torch.device("cpu")
+        self.dtype = torch.float32
+        self.hoist_context = True        # K/V of the (step-invariant) text context computed once per prompt
+
+    # -- same call the reference makes: DiffusionPipeline.from_pretrained(...).to(device)
+    def to(self, device=None, dtype=None):
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        for m in (self.unet, self.text_encoder, self.vae):
+            if m is not None:
+                m.to(device=device, dtype=dtype)
+        if device is not None:
+            self.device = torch.device(device)
+        if dtype is not None:
+            self.dtype = dtype
+        return self
+
+    def set_progress_bar_config(self, **kw):
+        pass
+
+    @torch.no_grad()
+    def encode_prompt(self, prompt, device=None, num_images_per_prompt: int = 1,
+                      do_classifier_free_guidance: bool = False, negative_prompt=None, **kw):
+        device = torch.device(device) if device is not None else self.device
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+
+        def enc(texts):
+            tok = self.tokenizer(texts, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                 truncation=True, return_tensors="pt")
+            out = self.text_encoder(input_ids=tok["input_ids"].to(device))[0]
+            return out.to(self.dtype).repeat_interleave(num_images_per_prompt, dim=0)
+
+        pe = enc(prompts)
+        ne = None
+        if do_classifier_free_guidance:
+            neg = [""] * len(prompts) if negative_prompt is None else (
+                [negative_prompt] * len(prompts) if isinstance(negative_prompt, str) else list(negative_prompt))
+            ne = enc(neg)
+        return pe, ne
+
+    @torch.no_grad()
+    def __call__(self, prompt, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 num_images_per_prompt: int = 1, generator: Optional[torch.Generator] = None,
+                 output_type: str = "pil", height: int = None, width: int = None, **kw) -> PipeOutput:
+        n = num_images_per_prompt
+        cfg = guidance_scale > 1.0
+        pe, ne = self.encode_prompt(prompt, self.device, n, cfg)
+        ctx = torch.cat([ne, pe]) if cfg else pe
+        s = self.unet.cfg.sample_size
+        hh, ww = (height // 8 if height else s), (width // 8 if width else s)
+        # diffusers' randn_tensor: a CPU generator draws on the CPU in the target dtype, then moves
+        gdev = generator.device if generator is not None else self.device
+        latents = torch.randn((n, self.unet.cfg.in_channels, hh, ww), generator=generator, device=gdev,
+                              dtype=self.dtype).to(self.device)
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps, device="cpu")
+        latents = latents * sch.init_noise_sigma
+        if self.hoist_context:
+            self.unet.cache_context(ctx)
+        try:
+            for t in sch.timesteps.tolist():
+                x = torch.cat([latents] * 2) if cfg else latents
+                eps = self.unet(x, torch.tensor([t], device=self.device), ctx)
+                if cfg:
+                    eu, ec = eps.chunk(2)
+                    eps = eu + guidance_scale * (ec - eu)
+                latents = sch.step(eps, t, latents)
+        finally:
+            self.unet.cache_context(None)
+        images: list = []
+        if output_type != "latent" and self.vae is not None:
+            img = self.vae.decode(latents).float()
+            img = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()
+            if output_type == "pil":
+                from PIL import Image
+                images = [Image.fromarray((im * 255).round().astype("uint8")) for im in img]
+            else:
+                images = list(img)
+        return PipeOutput(images=images, latents=latents)
+
+
+# ------------------------------------------------------------------------------------ loading
+
+ARCH = {
+    "CompVis/stable-diffusion-v1-4": ("sd1", 768),
+    "runwayml/stable-diffusion-v1-5": ("sd1", 768),
+    "tiny-sd-test": ("tiny", 64),
+}
+
+
+def _seeded_init(module: nn.Module, seed: int) -> None:
+    g = torch.Generator().manual_seed(seed)
+    for p in module.parameters():
+        with torch.no_grad():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / math.sqrt(fan_in))
+            elif "norm" in "":  # never true: norm weights keep their default (1 / 0)
+                pass
+
+
+def load_pipeline(model_id: str, torch_dtype=torch.float32, device="cpu", model_dir: Optional[str] = None,
+                  synthetic: bool = False, vae: bool = True, seed: int = 0) -> StableDiffusionPipeline:
+    """`DiffusionPipeline.from_pretrained(model_id, ...)` replacement.  Order: real diffusers if
+    importable and not synthetic -> local directory -> seeded-random weights (only on request)."""
+    if not synthetic and model_dir is None:
+        try:  # a machine that has diffusers + weights: use the real thing, the edit/generate code is agnostic
+            from diffusers import DiffusionPipeline  # type: ignore
+            kw = dict(torch_dtype=torch_dtype, safety_checker=None)
+            if not vae:
+                kw["vae"] = None
+            return DiffusionPipeline.from_pretrained(model_id, **kw).to(device)
+        except ImportError:
+            raise RuntimeError(
+                f"cannot load '{model_id}': diffusers is not installed and no --model_dir was given. "
+                "Pass --model_dir <diffusers-format directory> or --synthetic_model (random weights).")
+    kind, _ = ARCH.get(model_id, ("sd1", 768))
+    ucfg = UNetConfig.tiny() if kind == "tiny" else UNetConfig.sd14()
+    tcfg = TextConfig.tiny(ucfg.cross_attention_dim) if kind == "tiny" else TextConfig()
+    torch.manual_seed(seed)
+    unet = UNet2DConditionModel(ucfg)
+    text = build_text_encoder(tcfg, model_dir)
+    vae_m = VaeDecoder((32, 32, 64, 64) if kind == "tiny" else (128, 256, 512, 512)) if vae else None
+    if model_dir:
+        from safetensors.torch import load_file
+        up = os.path.join(model_dir, "unet", "diffusion_pytorch_model.safetensors")
+        unet.load_state_dict(load_file(up), strict=True)
+        vp = os.path.join(model_dir, "vae", "diffusion_pytorch_model.safetensors")
+        if vae_m is not None and os.path.exists(vp):
+            sd = {k: v for k, v in load_file(vp).items() if k.startswith(("decoder.", "post_quant_conv."))}
+            vae_m.load_state_dict(sd, strict=False)
+    for m in (unet, text, vae_m):
+        if m is not None:
+            m.eval().requires_grad_(False)
+    pipe = StableDiffusionPipeline(unet, text, load_tokenizer(model_dir), vae_m)
+    return pipe.to(device, torch_dtype)
+
+
+def patch_unet(pipe, state: Dict[str, torch.Tensor]) -> List[str]:
+    """`pipe.unet.load_state_dict(uce_weights, strict=False)` (generate-images-sd.py:17-19), with the
+    fp32 -> bf16 cast done by the HIP kernel when the parameters live on a GPU in bf16."""
+    params = dict(pipe.unet.named_parameters())
+    unknown = [k for k in state if k not in params]
+    if unknown:
+        raise KeyError(f"keys not in the U-Net: {unknown[:3]}...")
+    handle = None
+    for k, v in state.items():
+        p = params[k]
+        if tuple(p.shape) != tuple(v.shape):
+            raise ValueError(f"{k}: shape {tuple(v.shape)} vs parameter {tuple(p.shape)}")
+        if p.is_cuda and p.dtype == torch.bfloat16 and v.dtype == torch.float32:
+            from .. import edit as _edit
+            handle = handle or _edit.UceHandle.get(p.device)
+            handle.cast_bf16(v.to(p.device).contiguous(), p.data)
+        else:
+            p.data.copy_(v.to(device=p.device, dtype=p.dtype))
+    return list(state)

@@ -1,0 +1,315 @@
+"""A self-contained Stable-Diffusion U-Net (UNet2DConditionModel of SD-1.x / SD-2.x) in plain
+PyTorch with diffusers-compatible parameter names, so that (a) the reference's name predicate
+('attn2' ... 'to_k'/'to_v', uce_sd_erase.py:17-20) finds the same 32 modules, (b) edited
+safetensors artifacts patch it by name with load_state_dict(strict=False)
+(generate-images-sd.py:17-19) and (c) a real diffusers-format checkpoint directory loads into it.
+
+`diffusers` is not installed on the machines this runs on; the architecture below restates the
+published SD-1.x U-Net (diffusers==0.33.0 models/unets/unet_2d_condition.py, unet_2d_blocks.py,
+transformers/transformer_2d.py, attention.py - requirements.txt:1 of the reference; not vendored
+there).  Numerical parity with a real diffusers run is UNPINNED (no weights, no diffusers here).
+
+The cross-attention (attn2) core runs in the hand-written HIP kernel `uce_xattn_fwd` through
+the C ABI when the module lives on a GPU in bf16/f16; everything else is stock torch ops.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    cross_attention_dim: int = 768
+    attention_head_dim: int = 8          # SD-1.x: number of heads (diffusers' historical misnomer)
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                         "CrossAttnDownBlock2D", "DownBlock2D")
+    up_block_types: Tuple[str, ...] = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D",
+                                       "CrossAttnUpBlock2D")
+    norm_num_groups: int = 32
+    sample_size: int = 64
+
+    @classmethod
+    def sd14(cls) -> "UNetConfig":
+        return cls()
+
+    @classmethod
+    def tiny(cls) -> "UNetConfig":
+        """Same topology, small widths: for CPU tests."""
+        return cls(block_out_channels=(32, 64, 64, 64), cross_attention_dim=64, attention_head_dim=2,
+                   norm_num_groups=8, sample_size=8)
+
+
+# ------------------------------------------------------------------------------------ pieces
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """Sinusoidal embedding, flip_sin_to_cos=True, freq_shift=0 (SD-1.x settings)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim: int, dim: int):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin: int, cout: int, temb: int, groups: int):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=1e-5)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=1e-5)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Attention(nn.Module):
+    """diffusers `Attention` with the default processor: to_q/to_k/to_v (no bias), to_out[0]."""
+
+    def __init__(self, query_dim: int, heads: int, dim_head: int, cross_dim: Optional[int] = None):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.is_cross = cross_dim is not None
+        kv_dim = cross_dim if cross_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(kv_dim, inner, bias=False)
+        self.to_v = nn.Linear(kv_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None   # hoisted K/V of a constant context
+
+    def forward(self, x, context=None):
+        ctx = x if context is None else context
+        q = self.to_q(x)
+        if self.is_cross and self.kv_cache is not None:
+            k, v = self.kv_cache
+        else:
+            k, v = self.to_k(ctx), self.to_v(ctx)
+        o = _attention_core(q, k, v, self.heads, self.is_cross)
+        return self.to_out[0](o)
+
+
+def _attention_core(q, k, v, heads: int, is_cross: bool):
+    """[B, L, C] in / out.  Cross-attention on a GPU in bf16/f16 -> the HIP kernel; otherwise SDPA."""
+    if is_cross and q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.shape[1] <= 128 \
+            and (q.shape[2] // heads) % 8 == 0 and q.shape[2] // heads <= 160:
+        from .. import edit as _edit
+        return _edit.UceHandle.get(q.device).xattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+    B, Lq, C = q.shape
+    dh = C // heads
+
+    def split(t):
+        return t.view(B, t.shape[1], heads, dh).transpose(1, 2)
+
+    o = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=None, dropout_p=0.0, is_causal=False)
+    return o.transpose(1, 2).reshape(B, Lq, C)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim: int, inner: int):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, dim_head: int, cross_dim: int):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, heads, dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, heads, dim_head, cross_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), context)
+        return x + self.ff(self.norm3(x))
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, channels: int, heads: int, cross_dim: int, groups: int):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, channels, eps=1e-6)
+        self.proj_in = nn.Conv2d(channels, channels, 1)      # SD-1.x: conv projections
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(channels, heads, channels // heads, cross_dim)])
+        self.proj_out = nn.Conv2d(channels, channels, 1)
+
+    def forward(self, x, context):
+        B, C, H, W = x.shape
+        h = self.proj_in(self.norm(x))
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return self.proj_out(h) + x
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, groups, layers, cross: bool, heads, cross_dim, add_down: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(layers)])
+        if cross:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(layers)])
+        self.has_cross = cross
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
+
+    def forward(self, x, temb, context):
+        outs = []
+        for i, res in enumerate(self.resnets):
+            x = res(x, temb)
+            if self.has_cross:
+                x = self.attentions[i](x, context)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, cprev, temb, groups, layers, cross: bool, heads, cross_dim, add_up: bool):
+        super().__init__()
+        res = []
+        for i in range(layers):
+            skip = cin if i == layers - 1 else cout
+            rin = cprev if i == 0 else cout
+            res.append(ResnetBlock2D(rin + skip, cout, temb, groups))
+        self.resnets = nn.ModuleList(res)
+        if cross:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(layers)])
+        self.has_cross = cross
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
+
+    def forward(self, x, skips: List[torch.Tensor], temb, context):
+        for i, res in enumerate(self.resnets):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = res(x, temb)
+            if self.has_cross:
+                x = self.attentions[i](x, context)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class MidBlock(nn.Module):
+    def __init__(self, c, temb, groups, heads, cross_dim):
+        super().__init__()
+        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, cross_dim, groups)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups), ResnetBlock2D(c, c, temb, groups)])
+
+    def forward(self, x, temb, context):
+        x = self.resnets[0](x, temb)
+        x = self.attentions[0](x, context)
+        return self.resnets[1](x, temb)
+
+
+class UNet2DConditionModel(nn.Module):
+    """Registration order (conv_in, time_embedding, down_blocks, up_blocks, mid_block, ...) follows
+    diffusers so that named_modules() yields the attn2 projections in the same order."""
+
+    def __init__(self, cfg: UNetConfig = UNetConfig()):
+        super().__init__()
+        self.cfg = cfg
+        ch = cfg.block_out_channels
+        temb = ch[0] * 4
+        g = cfg.norm_num_groups
+        heads = cfg.attention_head_dim
+        self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb)
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])
+        out = ch[0]
+        for i, t in enumerate(cfg.down_block_types):
+            cin, out = out, ch[i]
+            self.down_blocks.append(DownBlock(cin, out, temb, g, cfg.layers_per_block, t.startswith("CrossAttn"),
+                                              heads, cfg.cross_attention_dim, add_down=i < len(ch) - 1))
+        self.mid_block = MidBlock(ch[-1], temb, g, heads, cfg.cross_attention_dim)
+        rev = list(reversed(ch))
+        out = rev[0]
+        for i, t in enumerate(cfg.up_block_types):
+            prev, out = out, rev[i]
+            cin = rev[min(i + 1, len(ch) - 1)]
+            self.up_blocks.append(UpBlock(cin, out, prev, temb, g, cfg.layers_per_block + 1, t.startswith("CrossAttn"),
+                                          heads, cfg.cross_attention_dim, add_up=i < len(ch) - 1))
+        self.conv_norm_out = nn.GroupNorm(g, ch[0], eps=1e-5)
+        self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
+
+    # -- context hoisting: K/V of the text context do not change over the denoising loop -----------
+    def cache_context(self, context: Optional[torch.Tensor]) -> None:
+        for m in self.modules():
+            if isinstance(m, Attention) and m.is_cross:
+                m.kv_cache = None if context is None else (m.to_k(context), m.to_v(context))
+
+    def forward(self, sample, timestep, encoder_hidden_states):
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], device=sample.device)
+        t = t.reshape(-1).expand(sample.shape[0])
+        temb = self.time_embedding(timestep_embedding(t, self.cfg.block_out_channels[0]).to(sample.dtype))
+        x = self.conv_in(sample)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, temb, encoder_hidden_states)
+            skips.extend(outs)
+        x = self.mid_block(x, temb, encoder_hidden_states)
+        for blk in self.up_blocks:
+            x = blk(x, skips, temb, encoder_hidden_states)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
