@@ -114,6 +114,50 @@ def cpu_baseline(inp, budget_s: float = 12.0):
                        f"({len(ws)} modules) = {whole:.3f} s extrapolated per width class")
 
 
+def generation_leg(device, world, n_images, steps, edited_slab, inp):
+    """Secondary figure (BASELINE.json's second metric): images/s of the edited SD-1.4 pipeline,
+    512x512, `steps` PNDM steps (+1 U-Net call), guidance 7.5, bf16, CPU-seeded latents, synthetic
+    (seeded-random) weights, cross-attention through uce_xattn_fwd.  Every rank generates its own
+    `n_images` prompts (the sharded rows of evalscripts/generate-images-sd.py); the edited attn2
+    weights are broadcast from rank 0 first when world > 1."""
+    from uce_amd.sd import pipeline as sdp
+    from uce_amd import edit as E
+    _log("generation leg: building the synthetic SD-1.4 pipeline")
+    pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.bfloat16, device, synthetic=True, vae=True)
+    if edited_slab is not None:
+        blob = edited_slab.clone()
+        if world > 1:
+            torch.distributed.broadcast(blob, src=0)          # RCCL over xGMI: the one exchange step
+        mods = E.collect_uce_modules(pipe.unet)
+        off = 0
+        state = {}
+        for n, m in mods:
+            r = m.weight.shape[0]
+            state[n + ".weight"] = blob[off:off + r]
+            off += r
+        sdp.patch_unet(pipe, state)
+    rank = int(os.environ.get("RANK", "0"))
+    pipe("warm up", num_inference_steps=2, generator=torch.Generator().manual_seed(0))
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_images):
+        pipe(f"synthetic prompt {rank * n_images + i}", num_inference_steps=steps, guidance_scale=7.5,
+             generator=torch.Generator().manual_seed(1000 + rank * n_images + i))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    return {"metric": "images/sec 512x512 50-step", "value": round(world * n_images / el, 4), "unit": "images/s",
+            "n_gpus": world, "images_per_rank": n_images, "steps": steps, "dtype": "bf16", "scaling": "weak",
+            "data": "synthetic weights, synthetic prompts, CPU-seeded latents", "seconds": round(el, 3)}
+
+
 def time_kernel(fn, iters: int):
     """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
     back-to-back launches (the library enqueues on torch's current stream)."""
@@ -136,6 +180,9 @@ def main() -> None:
     ap.add_argument("--workload", default="sd14_erase50", choices=sorted(WORKLOADS))
     ap.add_argument("--algo", default="auto", choices=["auto", "primal", "dual"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-images", type=int, default=2,
+                    help="images per rank for the secondary images/s figure (0 = skip)")
+    ap.add_argument("--gen-steps", type=int, default=50)
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -216,6 +263,9 @@ def main() -> None:
         except Exception:
             pass
 
+    gen = None
+    if args.gen_images > 0:
+        gen = generation_leg(device, world, args.gen_images, args.gen_steps, out if out.shape[1] == 768 else None, inp)
     result = {
         "metric": "concepts/sec closed-form edit (SD-1.4, 768-d)",
         "value": round(world * N * args.steps / elapsed, 1),
@@ -235,6 +285,8 @@ def main() -> None:
                    "parallelism": "replicas only" if world > 1 else "single GPU"},
         "roofline": roof,
     }
+    if gen is not None:
+        result["generate"] = gen
     if rank == 0:
         _log("gpu part: " + json.dumps(result))
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,111 @@
+"""GPU: the drop-in scripts end to end on synthetic weights (no checkpoints exist on these
+machines): erase CLI -> artifact -> generation with the patched U-Net (cross-attention through the
+HIP kernel), and the debias driver against its golden with a scripted sampling step."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+from tests.golden_io import Case
+from uce_amd import REPO_ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_erase_cli_then_generate_cli(tmp_path):
+    from safetensors.torch import load_file
+    env = dict(os.environ)
+    erase = os.path.join(REPO_ROOT, "trainscripts", "uce_sd_erase.py")
+    gen = os.path.join(REPO_ROOT, "evalscripts", "generate-images-sd.py")
+    r = subprocess.run([sys.executable, erase, "--model_id", "tiny-sd-test", "--synthetic_model",
+                        "--edit_concepts", "Van Gogh; Picasso", "--concept_type", "art",
+                        "--preserve_concepts", "Monet", "--save_dir", str(tmp_path), "--exp_name", "tiny_edit"],
+                       check=True, env=env, capture_output=True, text=True, timeout=600)
+    assert "Erasing: ['Van Gogh', 'Picasso']" in r.stdout and "Guiding: ['art', 'art']" in r.stdout
+    assert "Model edited in" in r.stdout
+    state = load_file(str(tmp_path / "tiny_edit.safetensors"))
+    assert len(state) == 32 and all(k.endswith(".weight") and "attn2" in k for k in state)
+    prompts = tmp_path / "p.csv"
+    pd.DataFrame({"case_number": [0, 1], "prompt": ["a painting by Van Gogh", "a dog"],
+                  "evaluation_seed": [7, 8]}).to_csv(prompts, index=False)
+    subprocess.run([sys.executable, gen, "--model_id", "tiny-sd-test", "--synthetic_model", "--prompts_path",
+                    str(prompts), "--save_path", str(tmp_path), "--exp_name", "imgs", "--uce_model_path",
+                    str(tmp_path / "tiny_edit.safetensors"), "--num_inference_steps", "3"],
+                   check=True, env=env, timeout=600)
+    assert sorted(os.listdir(tmp_path / "imgs")) == ["0_0.png", "1_0.png"]
+
+
+def test_unet_cross_attention_runs_through_hip_kernel_and_matches_fp32():
+    """bf16 U-Net forward on the GPU (attn2 -> uce_xattn_fwd) vs the same weights in fp32 on the CPU."""
+    from uce_amd.sd import pipeline as sdp
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False, seed=3)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    ctx = torch.randn(2, 77, 64, generator=g)
+    t = torch.tensor([500])
+    ref = pipe.unet(x, t, ctx)
+    pipe.to("cuda:0", torch.bfloat16)
+    calls = {"n": 0}
+    from uce_amd import edit as E
+    orig = E.UceHandle.xattn
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+
+    E.UceHandle.xattn = counted
+    try:
+        out = pipe.unet(x.cuda().bfloat16(), t.cuda(), ctx.cuda().bfloat16()).float().cpu()
+    finally:
+        E.UceHandle.xattn = orig
+    assert calls["n"] == 16                                   # one per attn2 (16 transformer blocks)
+    assert O.rel_fro(out, ref) < 5e-2                         # bf16 network vs fp32
+
+
+def test_patch_unet_bf16_cast_matches_torch():
+    from uce_amd import edit as E
+    from uce_amd.sd import pipeline as sdp
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.bfloat16, "cuda:0", synthetic=True, vae=False)
+    mods = E.collect_uce_modules(pipe.unet)
+    g = torch.Generator().manual_seed(1)
+    state = {n + ".weight": torch.randn(m.weight.shape, generator=g) for n, m in mods}
+    sdp.patch_unet(pipe, state)
+    for n, m in mods:
+        assert torch.equal(m.weight.cpu(), state[n + ".weight"].to(torch.bfloat16))
+
+
+def test_debias_driver_scripted_matches_golden(tmp_path):
+    """debias.UCE with the sampling step scripted (the reference's is unseeded) on the golden's
+    embeddings and weights: final artifact vs the reference's."""
+    from safetensors.torch import load_file
+    from tests import fakepipe
+    from uce_amd import debias
+    c = Case("debias_n4x2_d768")
+    m = c.meta
+    rng = np.random.Generator(np.random.PCG64(12))
+    from tests.tools_shim import FIXTURE_TABLE
+    unet = fakepipe.build_unet(FIXTURE_TABLE, 768, rng)
+    pipe = fakepipe.FakePipe(unet, 768)
+    scripted = iter(list(c.arr("direction_scales")))
+    slab, path = debias.UCE(pipe, None, m["edit"], m["debias"], m["preserve"], m["edit_scale"], m["preserve_scale"],
+                            m["lamb"], str(tmp_path), "deb", 0.05, 0.1, 10, 20, 7.5, desired_ratios=[0.5, 0.5],
+                            max_iterations=5, device="cuda:0", ratios_fn=lambda **kw: next(scripted))
+    state = load_file(path)
+    for i, n in enumerate(m["modules"]):
+        ref, ex = c.t(f"W_ref32_{i}"), c.t(f"W_exact64_{i}")
+        assert torch.equal(c.t(f"W_old_{i}"), unet.get_submodule(n).weight)
+        assert O.rel_fro(state[n + ".weight"], ex) < 1e-5
+        assert O.rel_fro(state[n + ".weight"], ref) < max(1e-4, 1.5 * O.rel_fro(ref, ex))
+
+
+def test_debias_ratio_arithmetic():
+    from uce_amd import debias
+    r = debias.ratios_from_labels(["male"] * 7 + ["female"] * 3, ["male", "female"], [0.5, 0.5], 0.05)
+    assert np.allclose(r, [-0.2, 0.2])
+    r = debias.ratios_from_labels(["male"] * 5 + ["female"] * 5, ["male", "female"], [0.52, 0.48], 0.05)
+    assert np.all(r == 0)

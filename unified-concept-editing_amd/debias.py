@@ -1,0 +1,92 @@
+"""Debias driver: the drop-in for `get_ratios` + `UCE` of the reference's
+trainscripts/uce_sd_debias.py:14-35, 37-149.
+
+Per iteration (uce_sd_debias.py:95-141): patch the U-Net with the current weights, generate
+`num_images_per_prompt` images per edit concept, zero-shot classify them against the debias
+concepts, turn the observed ratios into `direction_scale = desired - observed` (zeroed when every
+|diff| < max_diff), stop when everything is balanced, otherwise re-solve the closed form with the
+CUMULATIVE drift (the reference adds the drift in place to its cached guide outputs, so it
+accumulates; `step_size` is parsed but never used there - kept that way).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, List, Sequence
+
+import numpy as np
+import torch
+
+from . import edit as E
+from .sd import pipeline as sdp
+
+
+def ratios_from_labels(labels: Sequence[str], debias_concepts: Sequence[str], desired_ratios: Sequence[float],
+                       max_diff: float) -> np.ndarray:
+    """uce_sd_debias.py:28-32."""
+    results = np.array(list(labels))
+    ratios = np.array([desired - (sum(results == c) / len(results)) for c, desired in zip(debias_concepts, desired_ratios)])
+    if max(ratios) < max_diff and abs(min(ratios)) < max_diff:
+        ratios = 0 * ratios
+    return ratios
+
+
+def get_ratios(pipe, classify: Callable, slab: E.WeightSlab, edit_concepts, debias_concepts, desired_ratios, max_diff,
+               num_images_per_prompt=10, num_inference_steps=20, guidance_scale=7.5) -> np.ndarray:
+    """uce_sd_debias.py:14-35 (images are sampled UNSEEDED there too)."""
+    state = slab.state_dict()
+    if hasattr(pipe.unet, "cfg"):
+        sdp.patch_unet(pipe, state)
+    else:
+        pipe.unet.load_state_dict(state, strict=False)
+    direction_scale = []
+    for concept in edit_concepts:
+        images = pipe(concept, num_inference_steps=num_inference_steps, num_images_per_prompt=num_images_per_prompt,
+                      guidance_scale=guidance_scale).images
+        labels = classify(images, debias_concepts)
+        direction_scale.append(ratios_from_labels(labels, debias_concepts, desired_ratios, max_diff))
+    return np.array(direction_scale)
+
+
+def clip_zero_shot_classifier(device):
+    """The reference's classifier (uce_sd_debias.py:245-250): CLIP ViT-B/32 zero-shot, top-1 label."""
+    from transformers import pipeline as hf_pipeline
+    clf = hf_pipeline(task="zero-shot-image-classification", model="openai/clip-vit-base-patch32",
+                      torch_dtype=torch.bfloat16, device=device)
+
+    def classify(images, labels):
+        return [r[0]["label"] for r in clf(images, candidate_labels=list(labels))]
+    return classify
+
+
+def UCE(pipe, classify, edit_concepts, debias_concepts, preserve_concepts, edit_scale, preserve_scale, lamb, save_dir,
+        exp_name, max_diff, step_size, num_images_per_prompt, num_inference_steps, guidance_scale,
+        desired_ratios=(0.5, 0.5), max_iterations=30, device="cuda:0", ratios_fn=None):
+    """Same positional signature as the reference's debias UCE() (:37); `desired_ratios`,
+    `max_iterations`, `device` replace the module globals it reads; `ratios_fn` lets a test script
+    the (unseeded, irreproducible) sampling step."""
+    handle = E.UceHandle.get(device)
+    modules = E.collect_uce_modules(pipe.unet)
+    slab = E.WeightSlab.from_modules(modules, handle.device)
+    embeds = E.last_token_embeddings(pipe, list(edit_concepts) + list(debias_concepts) + list(preserve_concepts),
+                                     handle.device)
+    C_edit = torch.stack([embeds[e] for e in edit_concepts]).contiguous()
+    C_deb = torch.stack([embeds[c] for c in debias_concepts]).contiguous()
+    C_pres = torch.stack([embeds[p] for p in preserve_concepts]).contiguous() if preserve_concepts else None
+    state = E.DebiasState(handle, slab, C_edit, C_deb, C_pres, edit_scale, preserve_scale, lamb)
+    if hasattr(pipe, "to"):
+        pipe = pipe.to(torch.bfloat16)                         # :90
+    start_time = time.time()
+    for iteration in range(max_iterations):
+        if ratios_fn is not None:
+            direction_scale = ratios_fn(iteration=iteration, slab=state.current)
+        else:
+            direction_scale = get_ratios(pipe, classify, state.current, edit_concepts, debias_concepts, desired_ratios,
+                                         max_diff, num_images_per_prompt, num_inference_steps, guidance_scale)
+        if np.abs(direction_scale).max() == 0:                 # :110-112
+            print("All concepts are debiased")
+            break
+        state.step(direction_scale)
+    end_time = time.time()
+    path = E.save_uce_state(state.current, save_dir, exp_name)
+    print(f"\n\nDebiased concepts using UCE\nModel edited in {end_time - start_time} seconds\n")
+    return state.current, path

@@ -1,0 +1,141 @@
+"""Image-generation eval path: the drop-in for `generate_images` of the reference's
+evalscripts/generate-images-sd.py:10-46, prompt-sharded over the GPUs of one node.
+
+Reference behaviour kept: bf16 pipeline, optional patch of the U-Net with the edited attn2 weights
+(`load_state_dict(strict=False)`, :17-19), one `pipe(...)` call per CSV row with
+`generator=torch.Generator().manual_seed(evaluation_seed)` (a CPU generator, :41), rows filtered by
+`from_case <= case_number <= till_case` (:33), PNGs named `{save_path}/{exp_name}/{case}_{i}.png`.
+
+Added: when launched with WORLD_SIZE > 1 (one process per GPU, torch.distributed; backend nccl =
+RCCL over xGMI on ROCm, gloo on CPU) rank 0 reads the edited-weight file and BROADCASTS the blob
+to the other ranks (one collective, ~77 MB fp32 for SD-1.4), then rank r generates the selected
+rows with `index % world == r`: no data-path collective after that.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .sd import pipeline as sdp
+
+
+def dist_env() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(device: torch.device) -> Tuple[int, int]:
+    rank, world, _ = dist_env()
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = "nccl" if device.type == "cuda" else "gloo"
+            kw = {"device_id": device} if device.type == "cuda" else {}
+            dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def broadcast_uce_weights(path: Optional[str], keys_like, device: torch.device, rank: int, world: int
+                          ) -> Optional[Dict[str, torch.Tensor]]:
+    """Rank 0 loads the safetensors artifact; everyone ends up with the same {name: fp32 tensor}.
+    The tensors travel as ONE flat fp32 buffer (a single broadcast)."""
+    if path is None:
+        return None
+    import torch.distributed as dist
+    from safetensors.torch import load_file
+    if world == 1:
+        return load_file(path)
+    meta: List = [None]
+    state = None
+    if rank == 0:
+        state = load_file(path)
+        meta = [[(k, list(v.shape)) for k, v in state.items()]]
+    dist.broadcast_object_list(meta, src=0)
+    layout = meta[0]
+    total = sum(int(torch.Size(s).numel()) for _, s in layout)
+    flat = torch.empty(total, dtype=torch.float32, device=device)
+    if rank == 0:
+        off = 0
+        for k, shp in layout:
+            n = state[k].numel()
+            flat[off:off + n].copy_(state[k].reshape(-1))
+            off += n
+    dist.broadcast(flat, src=0)
+    out, off = {}, 0
+    for k, shp in layout:
+        n = int(torch.Size(shp).numel())
+        out[k] = flat[off:off + n].view(shp)
+        off += n
+    return out
+
+
+def select_rows(df, from_case: int, till_case: int, rank: int, world: int):
+    """(index, row) pairs this rank generates: the reference's case filter, then round-robin."""
+    picked = [(i, r) for i, (_, r) in enumerate(df.iterrows())
+              if (r.case_number >= from_case and r.case_number <= till_case)]
+    return [(i, r) for j, (i, r) in enumerate(picked) if j % world == rank]
+
+
+def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name="test", device="cuda:0",
+                    torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=100,
+                    num_images_per_prompt=10, from_case=0, till_case=1000000, model_dir=None, synthetic=False,
+                    latents_only=False, skip_existing=False, pipe=None) -> Dict[str, float]:
+    import pandas as pd
+    rank, world, local = dist_env()
+    dev = torch.device(device)
+    if world > 1 and dev.type == "cuda":
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+    rank, world = init_distributed(dev)
+
+    # 1. the pipeline (every rank builds its own replica)
+    if pipe is None:
+        pipe = sdp.load_pipeline(model_id, torch_dtype=torch_dtype, device=dev, model_dir=model_dir,
+                                 synthetic=synthetic, vae=not latents_only)
+    # 2. edited weights: one broadcast from rank 0, then a by-name patch of the attn2 projections
+    state = broadcast_uce_weights(uce_model_path, None, dev, rank, world)
+    if state is not None:
+        if hasattr(pipe.unet, "cfg"):
+            sdp.patch_unet(pipe, state)
+        else:  # a real diffusers pipeline
+            pipe.unet.load_state_dict(state, strict=False)
+
+    df = pd.read_csv(prompts_path)
+    folder_path = f"{save_path}/{exp_name}"
+    os.makedirs(folder_path, exist_ok=True)
+    mine = select_rows(df, from_case, till_case, rank, world)
+
+    t0 = time.perf_counter()
+    n_img = 0
+    for _, row in mine:
+        prompt = str(row.prompt)
+        seed = int(row.evaluation_seed)
+        case_number = row.case_number
+        if skip_existing and os.path.exists(f"{folder_path}/{case_number}_0.png"):
+            continue
+        out = pipe(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                   num_images_per_prompt=num_images_per_prompt,
+                   generator=torch.Generator().manual_seed(seed),
+                   **({"output_type": "latent"} if latents_only else {}))
+        if latents_only:
+            lat = out.latents if hasattr(out, "latents") else out.images
+            torch.save(lat.cpu(), f"{folder_path}/{case_number}.pt")
+        else:
+            for num, im in enumerate(out.images):
+                im.save(f"{folder_path}/{case_number}_{num}.png")
+        n_img += num_images_per_prompt
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    stats = {"images": float(n_img), "seconds": elapsed, "rank": float(rank), "world": float(world)}
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([float(n_img), elapsed], dtype=torch.float64, device=dev)
+        tot = t.clone()
+        dist.all_reduce(tot[:1], op=dist.ReduceOp.SUM)
+        mx = t.clone()
+        dist.all_reduce(mx[1:], op=dist.ReduceOp.MAX)
+        stats["images_total"], stats["seconds_max"] = float(tot[0]), float(mx[1])
+    return stats
