@@ -209,6 +209,7 @@ def main() -> None:
     algo = cli.ALGO_IDS[args.algo]
     out = torch.empty_like(W)
     H.reserve(d, max(N, d))
+    H.reserve_rows(rows, max(n_e, 1))
 
     def step():
         H.edit(C, G, s, 0.5, W, out=out, algo=algo)
@@ -240,7 +241,25 @@ def main() -> None:
     # ---- per-kernel timing of the dominant kernel, HIP events on the launch stream
     use_dual = (algo == 2) or (algo == 0 and ((N + 63) // 64) * 64 < d)
     iters = max(20, min(200, args.steps))
-    if use_dual and n_e <= 256:
+    if use_dual and 33 <= n_e <= 256 and d in (768, 1024, 2048):
+        # uce_edit's path here: projection (+ riders) -> triangular solves -> update; the update is the
+        # HBM-bound pass over the weights and the longest kernel
+        Dm, R = H.dual_factors(C, G, s, 0.5)
+        T = H.lowrank_project(W, Dm)
+        ms = time_kernel(lambda: H.lowrank_update(W, T, R, out=out), iters)
+        nep = T.shape[1]
+        alg_bytes = 8.0 * rows * d + 4.0 * rows * nep + 4.0 * n_e * d      # W in + W out, T in, R once
+        roof = dict(kernel="k_lr_update_r16" if n_e <= 64 else "k_lr_update", bound="hbm",
+                    achieved=round(alg_bytes / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    avg_ms=round(ms, 5), algorithmic_bytes=alg_bytes)
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        ms_p = time_kernel(lambda: H.lowrank_project(W, Dm), iters)
+        flops_p = 2.0 * rows * d * nep
+        roof["second_kernel"] = dict(kernel="k_lr_project", bound="mfma", achieved=round(flops_p / (ms_p * 1e-3) / 1e12, 2),
+                                     peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", avg_ms=round(ms_p, 5),
+                                     frac=round(flops_p / (ms_p * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4),
+                                     note="timed alone, without the Gram+Cholesky rider blocks it carries inside uce_edit")
+    elif use_dual and n_e <= 256:
         Dm, R = H.dual_factors(C, G, s, 0.5)
         ms = time_kernel(lambda: H.apply_lowrank(W, Dm, R, out=out), iters)
         alg_bytes = 8.0 * rows * d + 8.0 * n_e * d          # W in + W out (+ the two factors once)

@@ -11,7 +11,7 @@
  *   - All data pointers are DEVICE pointers owned by the caller (e.g. tensor.data_ptr()).
  *     The library owns only an opaque per-handle workspace (uce_create / uce_reserve).
  *   - All work is enqueued on the caller's stream (pass torch.cuda.current_stream().cuda_stream
- *     as a void*); no call synchronises the device except uce_create/uce_reserve/uce_destroy
+ *     as a void*); no call synchronises the device except uce_create, uce_reserve, uce_reserve_rows, uce_destroy
  *     (allocation) and uce_status (reads one int back).
  *   - One handle per GPU per thread; calls on one handle must not overlap in time.
  *   - Matrices are row-major and dense unless stated.  d (the text-embedding width) must be
@@ -86,6 +86,18 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
 /* Low-rank apply: W_new = W_old + (W_old Dm^T) R, one fused HBM-bound pass (N_edit <= 256). */
 int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const float* R, float* W_new,
                       long rows, int d, int N_edit, uce_stream_t stream);
+
+/* The same update as two kernels (what uce_edit uses for N_edit >= 33, d in {768, 1024, 2048}):
+ *   uce_lowrank_project : T [rows, NEP] f32 = W_old Dm^T,  NEP = roundup(N_edit, 64) is T's row stride.
+ *                         Needs only Dm, not the solve: uce_edit runs the 64x64 Cholesky of the dual
+ *                         system inside the same launch (block 0), hidden under this GEMM.
+ *   uce_lowrank_update  : W_new = W_old + T R   (one HBM-bound pass over the weights).
+ * uce_reserve_rows pre-allocates the handle's own T for uce_edit (rows x roundup(n_edit_max, 64)). */
+int uce_lowrank_project(uce_handle_t h, const float* W_old, const float* Dm, float* T, long rows, int d,
+                        int N_edit, uce_stream_t stream);
+int uce_lowrank_update(uce_handle_t h, const float* W_old, const float* T, const float* R, float* W_new,
+                       long rows, int d, int N_edit, uce_stream_t stream);
+int uce_reserve_rows(uce_handle_t h, long rows_max, int n_edit_max);
 
 /* DeltaT [d,d] f32 from the dual factors (used when N_edit is too large for the low-rank apply). */
 int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int N_edit, int d,

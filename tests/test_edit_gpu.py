@@ -296,3 +296,45 @@ def test_edit_edge_cases(H):
     # invalid arguments are rejected, not crashed on
     with pytest.raises(L.UceError):
         H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, out=W)
+
+
+@pytest.mark.parametrize("Ne,d,rows_", [(50, 768, 24960), (33, 768, 1500), (64, 1024, 2000), (100, 768, 3000),
+                                        (36, 2048, 1300), (200, 768, 1111)])
+def test_lowrank_project_and_update(H, Ne, d, rows_):
+    """The two-kernel low-rank apply (what uce_edit forks over two streams) against fp64."""
+    rng = np.random.Generator(np.random.PCG64(Ne + d))
+    W = O.linear_default_weight(rows_, d, rng)
+    Dm = rng.standard_normal((Ne, d)).astype(np.float32)
+    R = (rng.standard_normal((Ne, d)) * 0.01).astype(np.float32)
+    Wd, Dd, Rd = _dev(W), _dev(Dm), _dev(R)
+    T = H.lowrank_project(Wd, Dd)
+    T64 = W.astype(np.float64) @ Dm.astype(np.float64).T
+    assert T.shape == (rows_, (Ne + 63) // 64 * 64)
+    assert O.rel_fro(T[:, :Ne].cpu(), T64) < 1e-6
+    assert float(T[:, Ne:].abs().max()) == 0.0 if T.shape[1] > Ne else True
+    out = H.lowrank_update(Wd, T, Rd)
+    want = W.astype(np.float64) + T64 @ R.astype(np.float64)
+    assert O.rel_fro(out.cpu(), want) < 1e-6
+    # and the fused single-kernel form agrees
+    fused = H.apply_lowrank(Wd, Dd, Rd)
+    assert O.rel_fro(fused.cpu(), want) < 1e-6
+
+
+@pytest.mark.parametrize("N_e,N_p,d,rows_", [(40, 10, 1024, 4096), (36, 4, 2048, 2600), (120, 30, 768, 5000)])
+def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
+    """uce_edit's forked path (N_edit >= 33, rows >= 1024) at SD-2.x / SDXL widths vs torch fp64 on the GPU,
+    run twice back to back (the side stream re-uses the handle's workspace)."""
+    N = N_e + N_p
+    Call = O.clip_like_embeddings(N + 1, d, seed=N + d)
+    C, G = Call[:N], np.repeat(Call[N:N + 1], N_e, axis=0)
+    s = np.ones(N, dtype=np.float32)
+    rng = np.random.Generator(np.random.PCG64(N))
+    Cd, Gd, sd = _dev(C), _dev(G), _dev(s)
+    for rep in range(2):
+        W = O.linear_default_weight(rows_, d, rng)
+        Wd = _dev(W)
+        out = H.edit(Cd, Gd, sd, 0.5, Wd, check=True)
+        C64, W64 = Cd.double(), Wd.double()
+        A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda:0") + C64.T @ C64
+        Delta = torch.linalg.solve(A, C64[:N_e].T @ (Gd - Cd[:N_e]).double()).T
+        assert O.rel_fro(out.cpu(), (W64 + W64 @ Delta).cpu()) < EPS_BUILD

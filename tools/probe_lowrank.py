@@ -1,4 +1,4 @@
-"""GPU probe: k_apply_lowrank time vs N_edit (and a plain copy for the HBM yardstick)."""
+"""GPU probe: low-rank apply kernels vs N_edit (fused and two-kernel forms) + whole-edit time."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,12 +19,14 @@ def timeit(fn, iters=50):
     return e0.elapsed_time(e1) / iters * 1e3
 
 print("copy_ us", timeit(lambda: out.copy_(W)))
-for ne in (1, 16, 17, 32, 48, 50, 64, 96, 128, 256):
-    Dm = torch.randn(ne, d, device="cuda")
-    R = torch.randn(ne, d, device="cuda") * 0.01
+for ne in (1, 16, 32, 48, 50, 64, 128, 256):
+    Dm = torch.randn(ne, d, device="cuda"); R = torch.randn(ne, d, device="cuda") * 0.01
     t = timeit(lambda: H.apply_lowrank(W, Dm, R, out=out))
-    print(f"Ne={ne:4d}  {t:8.2f} us   {8*rows*d/t/1e3:8.1f} GB/s")
+    T = H.lowrank_project(W, Dm)
+    tp = timeit(lambda: H.lowrank_project(W, Dm))
+    tu = timeit(lambda: H.lowrank_update(W, T, R, out=out))
+    print(f"Ne={ne:4d}  fused {t:8.2f} us | project {tp:7.2f} us  update {tu:7.2f} us ({8*rows*d/tu/1e3:7.1f} GB/s)")
 C = torch.from_numpy(synth.clip_like_embeddings(50, d, 0)).cuda(); G = C.roll(1, 0).contiguous(); s = torch.ones(50, device="cuda")
-for name, fn in [("gram_dual+potrf+trisolve+sub (dual_factors)", lambda: H.dual_factors(C, G, s, 0.5)),
+for name, fn in [("dual_factors (gram+potrf+trisolve)", lambda: H.dual_factors(C, G, s, 0.5)),
                  ("edit auto", lambda: H.edit(C, G, s, 0.5, W, out=out))]:
-    print(name, timeit(fn), "us")
+    print(name, f"{timeit(fn):.2f} us")

@@ -2,12 +2,13 @@
 // orchestration of the edit pipeline (gram -> potrf chain -> trisolve -> apply) on one stream.
 #include "uce_common.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <new>
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 static void free_ws(uce_ctx* h) {
-  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->DeltaT, h->Dm, h->R};
+  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->DeltaT, h->Dm, h->R};  // (T is separate)
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->M = h->Lmat = h->Linv = h->slabs = h->Bt = h->Yg = nullptr;
@@ -65,9 +66,22 @@ int uce_ensure(uce_ctx* h, int d, int n) {
   return UCE_OK;
 }
 
+int uce_ensure_T(uce_ctx* h, long rows, int N_edit) {
+  const size_t need = (size_t)rows * (size_t)((N_edit + 63) / 64 * 64);
+  if (need <= h->T_elems) return UCE_OK;
+  UCE_HIP_TRY(hipSetDevice(h->device));
+  UCE_HIP_TRY(hipDeviceSynchronize());
+  if (h->T) (void)hipFree(h->T);
+  h->T = nullptr;
+  h->T_elems = 0;
+  if (hipMalloc((void**)&h->T, need * sizeof(float)) != hipSuccess) return UCE_ENOMEM;
+  h->T_elems = need;
+  return UCE_OK;
+}
+
 extern "C" {
 
-int uce_version(void) { return 100; }
+int uce_version(void) { return 101; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -95,6 +109,8 @@ int uce_create(uce_handle_t* out, int device) {
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->status, 0, sizeof(int));
+  if (hipMalloc((void**)&h->ticket, sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
+  (void)hipMemset(h->ticket, 0, sizeof(unsigned));
   *out = h;
   return UCE_OK;
 }
@@ -105,6 +121,8 @@ int uce_destroy(uce_handle_t h) {
   (void)hipDeviceSynchronize();
   free_ws(h);
   if (h->status) (void)hipFree(h->status);
+  if (h->T) (void)hipFree(h->T);
+  if (h->ticket) (void)hipFree(h->ticket);
   delete h;
   return UCE_OK;
 }
@@ -112,6 +130,27 @@ int uce_destroy(uce_handle_t h) {
 int uce_reserve(uce_handle_t h, int d_max, int n_max) {
   if (!h || d_max <= 0 || n_max <= 0 || d_max % 64) return UCE_EINVAL;
   return uce_ensure(h, d_max, round_up(n_max, 64));
+}
+
+int uce_reserve_rows(uce_handle_t h, long rows_max, int n_edit_max) {
+  if (!h || rows_max <= 0 || n_edit_max <= 0) return UCE_EINVAL;
+  return uce_ensure_T(h, rows_max, n_edit_max);
+}
+
+int uce_lowrank_project(uce_handle_t h, const float* W_old, const float* Dm, float* T, long rows, int d,
+                        int N_edit, uce_stream_t stream) {
+  if (!h || !W_old || !Dm || !T || rows < 0 || N_edit <= 0 || !lowrank_split_supported(d, N_edit)) return UCE_EINVAL;
+  if (rows == 0) return UCE_OK;
+  return launch_lr_project(W_old, Dm, nullptr, T, rows, d, N_edit, (hipStream_t)stream);
+}
+
+int uce_lowrank_update(uce_handle_t h, const float* W_old, const float* T, const float* R, float* W_new,
+                       long rows, int d, int N_edit, uce_stream_t stream) {
+  if (!h || !W_old || !T || !R || !W_new || rows < 0 || N_edit <= 0 || W_old == W_new ||
+      !lowrank_split_supported(d, N_edit))
+    return UCE_EINVAL;
+  if (rows == 0) return UCE_OK;
+  return launch_lr_update(W_old, T, R, W_new, rows, d, N_edit, (hipStream_t)stream);
 }
 
 int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
@@ -197,6 +236,33 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   const int n_pad = round_up(N, 64);
   rc = uce_ensure(h, d, n_pad);
   if (rc) return rc;
+  static const int no_split = getenv("UCE_NO_SPLIT") ? atoi(getenv("UCE_NO_SPLIT")) : 0;
+  if (!no_split && N_edit >= 33 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
+    // N <= 64: THREE launches on the caller's stream, no events:
+    //   1 projection T = W_old (G - C_e)^T   ||   block 0 of the same launch: K = lambda S^-1 + C C^T and
+    //     its 64x64 Cholesky + inverse (hidden under the GEMM)
+    //   2 triangular solves -> R     3 update W_new = W_old + T R
+    // N > 64: Gram launch + potrf launch chain first, then the same three without the rider.
+    rc = uce_ensure_T(h, rows, N_edit);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_pad == 64) {
+      rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st, h, C, s, N, lamb);
+      if (rc) return rc;
+    } else {
+      int nsplit = 1;
+      size_t slab_stride = 0;
+      rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, nullptr, nullptr, 0, &nsplit, &slab_stride, st);
+      if (rc) return rc;
+      rc = launch_potrf(h, h->M, n_pad, st);
+      if (rc) return rc;
+      rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st);
+      if (rc) return rc;
+    }
+    rc = launch_trisolve(h, n_pad, d, nullptr, C, N, h->R, N_edit, st);
+    if (rc) return rc;
+    return launch_lr_update(W_old, h->T, h->R, W_new, rows, d, N_edit, st);
+  }
   rc = uce_dual_factors(h, C, G, s, N, N_edit, d, lamb, h->Dm, h->R, stream);
   if (rc) return rc;
   if (apply_lowrank_fits(d, N_edit))

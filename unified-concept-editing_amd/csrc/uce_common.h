@@ -41,6 +41,9 @@ struct uce_ctx {
   float* Dm;      // [n_cap, d_cap]
   float* R;       // [n_cap, d_cap]
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
+  unsigned* ticket;  // arrival counter of the rider blocks (zero between launches)
+  float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply
+  size_t T_elems;
 };
 
 // ---- internal launchers (defined across the .hip files) -------------------------------------
@@ -67,6 +70,13 @@ bool apply_lowrank_fits(int d, int N_edit);
 int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d, float* DeltaT,
                               hipStream_t st);
 int launch_sub_rows(const float* G, const float* C, float* Dm, long n, hipStream_t st);
+bool lowrank_split_supported(int d, int N_edit);
+int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
+                      int N_edit, hipStream_t st, uce_ctx* h = nullptr, const float* C = nullptr,
+                      const float* s = nullptr, int N = 0, float lamb = 0.f);
+int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
+                     int N_edit, hipStream_t st);
+int uce_ensure_T(uce_ctx* h, long rows, int N_edit);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
                  int dh, float scale, int dtype, hipStream_t st);
 

@@ -1,0 +1,641 @@
+// Two-kernel form of the low-rank apply  W_new = W_old + (W_old D_e^T) R_e :
+//
+//   k_lr_project<D,MT> : T [rows, NEP] = W_old D_e^T      needs only D_e = G - C_e, not the solve: in
+//                        uce_edit ONE launch carries this GEMM (blocks 1..) and the 64x64 Cholesky of
+//                        the dual system (block 0), so the latency-bound factorisation hides under
+//                        the f32-MFMA-bound projection without any cross-stream event (a HIP event
+//                        hand-off between two streams measured 13-14 us each way on this stack).
+//   k_lr_update<D>     : W_new = W_old + T R_e            one pass over the weights, HBM bound:
+//                        algorithmic bytes 8*rows*d (+ the small T and R).
+//
+// Splitting the fused kernel (uce_apply.hip) at T costs 2*4*rows*NEP bytes of extra traffic (6.4 MB
+// at N_edit <= 64 for SD-1.4, 4 %) and buys (a) overlap of the 0.1 GF MFMA-bound projection with the
+// latency-bound small-system chain, (b) an update kernel whose LDS footprint is tiny, so several
+// workgroups per CU stream W with their phases naturally interleaved.
+#include "uce_common.h"
+#include "uce_potrf64.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int PJ_KC = 64;    // floats per W k-chunk
+constexpr int PJ_LD = 72;    // LDS row stride of the chunk (floats): conflict-free b128 fragment reads
+
+// ---------------------------------------------------------------------------------------------
+// projection: 8 waves, wave = (concept tile class c4 = w & 3, M half = w >> 2); the W k-chunk of the
+// MT*16-row super-tile and the D_e k-chunk (64 concepts) are staged once in LDS and shared by the waves;
+// each D_e fragment read from LDS feeds NMT MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int D, int MT, int NMT>
+__device__ __forceinline__ void project_body(const float* __restrict__ W_old, const float* __restrict__ Dm,
+                                             const float* __restrict__ Csub, float* __restrict__ T,
+                                             long rows, int Ne, int NEP, float* Wc, int mbase, int blk_off) {
+  constexpr int d = D;
+  constexpr int SR = MT * 16;
+  float* Dc = Wc + 2 * SR * PJ_LD;                    // [2][64][PJ_LD]  D_e k-chunk of the current batch
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c4 = w & 3;
+  const int li = lane & 15, lk = lane >> 4;
+  const long R0 = (long)(blockIdx.x - blk_off) * SR;
+
+  constexpr int NC = D / PJ_KC;                       // k-chunks (12 / 16 / 32), even
+  constexpr int F4 = SR * (PJ_KC / 4);                // float4 per W chunk
+  constexpr int NLD = (F4 + 511) / 512;               // per thread
+  struct Stage { float4_t w[NLD]; float4_t x[2]; float4_t y[2]; };
+  const float cscale = Csub ? 1.f : 0.f;              // D_e = X - cscale * Y (X = G, Y = C_e) or X = Dm
+  const float* Ysrc = Csub ? Csub : Dm;
+  const int nbatch = NEP >> 6;
+#pragma unroll 1
+  for (int bt = 0; bt < nbatch; ++bt) {
+    // both operands come in as full 256-byte row segments (16 lanes x 16 B) and go through LDS: the
+    // W rows of the super-tile and the 64 concept rows of this batch (masked beyond N_edit)
+    auto load_stage = [&](int kc, Stage& st) {
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) {
+        const int e = tid + 512 * p;
+        const int r = (e >> 4) < SR ? (e >> 4) : SR - 1, cc = (e & 15) << 2;
+        long gr = R0 + r;
+        gr = gr < rows ? gr : rows - 1;
+        st.w[p] = *(const float4_t*)(W_old + gr * d + kc * PJ_KC + cc);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int e = tid + 512 * p;                  // 64 rows x 16 float4
+        const int er = bt * 64 + (e >> 4), cc = (e & 15) << 2;
+        const size_t off = (size_t)(er < Ne ? er : Ne - 1) * d + kc * PJ_KC + cc;
+        st.x[p] = *(const float4_t*)(Dm + off);
+        st.y[p] = *(const float4_t*)(Ysrc + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto park_stage = [&](int buf, const Stage& st) {
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) {
+        const int e = tid + 512 * p;
+        if (e < F4) *(float4_t*)&Wc[(buf * SR + (e >> 4)) * PJ_LD + ((e & 15) << 2)] = st.w[p];
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int e = tid + 512 * p;
+        const float m = (bt * 64 + (e >> 4) < Ne) ? 1.f : 0.f;
+        *(float4_t*)&Dc[(buf * 64 + (e >> 4)) * PJ_LD + ((e & 15) << 2)] = (st.x[p] - cscale * st.y[p]) * m;
+      }
+    };
+    float4_t acc[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) acc[m] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+      // k permutation: MFMA q of 16-k group g uses k = 16g + 4*(lane>>4) + q on both operands
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4_t a[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+          a[m] = *(const float4_t*)&Wc[(buf * SR + (mbase + m) * 16 + li) * PJ_LD + g * 16 + 4 * lk];
+        const float4_t bb = *(const float4_t*)&Dc[(buf * 64 + c4 * 16 + li) * PJ_LD + g * 16 + 4 * lk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int m = 0; m < NMT; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], bb[q], acc[m], 0, 0, 0);
+      }
+    };
+    // chunk c: loaded during iteration c-2 into register set c&1, parked in LDS buffer c&1 during
+    // iteration c-1, consumed in iteration c.
+    Stage sA, sB;
+    __syncthreads();                                  // previous batch is done with the LDS buffers
+    load_stage(0, sA);
+    load_stage(1, sB);
+    park_stage(0, sA);
+    load_stage(2 < NC ? 2 : 0, sA);
+    __syncthreads();
+#pragma unroll 1
+    for (int kc = 0; kc < NC; kc += 2) {
+      park_stage(1, sB);                              // chunk kc + 1
+      load_stage(kc + 3 < NC ? kc + 3 : kc, sB);
+      compute(0);                                     // chunk kc
+      __syncthreads();
+      if (kc + 2 < NC) park_stage(0, sA);             // chunk kc + 2
+      load_stage(kc + 4 < NC ? kc + 4 : kc, sA);
+      compute(1);                                     // chunk kc + 1
+      __syncthreads();
+    }
+    // D layout: col = lane & 15 (concept), row = 4*(lane>>4) + r
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long gr = R0 + (mbase + m) * 16 + 4 * lk + r;
+        if (gr < rows) T[gr * NEP + (bt * 4 + c4) * 16 + li] = acc[m][r];
+      }
+  }
+}
+
+// Optional riders of the projection launch (blocks 0..GP_NB-1): the whole small-system factorisation
+// of the dual form when it is a single 64-block (N <= 64):  K = lambda S^-1 + C C^T  (f64 MFMA over
+// the d features, split over GP_NB blocks x 2 wave quads), then the 64x64 Cholesky + inverse by the
+// rider block that finishes its slab LAST.  Riders need nothing from the projection and vice versa,
+// so riding along costs no launch and no event, and - being shorter than the GEMM beside them - no
+// time.  The slab hand-off between rider blocks is the split-K reduction of the CDNA guide (G16):
+// plain slab stores -> per-wave vmcnt(0) -> barrier -> one lane: agent-scope release fence + vmcnt(0)
+// -> relaxed agent-scope ticket; the block drawing the last ticket does one agent-scope acquire,
+// a barrier, then plain loads of all slabs (summed in slab order: bit-repeatable).  Correct for any
+// placement of the rider blocks; the ticket word is zero at creation and reset by its last taker.
+struct GramPotrfJob {
+  const float* C;       // [N, d]; null = no riders
+  const float* s;       // [N]
+  int N;
+  float lamb;
+  double* slabs;        // [GP_NB][64][64] partial Grams
+  unsigned* ticket;     // one word, zero between launches
+  double* Lmat;         // [64, 64] (ld 64)
+  double* Linv;         // [64, 64]
+  int* status;
+};
+
+constexpr int GP_NB = 4;        // rider blocks
+constexpr int GP_LD = 40;       // floats, k-contiguous NT tile stride (conflict-free b128)
+constexpr int GP_TLD = 66;      // doubles
+
+template <int D>
+__device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned char* smem_raw) {
+  float* As = (float*)smem_raw;                                   // [2 halves][64][GP_LD]
+  double* P1 = (double*)(smem_raw + 2 * 64 * GP_LD * sizeof(float));   // [64][GP_TLD]
+  Potrf64Scratch* sc = (Potrf64Scratch*)(smem_raw + 2 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double));
+  // (all LDS in the dynamic region: a static __shared__ would shift its 16-byte alignment)
+  unsigned* s_last_p = (unsigned*)(smem_raw + 2 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch));
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int half = w >> 2, wq = w & 3;
+  const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
+  const int ht = tid & 255;                                       // thread index within its half
+  const int blk = blockIdx.x;                                     // 0 .. GP_NB-1
+  double4_t acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  float* Ah = As + half * 64 * GP_LD;
+  const int lrow = ht >> 3, lc4 = (ht & 7) * 4;
+  constexpr int KS = D / (2 * GP_NB);                             // features per (block, half) slice
+  constexpr int NCH = KS / 32;                                    // 32-feature chunks (3 / 4 / 8)
+  const int kbeg = (blk * 2 + half) * KS;
+  // the whole slice is fetched up front (one memory round trip instead of one per chunk)
+  float4_t pre[NCH][2];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = p * 32 + lrow;
+      pre[ch][p] = *(const float4_t*)(j.C + (size_t)(r < j.N ? r : j.N - 1) * D + kbeg + ch * 32 + lc4);
+    }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = p * 32 + lrow;
+      *(float4_t*)&Ah[r * GP_LD + lc4] = (r < j.N) ? pre[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kofs = u * 16 + 4 * (lane >> 4);
+      const float4_t fa0 = *(const float4_t*)&Ah[(wr + (lane & 15)) * GP_LD + kofs];
+      const float4_t fa1 = *(const float4_t*)&Ah[(wr + 16 + (lane & 15)) * GP_LD + kofs];
+      const float4_t fb0 = *(const float4_t*)&Ah[(wc + (lane & 15)) * GP_LD + kofs];
+      const float4_t fb1 = *(const float4_t*)&Ah[(wc + 16 + (lane & 15)) * GP_LD + kofs];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0][0] = mfma_f64((double)fa0[t], (double)fb0[t], acc[0][0]);
+        acc[0][1] = mfma_f64((double)fa0[t], (double)fb1[t], acc[0][1]);
+        acc[1][0] = mfma_f64((double)fa1[t], (double)fb0[t], acc[1][0]);
+        acc[1][1] = mfma_f64((double)fa1[t], (double)fb1[t], acc[1][1]);
+      }
+    }
+    __syncthreads();
+  }
+  // D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15
+  const int c = lane & 15, rq = lane >> 4;
+  if (half == 1) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P1[(wr + m * 16 + rq + 4 * r) * GP_TLD + wc + n * 16 + c] = acc[m][n][r];
+  }
+  __syncthreads();
+  double* myslab = j.slabs + (size_t)blk * 64 * 64;
+  if (half == 0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr + m * 16 + rq + 4 * r, col = wc + n * 16 + c;
+          myslab[row * 64 + col] = acc[m][n][r] + P1[row * GP_TLD + col];
+        }
+  }
+  // ---- publish the slab, draw a ticket (CDNA guide, Guideline 16 / split-K reduction recipe)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(j.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last_p = (t == GP_NB - 1) ? 1u : 0u;
+    if (t == GP_NB - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(j.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      *j.status = 0;
+    }
+  }
+  __syncthreads();
+  if (!*s_last_p) return;
+  if (half == 0) {
+    const int ti = tid >> 4, tj = tid & 15;
+    double a[4][4], x[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int row = 4 * ti + r, col = 4 * tj + cc;
+        double v = j.slabs[row * 64 + col];
+#pragma unroll
+        for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)b * 64 * 64 + row * 64 + col];   // fixed order
+        if (row == col) {
+          const float sv = (row < j.N) ? j.s[row] : 1.f;
+          v += (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
+        }
+        a[r][cc] = v;
+      }
+    potrf64_reg(a, x, sc, tid, j.status, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        j.Lmat[(4 * ti + r) * 64 + 4 * tj + cc] = a[r][cc];
+        j.Linv[(4 * ti + r) * 64 + 4 * tj + cc] = x[r][cc];
+      }
+  }
+}
+
+constexpr size_t GP_SMEM = 2 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch) + 16;
+
+template <int D, int MT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_project(
+    const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ Csub,
+    float* __restrict__ T, long rows, int Ne, int NEP, GramPotrfJob job) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int has_rider = job.C ? GP_NB : 0;
+  if ((int)blockIdx.x < has_rider) {
+    gram_potrf_rider<D>(job, smem_raw);
+    return;
+  }
+  float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD]
+  constexpr int M0 = (MT + 1) / 2;
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
+    project_body<D, MT, M0>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, has_rider);
+  else
+    project_body<D, MT, MT - M0>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, has_rider);
+}
+
+// ---------------------------------------------------------------------------------------------
+// update: 4 waves, 64 rows per workgroup; wave w owns 64-column groups w, w+4, ...; lane j of a group
+// owns 4 consecutive columns, so W, R and the output all move 16 B per lane in full 256 B row
+// segments.  T tile [64, NEP] -> LDS once.  Per k-step one R fragment (L2) feeds 16 MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int D, int UP_MT, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_update(
+    const float* __restrict__ W_old, const float* __restrict__ T, const float* __restrict__ R,
+    float* __restrict__ W_new, long rows, int Ne, int NEP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int d = D;
+  constexpr int SR = UP_MT * 16;
+  const int tld = NEP + 2;
+  float* Ts = (float*)smem_raw;                       // [64][tld]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long R0 = (long)blockIdx.x * SR;
+
+  constexpr int MG = D / 256;                         // column groups per wave (3 / 4 / 8)
+  constexpr int RD = 4;                               // R fragments in flight
+  const int nks = (Ne + 3) >> 2;                      // k-steps that carry concepts
+  int rl_g = 0, rl_t = 0;
+  auto r_next = [&]() -> float4_t {
+    const int e = 4 * rl_t + lk;
+    const float4_t v = *(const float4_t*)(R + (size_t)(e < Ne ? e : Ne - 1) * d + (w + 4 * rl_g) * 64 + 4 * li);
+    if (++rl_t == nks) { rl_t = 0; rl_g = rl_g + 1 < MG ? rl_g + 1 : rl_g; }
+    return v;
+  };
+  auto res_load = [&](int gi, float4_t (&x)[UP_MT][4]) {
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        long gr = R0 + m * 16 + 4 * lk + r;
+        gr = gr < rows ? gr : rows - 1;
+        x[m][r] = *(const float4_t*)(W_old + gr * d + (w + 4 * gi) * 64 + 4 * li);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // first loads in flight before T is staged
+  float4_t res[UP_MT][4];
+  res_load(0, res);
+  float4_t ring[RD];
+#pragma unroll
+  for (int i = 0; i < RD; ++i) ring[i] = r_next();
+  {
+    const int f4_row = NEP >> 2;
+    for (int e = tid; e < SR * f4_row; e += 256) {
+      const int r = e / f4_row, c = (e - r * f4_row) << 2;
+      long gr = R0 + r;
+      gr = gr < rows ? gr : rows - 1;
+      const float4_t v = *(const float4_t*)(T + gr * NEP + c);
+      Ts[r * tld + c] = v[0];
+      Ts[r * tld + c + 1] = v[1];
+      Ts[r * tld + c + 2] = v[2];
+      Ts[r * tld + c + 3] = v[3];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int gi = 0; gi < MG; ++gi) {
+    float4_t acc[UP_MT][4];                           // acc[m][q][r]: row m*16 + 4*lk + r, column 4*li + q
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q][r] = res[m][r][q];
+    if (gi + 1 < MG) res_load(gi + 1, res);           // next group's W rows, ahead of this group's stores
+#pragma unroll 1
+    for (int t = 0; t < nks; ++t) {
+      const float4_t b = ring[0];
+#pragma unroll
+      for (int i = 0; i + 1 < RD; ++i) ring[i] = ring[i + 1];
+      ring[RD - 1] = r_next();
+      const int e = 4 * t + lk;
+      float a[UP_MT];
+#pragma unroll
+      for (int m = 0; m < UP_MT; ++m) a[m] = (e < Ne) ? Ts[(m * 16 + li) * tld + e] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < UP_MT; ++m)
+          acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[q], acc[m][q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long gr = R0 + m * 16 + 4 * lk + r;
+        if (gr < rows) {
+          const float4_t o = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+          __builtin_nontemporal_store(o, (float4_t*)(W_new + gr * d + (w + 4 * gi) * 64 + 4 * li));
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// update, N_edit <= 64 (<= 16 k-steps): ALL R fragments of a column group sit in registers, the set
+// for group g+1 is fetched during group g and - this is the point - is issued BEFORE the prefetch of
+// group g+1's W rows.  vmcnt retires in order on gfx950, so a wait on any load issued after a big HBM
+// prefetch also waits for that prefetch: with the ring-buffered variant below every group stalled
+// at its 4th k-step until the next group's 64 KB of W had landed, and MFMA time simply added to
+// memory time (41 us = 25 + 16 at N_edit = 50).  Here the MFMA loop of a group waits for nothing.
+// ---------------------------------------------------------------------------------------------
+template <int D, int UP_MT, int WPE, int NK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_update_r16(
+    const float* __restrict__ W_old, const float* __restrict__ T, const float* __restrict__ R,
+    float* __restrict__ W_new, long rows, int Ne, int NEP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int d = D;
+  constexpr int SR = UP_MT * 16;
+  const int tld = NEP + 2;
+  float* Ts = (float*)smem_raw;                       // [SR][tld]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long R0 = (long)blockIdx.x * SR;
+  constexpr int MG = D / 256;                         // column groups per wave (3 / 4 / 8)
+
+  // 32-bit per-lane offsets off wave-uniform bases (SGPR base + VGPR offset addressing): one VGPR per
+  // stream instead of a 64-bit pointer per load
+  const float* Wb = W_old + R0 * d;                   // workgroup-uniform
+  const int rows_left = (int)((rows - R0) < SR ? (rows - R0) : SR);
+  unsigned roff[NK];
+#pragma unroll
+  for (int t = 0; t < NK; ++t) {
+    const int e = 4 * t + lk;
+    roff[t] = (unsigned)((e < Ne ? e : Ne - 1) * d + w * 64 + 4 * li);
+  }
+  unsigned woff[UP_MT][4];
+#pragma unroll
+  for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = m * 16 + 4 * lk + r;
+      woff[m][r] = (unsigned)((lr < rows_left ? lr : rows_left - 1) * d + w * 64 + 4 * li);
+    }
+
+  float4_t rr[2][NK];
+  float4_t res[UP_MT][4];
+#pragma unroll
+  for (int t = 0; t < NK; ++t) rr[0][t] = *(const float4_t*)(R + roff[t]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) res[m][r] = *(const float4_t*)(Wb + woff[m][r]);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const int f4_row = NEP >> 2;
+    for (int e = tid; e < SR * f4_row; e += 256) {
+      const int r = e / f4_row, c = (e - r * f4_row) << 2;
+      long gr = R0 + r;
+      gr = gr < rows ? gr : rows - 1;
+      const float4_t v = *(const float4_t*)(T + gr * NEP + c);
+      Ts[r * tld + c] = v[0];
+      Ts[r * tld + c + 1] = v[1];
+      Ts[r * tld + c + 2] = v[2];
+      Ts[r * tld + c + 3] = v[3];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int gi = 0; gi < MG; ++gi) {
+    float4_t acc[UP_MT][4];                           // acc[m][q][r]: row m*16 + 4*lk + r, column 4*li + q
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q][r] = res[m][r][q];
+    if (gi + 1 < MG) {
+      // next group's R fragments FIRST (older than the W prefetch: their waits never include it)
+#pragma unroll
+      for (int t = 0; t < NK; ++t) rr[(gi + 1) & 1][t] = *(const float4_t*)(R + roff[t] + (gi + 1) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[m][r] = *(const float4_t*)(Wb + woff[m][r] + (gi + 1) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+      const int e = 4 * t + lk;
+      float a[UP_MT];                                 // T fragments: LDS (lgkmcnt, independent of vmcnt)
+#pragma unroll
+      for (int m = 0; m < UP_MT; ++m) a[m] = (e < Ne) ? Ts[(m * 16 + li) * tld + e] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < UP_MT; ++m)
+          acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], rr[gi & 1][t][q], acc[m][q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long gr = R0 + m * 16 + 4 * lk + r;
+        if (gr < rows) {
+          const float4_t o = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+          __builtin_nontemporal_store(o, (float4_t*)(W_new + gr * d + (w + 4 * gi) * 64 + 4 * li));
+        }
+      }
+  }
+}
+
+// rows / 16 tiles over 256 CUs with MT tiles per workgroup: time ~ ceil(workgroups / 256) * MT
+int pick_mt2(long rows) {
+  const long t16 = (rows + 15) / 16;
+  int best = 8;
+  long best_cost = -1;
+  for (int mt = 8; mt >= 5; --mt) {
+    const long wgs = (t16 + mt - 1) / mt;
+    const long cost = ((wgs + 255) / 256) * mt;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt; }
+  }
+  return best;
+}
+
+template <int D, int MT>
+int launch_project(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit,
+                   int NEP64, const GramPotrfJob& job, hipStream_t st) {
+  size_t smem = (size_t)2 * (MT * 16 + 64) * PJ_LD * sizeof(float);
+  if (job.C && smem < GP_SMEM) smem = GP_SMEM;
+  static bool attr_set = false;
+  if (!attr_set) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    attr_set = true;
+  }
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? GP_NB : 0);
+  hipLaunchKernelGGL((k_lr_project<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
+                     N_edit, NEP64, job);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+template <int D>
+int launch_project_d(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit,
+                     int NEP64, const GramPotrfJob& job, hipStream_t st) {
+  switch (pick_mt2(rows)) {
+    case 5: return launch_project<D, 5>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+    case 6: return launch_project<D, 6>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+    case 7: return launch_project<D, 7>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+    default: return launch_project<D, 8>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+  }
+}
+
+template <int D, int UP_MT, int WPE>
+int launch_update_v(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
+                    int NEP64, hipStream_t st) {
+  const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_update<D, UP_MT, WPE>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const long nwg = (rows + UP_MT * 16 - 1) / (UP_MT * 16);
+  hipLaunchKernelGGL((k_lr_update<D, UP_MT, WPE>), dim3((unsigned)nwg), dim3(256), smem, st, W_old, T, R, W_new, rows,
+                     N_edit, NEP64);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+template <int D, int UP_MT, int WPE>
+int launch_update_r16(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
+                      int NEP64, hipStream_t st) {
+  const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
+  const dim3 grid((unsigned)((rows + UP_MT * 16 - 1) / (UP_MT * 16))), block(256);
+  const int nks = (N_edit + 3) / 4;
+  if (nks <= 4)
+    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 4>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else if (nks <= 8)
+    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 8>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else if (nks <= 13)
+    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 13>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else
+    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 16>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+template <int D>
+int launch_update_d(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
+                    int NEP64, hipStream_t st) {
+  static const int variant = getenv("UCE_UPDATE_VARIANT") ? atoi(getenv("UCE_UPDATE_VARIANT")) : 10;
+  if (N_edit <= 64) {
+    switch (variant) {
+      case 10:   // default: the widest tile whose register-resident R set does not spill
+        if (N_edit <= 32) return launch_update_r16<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+        return launch_update_r16<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 15: return launch_update_r16<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 11: return launch_update_r16<D, 2, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 12: return launch_update_r16<D, 1, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 13: return launch_update_r16<D, 3, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 14: return launch_update_r16<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      default: break;
+    }
+  }
+  switch (variant) {
+    case 1: return launch_update_v<D, 2, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+    case 2: return launch_update_v<D, 2, 4>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+    case 3: return launch_update_v<D, 1, 4>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+    case 4: return launch_update_v<D, 3, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+    default: return launch_update_v<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+  }
+}
+
+}  // namespace
+
+bool lowrank_split_supported(int d, int N_edit) {
+  return (d == 768 || d == 1024 || d == 2048) && N_edit >= 1 && N_edit <= 256;
+}
+
+// X = Dm with Csub == nullptr, or X = G with Csub = C_e (D_e = G - C_e formed on the fly).  With `h`
+// and a dual system that is a single 64-block (N <= 64) the launch also builds and factors that
+// system (block 0): K = lamb S^-1 + C C^T -> h->Lmat (ld 64), h->Linv, h->status.
+int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
+                      int N_edit, hipStream_t st, uce_ctx* h, const float* C, const float* s, int N, float lamb) {
+  const int NEP64 = (N_edit + 63) / 64 * 64;
+  GramPotrfJob job{};
+  if (h) job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status};
+  if (d == 768) return launch_project_d<768>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  if (d == 1024) return launch_project_d<1024>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  if (d == 2048) return launch_project<2048, 5>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  return UCE_EINVAL;
+}
+
+int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
+                     int N_edit, hipStream_t st) {
+  const int NEP64 = (N_edit + 63) / 64 * 64;
+  if (d == 768) return launch_update_d<768>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+  if (d == 1024) return launch_update_d<1024>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+  if (d == 2048) return launch_update_d<2048>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+  return UCE_EINVAL;
+}

@@ -12,6 +12,7 @@
 //   k_trisolve    : one workgroup per 16 right-hand-side columns: forward then backward
 //                   substitution with the inverted diagonal blocks; Y lives in LDS (n <= 1024).
 #include "uce_common.h"
+#include "uce_potrf64.h"
 
 namespace {
 
@@ -24,180 +25,12 @@ __device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
   b = t - a * (a + 1) / 2;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Register-tiled Cholesky + inverse of one 64x64 SPD block by 256 threads.
-// Thread (ti, tj) = (tid >> 4, tid & 15) owns the 4x4 sub-block rows 4ti.., cols 4tj.. of the
-// matrix (a) and of X (x, starts as I, ends as L^-1).  Right-looking block elimination, TWO pivots
-// per step (32 steps, one barrier each): at step (k, k+1) the owners publish
-// columns k, k+1 of the current Schur complement and rows k, k+1 of X into LDS lines; everybody
-// reads the 2x2 pivot block P, inverts it, and applies the rank-2 update
-//     a_ij -= [a_ik a_i,k+1] P^-1 [a_jk a_j,k+1]^T ,   x_ij -= [a_ik a_i,k+1] P^-1 [x_kj x_k+1,j]^T .
-// The published lines are final as published (later register updates of eliminated rows/columns
-// are harmless garbage that is never read), so nothing is masked.  L and L^-1 are assembled from
-// the lines in one pass at the end: an even column is scaled by 1/sqrt(p00); an odd one first
-// gets the pivot-k elimination it skipped:  (c1 - c0 p01/p00) / sqrt(p11 - p01^2/p00).
-// ---------------------------------------------------------------------------------------------
-struct Potrf64Scratch {
-  double col[64][64];   // col[k][i]: column k of the Schur complement when it was published
-  double row[64][64];   // row[k][j]: row k of the partial inverse when it was published
-  double rs[64];        // 1/sqrt(effective pivot k)
-  double g[64];         // odd k: p01/p00 of its pair
-};
-
-__device__ __forceinline__ double rcp_f64(double v) {
-  double r = __builtin_amdgcn_rcp(v);
-  r = fma(fma(-v, r, 1.0), r, r);
-  r = fma(fma(-v, r, 1.0), r, r);
-  return r;
-}
-
-// One pair of pivots K = 4*kb + KR, K + 1 (KR in {0, 2} is static so register indices are static;
-// kb is a loop variable: the 32 steps are a 16-trip loop of two bodies, ~3 KB of code.  A fully
-// unrolled version of this loop is instruction-fetch bound: 50 KB of run-once straight-line code
-// took 31-38 us regardless of how many barriers it contained).
-template <int KR>
-__device__ __forceinline__ void potrf64_pair(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
-                                             int ti, int tj, int kb) {
-  const int K = 4 * kb + KR;
-  if (tj == kb) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sc->col[K][4 * ti + r] = a[r][KR];
-      sc->col[K + 1][4 * ti + r] = a[r][KR + 1];
-    }
-  }
-  if (ti == kb) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      sc->row[K][4 * tj + c] = x[KR][c];
-      sc->row[K + 1][4 * tj + c] = x[KR + 1][c];
-    }
-  }
-  __syncthreads();
-  const double p00 = sc->col[K][K], p01 = sc->col[K][K + 1], p11 = sc->col[K + 1][K + 1];
-  const double idet = rcp_f64(fma(p00, p11, -p01 * p01));
-  const double q00 = p11 * idet, q01 = -p01 * idet, q11 = p00 * idet;
-  double u[4], v[4], c0[4], c1[4], x0[4], x1[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double a0 = sc->col[K][4 * ti + r], a1 = sc->col[K + 1][4 * ti + r];
-    u[r] = fma(a0, q00, a1 * q01);
-    v[r] = fma(a0, q01, a1 * q11);
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    c0[c] = sc->col[K][4 * tj + c];
-    c1[c] = sc->col[K + 1][4 * tj + c];
-    x0[c] = sc->row[K][4 * tj + c];
-    x1[c] = sc->row[K + 1][4 * tj + c];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a[r][c] = fma(-u[r], c0[c], fma(-v[r], c1[c], a[r][c]));
-      x[r][c] = fma(-u[r], x0[c], fma(-v[r], x1[c], x[r][c]));
-    }
-}
-
-// a[][] holds this thread's 4x4 sub-block of the SPD tile on entry (lower triangle is what
-// matters); on exit a = sub-block of L (zero above the diagonal), x = sub-block of L^-1.
-__device__ __forceinline__ void potrf64_reg(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
-                                            int tid, int* status, int col_base) {
-  const int ti = tid >> 4, tj = tid & 15;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) x[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
-#pragma unroll 1
-  for (int kb = 0; kb < 16; ++kb) {
-    potrf64_pair<0>(a, x, sc, ti, tj, kb);
-    potrf64_pair<2>(a, x, sc, ti, tj, kb);
-  }
-  __syncthreads();
-  if (tid < 32) {
-    const int k = 2 * tid;
-    const double p00 = sc->col[k][k], p01 = sc->col[k][k + 1], p11 = sc->col[k + 1][k + 1];
-    const double g = p01 / p00;
-    const double p11e = fma(-g, p01, p11);           // pivot k+1 after eliminating pivot k
-    // first non-positive (or NaN) pivot wins; everything after it is garbage anyway
-    const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
-    if ((bad0 | bad1) && tid == 0) {
-      const int f0 = bad0 ? 2 * __builtin_ctzll(bad0) : 128, f1 = bad1 ? 2 * __builtin_ctzll(bad1) + 1 : 128;
-      atomicCAS(status, 0, col_base + (f0 < f1 ? f0 : f1) + 1);
-    }
-    sc->rs[k] = 1.0 / sqrt(p00);
-    sc->rs[k + 1] = 1.0 / sqrt(p11e);
-    sc->g[k] = 0.0;
-    sc->g[k + 1] = g;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = 4 * ti + r, col = 4 * tj + c;
-      double lv = 0.0, xv = 0.0;
-      if (col <= row) {
-        lv = sc->col[col][row];
-        if (col & 1) lv = fma(-sc->g[col], sc->col[col - 1][row], lv);
-        lv *= sc->rs[col];
-        xv = sc->row[row][col];
-        if (row & 1) xv = fma(-sc->g[row], sc->row[row - 1][col], xv);
-        xv *= sc->rs[row];
-      }
-      a[r][c] = lv;
-      x[r][c] = xv;
-    }
-}
-
-// Factors diagonal block 0.  With nsplit > 1 the block is first summed from the split-K slabs of
-// the Gram kernel (single-block systems skip the separate reduction launch).
+// Factors diagonal block 0 (body shared with the fused projection+factor launch, uce_potrf64.h).
 __global__ __launch_bounds__(256) void k_potrf_first(const double* __restrict__ M, int n, int nsplit,
                                                      size_t slab_stride, double* __restrict__ Lmat,
                                                      double* __restrict__ Linv, int* status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  double a[4][4], x[4][4];
-  typedef double double2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[r][c] = 0.0;
-  // slabs summed in index order (bit-repeatable); 2 slabs = 16 independent 16-byte loads per batch
-  for (int sp = 0; sp < nsplit; sp += 2) {
-    double2_t v[2][4][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int sq = (sp + q < nsplit) ? sp + q : sp;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-          v[q][r][hh] = *(const double2_t*)(M + (size_t)sq * slab_stride + (size_t)(4 * ti + r) * n + 4 * tj + 2 * hh);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (sp + q < nsplit) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            a[r][2 * hh] += v[q][r][hh][0];
-            a[r][2 * hh + 1] += v[q][r][hh][1];
-          }
-      }
-    }
-  }
-  potrf64_reg(a, x, sc, tid, status, 0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      Lmat[(size_t)(4 * ti + r) * n + 4 * tj + c] = a[r][c];
-      Linv[(4 * ti + r) * 64 + 4 * tj + c] = x[r][c];
-    }
+  potrf_first_body(M, n, nsplit, slab_stride, Lmat, Linv, status, (Potrf64Scratch*)smem_raw);
 }
 
 // one wave's 32x32 quadrant of  acc += sign * P[rows] * Q[cols]^T  (both tiles row-major in LDS,

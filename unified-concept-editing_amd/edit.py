@@ -122,6 +122,25 @@ class UceHandle:
                                               Dm.shape[0], _stream_ptr(self.device)), "uce_apply_lowrank")
         return out
 
+    def lowrank_project(self, W_old: torch.Tensor, Dm: torch.Tensor) -> torch.Tensor:
+        rows, d = W_old.shape
+        ne = Dm.shape[0]
+        T = torch.empty(rows, (ne + 63) // 64 * 64, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_lowrank_project(self._h, _ptr(W_old), _ptr(Dm), _ptr(T), rows, d, ne,
+                                                _stream_ptr(self.device)), "uce_lowrank_project")
+        return T
+
+    def lowrank_update(self, W_old: torch.Tensor, T: torch.Tensor, R: torch.Tensor,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rows, d = W_old.shape
+        out = torch.empty_like(W_old) if out is None else out
+        _lib.check(self.lib.uce_lowrank_update(self._h, _ptr(W_old), _ptr(T), _ptr(R), _ptr(out), rows, d,
+                                               R.shape[0], _stream_ptr(self.device)), "uce_lowrank_update")
+        return out
+
+    def reserve_rows(self, rows_max: int, n_edit_max: int) -> None:
+        _lib.check(self.lib.uce_reserve_rows(self._h, rows_max, n_edit_max), "uce_reserve_rows")
+
     def delta_from_factors(self, Dm: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
         Ne, d = Dm.shape
         DeltaT = torch.empty(d, d, dtype=torch.float32, device=self.device)

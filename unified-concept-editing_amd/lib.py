@@ -26,6 +26,9 @@ SIGNATURES = {
     "uce_apply": (_i, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
     "uce_dual_factors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "uce_apply_lowrank": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "uce_lowrank_project": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "uce_lowrank_update": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "uce_reserve_rows": (_i, [_vp, _l, _i]),
     "uce_delta_from_factors": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "uce_edit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _l, _i, _vp]),
     "uce_status": (_i, [_vp, C.POINTER(_i), _vp]),
