@@ -278,7 +278,9 @@ def main() -> None:
     roof["traffic"] = None
     if os.path.exists(traffic_file):
         try:
-            roof["traffic"] = json.load(open(traffic_file)).get(args.workload, {}).get(roof["kernel"])
+            t = json.load(open(traffic_file)).get(args.workload, {}).get(roof["kernel"])
+            roof["traffic"] = t["total_bytes"] if isinstance(t, dict) else t
+            roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/traffic.json), bytes per launch"
         except Exception:
             pass
 

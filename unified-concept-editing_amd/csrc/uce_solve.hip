@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
   // ---------------- forward: Y_k = Linv_kk (RHS_k - sum_{j<k} L_kj Y_j)
   for (int kb = 0; kb < nb; ++kb) {
     const int r0 = kb * 64 + w * 16;  // this wave's 16 rows
-    double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0}, acc2 = acc1, acc3 = acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + kk + 4 * r;
@@ -185,27 +185,61 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
       acc0[r] = v;
     }
     const double* Lrow = Lmat + (size_t)(r0 + c) * n;  // A operand: row = r0 + (lane&15)
-    for (int jb = 0; jb < kb; ++jb) {
+    // the diagonal-block fragments do not depend on the sum: fetch them first
+    const double* Lid = Linv + (size_t)kb * 64 * 64 + (size_t)(w * 16 + c) * 64;
+    double li_f[16];
 #pragma unroll
-      for (int t = 0; t < 16; t += 2) {
-        const int k0 = jb * 64 + t * 4 + kk;
-        const double a0 = -Lrow[k0], a1 = -Lrow[k0 + 4];
-        const double b0 = Y[(size_t)k0 * ldy + c], b1 = Y[(size_t)(k0 + 4) * ldy + c];
-        acc0 = mfma_f64(a0, b0, acc0);
-        acc1 = mfma_f64(a1, b1, acc1);
+    for (int t = 0; t < 16; ++t) li_f[t] = Lid[t * 4 + kk];
+    // L_kj fragments: 16-byte loads (lane (i, kk) takes columns 8u + 2kk, +1 of row i; the same k
+    // permutation is applied to the Y side, which is free in LDS), two tiles in flight ahead of the
+    // MFMAs (strided L2 reads take ~2k cycles here, a 16-MFMA tile only ~1k).
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    auto ld_tile = [&](int jb, double2_t (&f)[8]) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f[u] = *(const double2_t*)(Lrow + jb * 64 + 8 * u + 2 * kk);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_tile = [&](int jb, const double2_t (&f)[8]) {
+      double bf[16];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bf[2 * u] = Y[(size_t)(jb * 64 + 8 * u + 2 * kk) * ldy + c];
+        bf[2 * u + 1] = Y[(size_t)(jb * 64 + 8 * u + 2 * kk + 1) * ldy + c];
       }
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        acc0 = mfma_f64(-f[u][0], bf[2 * u], acc0);
+        acc1 = mfma_f64(-f[u][1], bf[2 * u + 1], acc1);
+        acc2 = mfma_f64(-f[u + 1][0], bf[2 * u + 2], acc2);
+        acc3 = mfma_f64(-f[u + 1][1], bf[2 * u + 3], acc3);
+      }
+    };
+    {
+      double2_t fA[8], fB[8], fC[8];
+      if (kb > 0) ld_tile(0, fA);
+      if (kb > 1) ld_tile(1, fB);
+      int jb = 0;
+      for (; jb + 2 < kb; jb += 3) {
+        ld_tile(jb + 2, fC);
+        mma_tile(jb, fA);
+        ld_tile(jb + 3 < kb ? jb + 3 : jb + 2, fA);
+        mma_tile(jb + 1, fB);
+        ld_tile(jb + 4 < kb ? jb + 4 : jb + 2, fB);
+        mma_tile(jb + 2, fC);
+      }
+      if (jb < kb) mma_tile(jb, fA);
+      if (jb + 1 < kb) mma_tile(jb + 1, fB);
     }
-    acc0 += acc1;
+    acc0 = (acc0 + acc1) + (acc2 + acc3);
 #pragma unroll
     for (int r = 0; r < 4; ++r) tmp[w * 16 + kk + 4 * r][c] = acc0[r];
     __syncthreads();
-    const double* Li = Linv + (size_t)kb * 64 * 64 + (size_t)(w * 16 + c) * 64;
     double4_t y0 = (double4_t){0.0, 0.0, 0.0, 0.0}, y1 = y0;
 #pragma unroll
     for (int t = 0; t < 16; t += 2) {
       const int k0 = t * 4 + kk;
-      y0 = mfma_f64(Li[k0], tmp[k0][c], y0);
-      y1 = mfma_f64(Li[k0 + 4], tmp[k0 + 4][c], y1);
+      y0 = mfma_f64(li_f[t], tmp[k0][c], y0);
+      y1 = mfma_f64(li_f[t + 1], tmp[k0 + 4][c], y1);
     }
     y0 += y1;
 #pragma unroll
@@ -216,33 +250,62 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
   // ---------------- backward: X_k = Linv_kk^T (Y_k - sum_{j>k} L_jk^T X_j)
   for (int kb = nb - 1; kb >= 0; --kb) {
     const int r0 = kb * 64 + w * 16;
-    double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0}, acc2 = acc1, acc3 = acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc0[r] = Y[(size_t)(r0 + kk + 4 * r) * ldy + c];
-    for (int jb = nb - 1; jb > kb; --jb) {
+    // diagonal-block fragments (transposed access) first, then the L_jk^T tiles one ahead
+    const double* Lid = Linv + (size_t)kb * 64 * 64;
+    double li_f[16];
 #pragma unroll
-      for (int t = 0; t < 16; t += 2) {
-        const int k0 = jb * 64 + t * 4 + kk;
-        // A[i][k] = L[k][r0 + i]
-        const double a0 = -Lmat[(size_t)k0 * n + r0 + c], a1 = -Lmat[(size_t)(k0 + 4) * n + r0 + c];
-        const double b0 = Y[(size_t)k0 * ldy + c], b1 = Y[(size_t)(k0 + 4) * ldy + c];
-        acc0 = mfma_f64(a0, b0, acc0);
-        acc1 = mfma_f64(a1, b1, acc1);
+    for (int t = 0; t < 16; ++t) li_f[t] = Lid[(size_t)(t * 4 + kk) * 64 + w * 16 + c];
+    // L_jk^T tiles (A[i][k] = L[k][r0 + i]: 16 consecutive rows of one column block per load
+    // instruction, 128 B per row group), two tiles in flight ahead of the MFMAs
+    auto ld_tile = [&](int jb, double (&f)[16]) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) f[t] = Lmat[(size_t)(jb * 64 + t * 4 + kk) * n + r0 + c];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_tile = [&](int jb, const double (&f)[16]) {
+      double bf[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) bf[t] = Y[(size_t)(jb * 64 + t * 4 + kk) * ldy + c];
+#pragma unroll
+      for (int t = 0; t < 16; t += 4) {
+        acc0 = mfma_f64(-f[t], bf[t], acc0);
+        acc1 = mfma_f64(-f[t + 1], bf[t + 1], acc1);
+        acc2 = mfma_f64(-f[t + 2], bf[t + 2], acc2);
+        acc3 = mfma_f64(-f[t + 3], bf[t + 3], acc3);
       }
+    };
+    {
+      double fA[16], fB[16], fC[16];
+      const int ntile = nb - 1 - kb;                  // tiles jb = nb-1 .. kb+1, index q -> jb = nb-1-q
+      if (ntile > 0) ld_tile(nb - 1, fA);
+      if (ntile > 1) ld_tile(nb - 2, fB);
+      int q = 0;
+      for (; q + 2 < ntile; q += 3) {
+        ld_tile(nb - 1 - (q + 2), fC);
+        mma_tile(nb - 1 - q, fA);
+        ld_tile(nb - 1 - (q + 3 < ntile ? q + 3 : q + 2), fA);
+        mma_tile(nb - 2 - q, fB);
+        ld_tile(nb - 1 - (q + 4 < ntile ? q + 4 : q + 2), fB);
+        mma_tile(nb - 3 - q, fC);
+      }
+      if (q < ntile) mma_tile(nb - 1 - q, fA);
+      if (q + 1 < ntile) mma_tile(nb - 2 - q, fB);
     }
-    acc0 += acc1;
+    acc0 = (acc0 + acc1) + (acc2 + acc3);
     __syncthreads();  // every wave has finished reading Y_k rows of this block before tmp reuse
 #pragma unroll
     for (int r = 0; r < 4; ++r) tmp[w * 16 + kk + 4 * r][c] = acc0[r];
     __syncthreads();
-    const double* Li = Linv + (size_t)kb * 64 * 64;
     double4_t x0 = (double4_t){0.0, 0.0, 0.0, 0.0}, x1 = x0;
 #pragma unroll
     for (int t = 0; t < 16; t += 2) {
       const int k0 = t * 4 + kk;
       // A[i][k] = Linv[k][w*16 + i]
-      x0 = mfma_f64(Li[(size_t)k0 * 64 + w * 16 + c], tmp[k0][c], x0);
-      x1 = mfma_f64(Li[(size_t)(k0 + 4) * 64 + w * 16 + c], tmp[k0 + 4][c], x1);
+      x0 = mfma_f64(li_f[t], tmp[k0][c], x0);
+      x1 = mfma_f64(li_f[t + 1], tmp[k0 + 4][c], x1);
     }
     x0 += x1;
 #pragma unroll
