@@ -158,6 +158,26 @@ def generation_leg(device, world, n_images, steps, edited_slab, inp):
             "data": "synthetic weights, synthetic prompts, CPU-seeded latents", "seconds": round(el, 3)}
 
 
+def xattn_leg(device):
+    """Cross-attention kernel alone at SD-1.4's four attn2 shapes (B = 2: the CFG pair of one image,
+    H = 8, Lk = 77, bf16): algorithmic bytes = Q + O + K + V once, per launch, vs the HBM peak."""
+    from uce_amd import edit as E
+    H = E.UceHandle.get(device)
+    out = []
+    for Lq, dh in ((4096, 40), (1024, 80), (256, 160), (64, 160)):
+        C = 8 * dh
+        q = torch.randn(2, Lq, C, device=device).bfloat16()
+        k = torch.randn(2, 77, C, device=device).bfloat16()
+        v = torch.randn_like(k)
+        o = torch.empty_like(q)
+        ms = time_kernel(lambda: H.xattn(q, k, v, 8, out=o), 100)
+        byts = 2.0 * (2 * Lq * C * 2) + 2.0 * (2 * 77 * C * 2)
+        out.append({"Lq": Lq, "dh": dh, "avg_us": round(ms * 1e3, 2), "bytes": byts,
+                    "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    return {"kernel": "k_xattn", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shapes": out,
+            "note": "batch-2 launches move 1.4-10.7 MB each: launch/latency-bound, not bandwidth-bound"}
+
+
 def time_kernel(fn, iters: int):
     """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
     back-to-back launches (the library enqueues on torch's current stream)."""
@@ -308,6 +328,8 @@ def main() -> None:
     }
     if gen is not None:
         result["generate"] = gen
+    if rank == 0 and args.gen_images > 0:
+        result["xattn"] = xattn_leg(device)
     if rank == 0:
         _log("gpu part: " + json.dumps(result))
         if not args.no_cpu_baseline and world == 1:

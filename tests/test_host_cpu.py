@@ -123,3 +123,16 @@ def test_product_synth_agrees_with_oracle_tables():
     assert synth.sd14_module_table() == O.sd14_module_table()
     assert synth.sdxl_module_table() == O.sdxl_module_table()
     assert np.array_equal(synth.clip_like_embeddings(5, 64, 3), O.clip_like_embeddings(5, 64, 3))
+
+
+def test_batched_embedding_extraction_matches_per_string_path():
+    """one batched text-encoder forward + gather == one call per string."""
+    from uce_amd.sd import pipeline as sdp
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
+    long_prompt = " ".join(f"w{i}" for i in range(90))
+    prompts = ["Van Gogh", "", "art", "a painting by Picasso", long_prompt, "Van Gogh"]
+    one = E.last_token_embeddings(pipe, prompts, "cpu")
+    bat = E.last_token_embeddings(pipe, prompts, "cpu", batch_size=4)
+    assert list(one) == list(bat) and len(one) == 5
+    for k in one:
+        assert torch.allclose(one[k], bat[k], atol=1e-5, rtol=1e-5), k

@@ -25,7 +25,7 @@ def main(argv=None) -> None:
                              synthetic=args.synthetic_model, vae=False)
     edit.UCE(pipe, job.edit_concepts, job.guide_concepts, job.preserve_concepts, job.erase_scale,
              job.preserve_scale, job.lamb, job.save_dir, job.exp_name, device=job.device,
-             algo=cli.ALGO_IDS[args.algo])
+             algo=cli.ALGO_IDS[args.algo], embed_batch=args.embed_batch)
 
 
 if __name__ == "__main__":

@@ -69,6 +69,8 @@ EXTRA_RUNTIME_FLAGS = [
 ]
 EXTRA_EDIT_FLAGS = [
     ("--algo", dict(type=str, default="auto", choices=["auto", "primal", "dual"], help="solver formulation")),
+    ("--embed_batch", dict(type=int, default=0, help="batch this many concept strings per text-encoder forward "
+                                                      "(0 = one string per call, as the reference does)")),
 ]
 EXTRA_GENERATE_FLAGS = [
     ("--latents_only", dict(action="store_true", help="skip VAE decode / PNG encode, save latents (.pt)")),

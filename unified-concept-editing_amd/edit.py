@@ -254,14 +254,34 @@ def save_uce_state(slab: WeightSlab, save_dir: str, exp_name: str) -> str:
 # concept embeddings  (uce_sd_erase.py:25-42)
 # --------------------------------------------------------------------------------------------
 
-def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[Dict[str, torch.Tensor]] = None
-                          ) -> Dict[str, torch.Tensor]:
+def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[Dict[str, torch.Tensor]] = None,
+                          batch_size: int = 0) -> Dict[str, torch.Tensor]:
     """Per UNIQUE string: text-encoder hidden state at index `attention_mask.sum() - 2`
-    (the last real token; '' -> the BOS position).  Returns {prompt: [d] fp32 on `device`}."""
+    (the last real token; '' -> the BOS position).  Returns {prompt: [d] fp32 on `device`}.
+
+    batch_size == 0 reproduces the reference call pattern exactly (one `encode_prompt` per unique
+    string, uce_sd_erase.py:26-42).  batch_size > 0 is SURVEY.md section 8(f) row 1: all unique
+    strings go through the text encoder in batches of that size and the last-token rows are
+    gathered on the device - the text encoder, not the closed-form solve, is what a 1 500-concept
+    edit spends its wall-clock on."""
     out = {} if cache is None else cache
+    todo = []
     for e in prompts:
-        if e in out:
-            continue
+        if e not in out and e not in todo:
+            todo.append(e)
+    if batch_size and batch_size > 1 and len(todo) > 1:
+        for i in range(0, len(todo), batch_size):
+            chunk = todo[i:i + batch_size]
+            t_emb = pipe.encode_prompt(prompt=chunk, device=device, num_images_per_prompt=1,
+                                       do_classifier_free_guidance=False)[0]            # [B, 77, d]
+            mask = pipe.tokenizer(chunk, padding="max_length", max_length=pipe.tokenizer.model_max_length,
+                                  truncation=True, return_tensors="pt")["attention_mask"]
+            idx = (mask.sum(dim=1) - 2).to(t_emb.device)
+            rows = t_emb[torch.arange(len(chunk), device=t_emb.device), idx, :]
+            for e, r in zip(chunk, rows):
+                out[e] = r.to(device=device, dtype=torch.float32)
+        return out
+    for e in todo:
         t_emb = pipe.encode_prompt(prompt=e, device=device, num_images_per_prompt=1,
                                    do_classifier_free_guidance=False)
         mask = pipe.tokenizer(e, padding="max_length", max_length=pipe.tokenizer.model_max_length,
@@ -314,7 +334,8 @@ def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[
 
 
 def UCE(pipe, edit_concepts, guide_concepts, preserve_concepts, erase_scale, preserve_scale, lamb, save_dir,
-        exp_name, device: str = "cuda:0", algo: int = _lib.ALGO_AUTO, return_slab: bool = False):
+        exp_name, device: str = "cuda:0", algo: int = _lib.ALGO_AUTO, return_slab: bool = False,
+        embed_batch: int = 0):
     """Same positional signature and artifact as the reference's UCE() (uce_sd_erase.py:12);
     `device` replaces the module global the reference reads."""
     start_time = time.time()
@@ -323,7 +344,7 @@ def UCE(pipe, edit_concepts, guide_concepts, preserve_concepts, erase_scale, pre
     modules = collect_uce_modules(pipe.unet)
     slab = WeightSlab.from_modules(modules, handle.device)
     embeds = last_token_embeddings(pipe, list(edit_concepts) + list(guide_concepts) + list(preserve_concepts),
-                                   handle.device)
+                                   handle.device, batch_size=embed_batch)
     C, G, s = concept_matrices(embeds, edit_concepts, guide_concepts, preserve_concepts, erase_scale,
                                preserve_scale, handle.device)
     new = edit_slab(handle, slab, C, G, s, lamb, algo)
