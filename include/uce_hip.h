@@ -87,7 +87,7 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
 int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const float* R, float* W_new,
                       long rows, int d, int N_edit, uce_stream_t stream);
 
-/* The same update as two kernels (what uce_edit uses for N_edit >= 33, d in {768, 1024, 2048}):
+/* The same update as two kernels (what uce_edit uses for d in {768, 1024, 2048} and slabs of >= 1024 rows):
  *   uce_lowrank_project : T [rows, NEP] f32 = W_old Dm^T,  NEP = roundup(N_edit, 64) is T's row stride.
  *                         Needs only Dm, not the solve: uce_edit runs the 64x64 Cholesky of the dual
  *                         system inside the same launch (block 0), hidden under this GEMM.

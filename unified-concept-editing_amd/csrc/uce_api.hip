@@ -237,7 +237,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   rc = uce_ensure(h, d, n_pad);
   if (rc) return rc;
   static const int no_split = getenv("UCE_NO_SPLIT") ? atoi(getenv("UCE_NO_SPLIT")) : 0;
-  if (!no_split && N_edit >= 33 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
+  if (!no_split && N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
     // N <= 64: THREE launches on the caller's stream, no events:
     //   1 projection T = W_old (G - C_e)^T   ||   block 0 of the same launch: K = lambda S^-1 + C C^T and
     //     its 64x64 Cholesky + inverse (hidden under the GEMM)

@@ -252,31 +252,38 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   }
   __syncthreads();
   if (!*s_last_p) return;
-  if (half == 0) {
-    const int ti = tid >> 4, tj = tid & 15;
-    double a[4][4], x[4][4];
+  // last arriver: all 8 waves factor - waves 0-3 carry the matrix tiles, waves 4-7 the tiles of L^-1
+  {
+    const int t256 = tid & 255;
+    const int ti = t256 >> 4, tj = t256 & 15;
+    double tt[4][4];
+    if (half == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int row = 4 * ti + r, col = 4 * tj + cc;
-        double v = j.slabs[row * 64 + col];
+        for (int cc = 0; cc < 4; ++cc) {
+          const int row = 4 * ti + r, col = 4 * tj + cc;
+          double v = j.slabs[row * 64 + col];
 #pragma unroll
-        for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)b * 64 * 64 + row * 64 + col];   // fixed order
-        if (row == col) {
-          const float sv = (row < j.N) ? j.s[row] : 1.f;
-          v += (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
+          for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)b * 64 * 64 + row * 64 + col];   // fixed order
+          if (row == col) {
+            const float sv = (row < j.N) ? j.s[row] : 1.f;
+            v += (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
+          }
+          tt[r][cc] = v;
         }
-        a[r][cc] = v;
-      }
-    potrf64_reg(a, x, sc, tid, j.status, 0);
+      potrf64_reg8<0>(tt, sc, t256, j.status, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        j.Lmat[(4 * ti + r) * 64 + 4 * tj + cc] = a[r][cc];
-        j.Linv[(4 * ti + r) * 64 + 4 * tj + cc] = x[r][cc];
-      }
+        for (int cc = 0; cc < 4; ++cc) j.Lmat[(4 * ti + r) * 64 + 4 * tj + cc] = tt[r][cc];
+    } else {
+      potrf64_reg8<1>(tt, sc, t256, j.status, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) j.Linv[(4 * ti + r) * 64 + 4 * tj + cc] = tt[r][cc];
+    }
   }
 }
 

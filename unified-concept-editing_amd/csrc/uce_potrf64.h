@@ -134,6 +134,109 @@ __device__ __forceinline__ void potrf64_reg(double (&a)[4][4], double (&x)[4][4]
 
 // Factors diagonal block 0.  With nsplit > 1 the block is first summed from the split-K slabs of
 // the Gram kernel (single-block systems skip the separate reduction launch).
+// ---------------------------------------------------------------------------------------------
+// 8-wave variant (512 threads): waves 0-3 own the matrix tiles (a), waves 4-7 own the tiles of X.
+// Same block elimination, same LDS lines, same single barrier per pivot pair; each thread issues
+// half the f64 FMAs and half the LDS traffic of the 4-wave version.  role = 0 (a) / 1 (x); `t` holds
+// this thread's 4x4 tile of its matrix on entry (role 1: ignored, X starts as I) and of L resp.
+// L^-1 on exit.
+// ---------------------------------------------------------------------------------------------
+template <int KR, int ROLE>
+__device__ __forceinline__ void potrf64_pair8(double (&t)[4][4], Potrf64Scratch* sc, int ti, int tj, int kb) {
+  const int K = 4 * kb + KR;
+  if (ROLE == 0) {
+    if (tj == kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc->col[K][4 * ti + r] = t[r][KR];
+        sc->col[K + 1][4 * ti + r] = t[r][KR + 1];
+      }
+    }
+  } else {
+    if (ti == kb) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sc->row[K][4 * tj + c] = t[KR][c];
+        sc->row[K + 1][4 * tj + c] = t[KR + 1][c];
+      }
+    }
+  }
+  __syncthreads();
+  const double p00 = sc->col[K][K], p01 = sc->col[K][K + 1], p11 = sc->col[K + 1][K + 1];
+  const double idet = rcp_f64(fma(p00, p11, -p01 * p01));
+  const double q00 = p11 * idet, q01 = -p01 * idet, q11 = p00 * idet;
+  double u[4], v[4], y0[4], y1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double a0 = sc->col[K][4 * ti + r], a1 = sc->col[K + 1][4 * ti + r];
+    u[r] = fma(a0, q00, a1 * q01);
+    v[r] = fma(a0, q01, a1 * q11);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    y0[c] = (ROLE == 0) ? sc->col[K][4 * tj + c] : sc->row[K][4 * tj + c];
+    y1[c] = (ROLE == 0) ? sc->col[K + 1][4 * tj + c] : sc->row[K + 1][4 * tj + c];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[r][c] = fma(-u[r], y0[c], fma(-v[r], y1[c], t[r][c]));
+}
+
+// All 512 threads call this (tid = 0..511).  role 0 threads pass their tile of the SPD block.
+template <int ROLE>
+__device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* sc, int tid256, int* status,
+                                             int col_base) {
+  const int ti = tid256 >> 4, tj = tid256 & 15;
+  if (ROLE == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
+  }
+#pragma unroll 1
+  for (int kb = 0; kb < 16; ++kb) {
+    potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
+    potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
+  }
+  __syncthreads();
+  if (ROLE == 0 && tid256 < 32) {
+    const int k = 2 * tid256;
+    const double p00 = sc->col[k][k], p01 = sc->col[k][k + 1], p11 = sc->col[k + 1][k + 1];
+    const double g = p01 / p00;
+    const double p11e = fma(-g, p01, p11);
+    const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
+    if ((bad0 | bad1) && tid256 == 0) {
+      const int f0 = bad0 ? 2 * __builtin_ctzll(bad0) : 128, f1 = bad1 ? 2 * __builtin_ctzll(bad1) + 1 : 128;
+      atomicCAS(status, 0, col_base + (f0 < f1 ? f0 : f1) + 1);
+    }
+    sc->rs[k] = 1.0 / sqrt(p00);
+    sc->rs[k + 1] = 1.0 / sqrt(p11e);
+    sc->g[k] = 0.0;
+    sc->g[k + 1] = g;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = 4 * ti + r, col = 4 * tj + c;
+      double val = 0.0;
+      if (col <= row) {
+        if (ROLE == 0) {
+          val = sc->col[col][row];
+          if (col & 1) val = fma(-sc->g[col], sc->col[col - 1][row], val);
+          val *= sc->rs[col];
+        } else {
+          val = sc->row[row][col];
+          if (row & 1) val = fma(-sc->g[row], sc->row[row - 1][col], val);
+          val *= sc->rs[row];
+        }
+      }
+      t[r][c] = val;
+    }
+}
+
 static __device__ __forceinline__ void potrf_first_body(const double* __restrict__ M, int n, int nsplit,
                                                         size_t slab_stride, double* __restrict__ Lmat,
                                                         double* __restrict__ Linv, int* status,
