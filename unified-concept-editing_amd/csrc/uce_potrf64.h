@@ -237,6 +237,38 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
     }
 }
 
+// 512-thread version of potrf_first_body (waves 0-3: matrix tiles, waves 4-7: tiles of L^-1)
+static __device__ __forceinline__ void potrf_first_body8(const double* __restrict__ M, int n, int nsplit,
+                                                         size_t slab_stride, double* __restrict__ Lmat,
+                                                         double* __restrict__ Linv, int* status,
+                                                         Potrf64Scratch* sc) {
+  const int tid = threadIdx.x, half = tid >> 8, t256 = tid & 255;
+  const int ti = t256 >> 4, tj = t256 & 15;
+  double tt[4][4];
+  if (half == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t off = (size_t)(4 * ti + r) * n + 4 * tj + c;
+        double v = M[off];
+        for (int sp = 1; sp < nsplit; ++sp) v += M[(size_t)sp * slab_stride + off];   // index order
+        tt[r][c] = v;
+      }
+    potrf64_reg8<0>(tt, sc, t256, status, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Lmat[(size_t)(4 * ti + r) * n + 4 * tj + c] = tt[r][c];
+  } else {
+    potrf64_reg8<1>(tt, sc, t256, status, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Linv[(4 * ti + r) * 64 + 4 * tj + c] = tt[r][c];
+  }
+}
+
 static __device__ __forceinline__ void potrf_first_body(const double* __restrict__ M, int n, int nsplit,
                                                         size_t slab_stride, double* __restrict__ Lmat,
                                                         double* __restrict__ Linv, int* status,

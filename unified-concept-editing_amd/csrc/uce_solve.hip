@@ -26,11 +26,11 @@ __device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
 }
 
 // Factors diagonal block 0 (body shared with the fused projection+factor launch, uce_potrf64.h).
-__global__ __launch_bounds__(256) void k_potrf_first(const double* __restrict__ M, int n, int nsplit,
+__global__ __launch_bounds__(512) void k_potrf_first(const double* __restrict__ M, int n, int nsplit,
                                                      size_t slab_stride, double* __restrict__ Lmat,
                                                      double* __restrict__ Linv, int* status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  potrf_first_body(M, n, nsplit, slab_stride, Lmat, Linv, status, (Potrf64Scratch*)smem_raw);
+  potrf_first_body8(M, n, nsplit, slab_stride, Lmat, Linv, status, (Potrf64Scratch*)smem_raw);
 }
 
 // one wave's 32x32 quadrant of  acc += sign * P[rows] * Q[cols]^T  (both tiles row-major in LDS,
@@ -70,7 +70,7 @@ __device__ __forceinline__ void quad_foreach(int row0, int col0, int lane, F f) 
       for (int r = 0; r < 4; ++r) f(m, n, r, row0 + m * 16 + rq + 4 * r, col0 + n * 16 + c);
 }
 
-__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ M, int n, int j,
+__global__ __launch_bounds__(512) void k_potrf_step(double* __restrict__ M, int n, int j,
                                                     double* __restrict__ Lmat,
                                                     double* __restrict__ Linv, int* status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -78,15 +78,18 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ M, int 
   double (*Mi)[LD] = (double (*)[LD])(smem_raw + 64 * LD * 8);       // M_ij  -> P_i
   double (*Mk)[LD] = (double (*)[LD])(smem_raw + 2 * 64 * LD * 8);   // M_kj  -> P_k
 
+  // 8 waves: quadrant = w & 3, half = w >> 2.  Half 0 forms P_i while half 1 forms P_k; half 0 does the
+  // tile update; the diagonal tile is then factored by all 8 waves (potrf64_reg8).
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+  const int half = w >> 2, wq = w & 3;
+  const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
   int ta, tb;
   tri_decode(blockIdx.x, ta, tb);
   const int i = j + 1 + ta, k = j + 1 + tb;
   const bool diag = (i == k);
 
   const double* Linv_j = Linv + (size_t)j * 64 * 64;
-  for (int e = tid; e < 64 * 64; e += 256) {
+  for (int e = tid; e < 64 * 64; e += 512) {
     const int r = e >> 6, c = e & 63;
     Li[r][c] = Linv_j[e];
     Mi[r][c] = M[(size_t)(i * 64 + r) * n + j * 64 + c];
@@ -94,61 +97,71 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ M, int 
   }
   __syncthreads();
 
-  // P_i = M_ij L_jj^-T ; P_k likewise
-  double4_t pi[2][2], pk[2][2];
-  quad_zero(pi);
-  quad_nt(pi, Mi, Li, wr, wc, lane, 1.0);
-  if (!diag) {
-    quad_zero(pk);
-    quad_nt(pk, Mk, Li, wr, wc, lane, 1.0);
-  }
+  // P_i = M_ij L_jj^-T (half 0) ; P_k likewise (half 1)
+  double4_t pp[2][2];
+  quad_zero(pp);
+  if (half == 0) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0);
+  else if (!diag) quad_nt(pp, Mk, Li, wr, wc, lane, 1.0);
   __syncthreads();
-  quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pi[m][nn][r]; });
-  if (!diag)
-    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pk[m][nn][r]; });
+  if (half == 0)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pp[m][nn][r]; });
+  else if (!diag)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pp[m][nn][r]; });
   __syncthreads();
 
   // tile (i, j+1) publishes L_ij
   if (k == j + 1) {
-    for (int e = tid; e < 64 * 64; e += 256) {
+    for (int e = tid; e < 64 * 64; e += 512) {
       const int r = e >> 6, c = e & 63;
       Lmat[(size_t)(i * 64 + r) * n + j * 64 + c] = Mi[r][c];
     }
   }
 
-  // M_ik -= P_i P_k^T
+  // M_ik -= P_i P_k^T   (half 0)
+  const bool factor_here = diag && i == j + 1;
   double4_t acc[2][2];
-  quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
-    acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
-  });
-  quad_nt(acc, Mi, diag ? Mi : Mk, wr, wc, lane, -1.0);
-
-  if (!(diag && i == j + 1)) {
+  if (half == 0) {
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
-      M[(size_t)(i * 64 + row) * n + k * 64 + col] = acc[m][nn][r];
+      acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
     });
-    return;
+    quad_nt(acc, Mi, diag ? Mi : Mk, wr, wc, lane, -1.0);
+    if (!factor_here) {
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+        M[(size_t)(i * 64 + row) * n + k * 64 + col] = acc[m][nn][r];
+      });
+    }
   }
+  if (!factor_here) return;
   // the next diagonal block: factor it now (accumulators -> LDS tile -> 4x4 register sub-blocks)
   __syncthreads();
-  quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
+  if (half == 0)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
   __syncthreads();
   Potrf64Scratch* sc = (Potrf64Scratch*)&Mi[0][0];   // P_i / P_k regions (66 KB) are dead now
-  const int ti = tid >> 4, tj = tid & 15;
-  double a[4][4], x[4][4];
+  const int t256 = tid & 255;
+  const int ti = t256 >> 4, tj = t256 & 15;
+  double tt[4][4];
+  if (half == 0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a[r][c] = Li[4 * ti + r][4 * tj + c];
-  potrf64_reg(a, x, sc, tid, status, i * 64);
-  double* Linv_n = Linv + (size_t)i * 64 * 64;
+      for (int c = 0; c < 4; ++c) tt[r][c] = Li[4 * ti + r][4 * tj + c];
+  }
+  __syncthreads();                                   // Li fully read before the scratch (which overlaps nothing of Li) is used
+  if (half == 0) {
+    potrf64_reg8<0>(tt, sc, t256, status, i * 64);
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      Lmat[(size_t)(i * 64 + 4 * ti + r) * n + i * 64 + 4 * tj + c] = a[r][c];
-      Linv_n[(4 * ti + r) * 64 + 4 * tj + c] = x[r][c];
-    }
+      for (int c = 0; c < 4; ++c) Lmat[(size_t)(i * 64 + 4 * ti + r) * n + i * 64 + 4 * tj + c] = tt[r][c];
+  } else {
+    potrf64_reg8<1>(tt, sc, t256, status, i * 64);
+    double* Linv_n = Linv + (size_t)i * 64 * 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Linv_n[(4 * ti + r) * 64 + 4 * tj + c] = tt[r][c];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,13 +346,13 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
                                     (int)smem_first));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(256), smem_first, st, (const double*)M, n, nsplit,
+  hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(512), smem_first, st, (const double*)M, n, nsplit,
                      slab_stride, h->Lmat, h->Linv, h->status);
   UCE_LAUNCH_CHECK();
   for (int j = 0; j + 1 < nb; ++j) {
     const int mt = nb - j - 1;
     const int tiles = mt * (mt + 1) / 2;
-    hipLaunchKernelGGL(k_potrf_step, dim3(tiles), dim3(256), smem, st, M, n, j, h->Lmat, h->Linv,
+    hipLaunchKernelGGL(k_potrf_step, dim3(tiles), dim3(512), smem, st, M, n, j, h->Lmat, h->Linv,
                        h->status);
     UCE_LAUNCH_CHECK();
   }
