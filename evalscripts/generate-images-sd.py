@@ -23,7 +23,7 @@ def main(argv=None) -> None:
         exp_name=a.exp_name, device=a.device, torch_dtype=torch.bfloat16, guidance_scale=a.guidance_scale,
         num_inference_steps=a.num_inference_steps, num_images_per_prompt=a.num_images_per_prompt,
         from_case=a.from_case, till_case=a.till_case, model_dir=a.model_dir, synthetic=a.synthetic_model,
-        latents_only=a.latents_only, skip_existing=a.skip_existing)
+        latents_only=a.latents_only, skip_existing=a.skip_existing, batch_prompts=a.batch_prompts)
     if int(stats["rank"]) == 0 and stats["seconds"] > 0:
         total = stats.get("images_total", stats["images"])
         secs = stats.get("seconds_max", stats["seconds"])

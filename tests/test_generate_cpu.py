@@ -71,6 +71,39 @@ def test_single_process_generation_names_and_seeding(tmp_path):
     assert (np.asarray(Image.open(tmp_path / "orig2" / "1_0.png")) == a).all()
 
 
+def test_batched_rows_equal_row_by_row(tmp_path):
+    """--batch_prompts: B rows per U-Net call, every row with its own CPU-seeded latents ->
+    the same files as the row-by-row loop of generate-images-sd.py:29-46."""
+    prompts = _tiny_prompts(tmp_path, 5)
+    kw = dict(model_id="tiny-sd-test", uce_model_path=None, prompts_path=prompts, save_path=str(tmp_path), device="cpu",
+              torch_dtype=torch.float32, num_inference_steps=3, num_images_per_prompt=2, synthetic=True, latents_only=True)
+    generate.generate_images(exp_name="rows", batch_prompts=1, **kw)
+    st = generate.generate_images(exp_name="batched", batch_prompts=3, **kw)     # 3 + a ragged batch of 2
+    assert st["images"] == 10
+    assert sorted(os.listdir(tmp_path / "batched")) == sorted(os.listdir(tmp_path / "rows")) == [f"{c}.pt" for c in range(5)]
+    for c in range(5):
+        a, b = torch.load(tmp_path / "rows" / f"{c}.pt"), torch.load(tmp_path / "batched" / f"{c}.pt")
+        assert a.shape == (2, 4, 8, 8)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), c
+    # PNG path through the worker threads: same names
+    kw["latents_only"] = False
+    generate.generate_images(exp_name="png", batch_prompts=4, **kw)
+    assert sorted(os.listdir(tmp_path / "png")) == [f"{c}_{i}.png" for c in range(5) for i in range(2)]
+
+
+def test_pipeline_generator_list_forms():
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
+    g = lambda s: torch.Generator().manual_seed(s)
+    one = [pipe(p, num_inference_steps=2, num_images_per_prompt=2, generator=g(7 + i), output_type="latent").latents
+           for i, p in enumerate(["a", "b"])]
+    both = pipe(["a", "b"], num_inference_steps=2, num_images_per_prompt=2, generator=[g(7), g(8)], output_type="latent").latents
+    assert torch.allclose(torch.cat(one), both, rtol=1e-4, atol=1e-5)
+    per_image = pipe(["a", "b"], num_inference_steps=2, generator=[g(1), g(2)], output_type="latent").latents
+    assert per_image.shape[0] == 2
+    with pytest.raises(ValueError):
+        pipe(["a", "b"], num_inference_steps=2, num_images_per_prompt=2, generator=[g(1), g(2), g(3)], output_type="latent")
+
+
 def test_patch_unet_rejects_unknown_keys(tmp_path):
     pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
     with pytest.raises(KeyError):
@@ -95,3 +128,21 @@ def test_two_rank_gloo_generation_with_broadcast(tmp_path):
     assert one == two == [f"{c}.pt" for c in range(5)]
     for f in one:
         assert torch.equal(torch.load(tmp_path / "one" / f), torch.load(tmp_path / "two" / f))
+
+
+def test_debias_sampling_is_sharded_over_ranks(tmp_path):
+    """the get_ratios sampling loop (uce_sd_debias.py:14-35) round-robins the edit concepts
+    over the ranks and all-reduces the [N_edit, N_debias] matrix: both ranks end with the single-process matrix."""
+    worker = os.path.join(REPO_ROOT, "tests", "debias_ratios_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    subprocess.run([sys.executable, worker, str(tmp_path)], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29541", worker, str(tmp_path)],
+                   check=True, env=env, timeout=900)
+    one = np.load(tmp_path / "ratios_w1_r0.npy")
+    assert one.shape == (5, 2) and np.allclose(one.sum(axis=1), 0.0)      # desired sums to 1, observed sums to 1
+    for r in (0, 1):
+        assert np.array_equal(np.load(tmp_path / f"ratios_w2_r{r}.npy"), one)
+    c0 = open(tmp_path / "calls_w2_r0.txt").read().split(";")
+    c1 = open(tmp_path / "calls_w2_r1.txt").read().split(";")
+    assert c0 == ["doctor", "teacher", "chef"] and c1 == ["nurse", "pilot"]   # disjoint, round-robin

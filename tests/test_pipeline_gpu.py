@@ -109,3 +109,66 @@ def test_debias_ratio_arithmetic():
     assert np.allclose(r, [-0.2, 0.2])
     r = debias.ratios_from_labels(["male"] * 5 + ["female"] * 5, ["male", "female"], [0.52, 0.48], 0.05)
     assert np.all(r == 0)
+
+
+def _tiny_gpu_pipe(vae=False, seed=3):
+    from uce_amd.sd import pipeline as sdp
+    return sdp.load_pipeline("tiny-sd-test", torch.bfloat16, "cuda:0", synthetic=True, vae=vae, seed=seed)
+
+
+def test_hipgraph_step_matches_eager_and_sees_weight_patches():
+    """The denoising evaluation replayed from a hipGraph (uce_xattn_fwd captured on the capture stream) vs the
+    eager launches; an in-place patch of the attn2 weights must be visible to the captured graph."""
+    from uce_amd import edit as E
+    from uce_amd.sd import pipeline as sdp
+    pipe = _tiny_gpu_pipe()
+    g = lambda: torch.Generator().manual_seed(5)
+    kw = dict(num_inference_steps=3, output_type="latent")
+    pipe.use_graph = False
+    eager = pipe("a photo of a dog", generator=g(), **kw).latents.float()
+    pipe.use_graph = True
+    graph = pipe("a photo of a dog", generator=g(), **kw).latents.float()
+    assert len(pipe._graphs) == 1
+    assert O.rel_fro(graph, eager) < 2e-2
+    again = pipe("a photo of a dog", generator=g(), **kw).latents.float()       # replay of the cached graph
+    assert len(pipe._graphs) == 1 and O.rel_fro(again, eager) < 2e-2
+    other = pipe("a cat", generator=g(), **kw).latents.float()                    # new context, same graph
+    assert len(pipe._graphs) == 1 and O.rel_fro(other, eager) > 1e-3
+    mods = E.collect_uce_modules(pipe.unet)
+    sdp.patch_unet(pipe, {n + ".weight": m.weight.float() * -2.0 for n, m in mods})
+    patched_graph = pipe("a photo of a dog", generator=g(), **kw).latents.float()
+    pipe.use_graph = False
+    patched_eager = pipe("a photo of a dog", generator=g(), **kw).latents.float()
+    assert O.rel_fro(patched_graph, patched_eager) < 2e-2
+    assert O.rel_fro(patched_graph, eager) > 1e-3
+
+
+def test_batched_prompts_match_single_prompts_on_gpu():
+    pipe = _tiny_gpu_pipe()
+    g = lambda s: torch.Generator().manual_seed(s)
+    kw = dict(num_inference_steps=3, output_type="latent")
+    single = torch.cat([pipe(p, generator=g(20 + i), **kw).latents for i, p in enumerate(["a dog", "a cat", "a tree"])])
+    batch = pipe(["a dog", "a cat", "a tree"], generator=[g(20), g(21), g(22)], **kw).latents
+    assert batch.shape == single.shape
+    assert O.rel_fro(batch.float(), single.float()) < 2e-2
+
+
+def test_debias_loop_with_real_sampling_on_gpu(tmp_path):
+    """debias.UCE end to end (sampling through the tiny pipeline, a deterministic stand-in classifier):
+    get_ratios -> cumulative drift -> re-solve, until balanced or max_iterations; artifact written."""
+    from safetensors.torch import load_file
+    from uce_amd import debias
+    from uce_amd.sd import pipeline as sdp
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cuda:0", synthetic=True, vae=True)
+    seen = []
+
+    def classify(images, labels):
+        seen.append(len(images))
+        return [labels[int(np.asarray(im)[..., 0].mean() > np.asarray(im)[..., 1].mean())] for im in images]
+
+    slab, path = debias.UCE(pipe, classify, ["doctor", "nurse"], ["male", "female"], ["a dog"], 1.0, 1.0, 0.5,
+                            str(tmp_path), "deb_real", 0.05, 0.1, 4, 2, 7.5, desired_ratios=[0.5, 0.5],
+                            max_iterations=2, device="cuda:0")
+    assert seen and all(n == 4 for n in seen) and len(seen) % 2 == 0 and len(seen) <= 4
+    state = load_file(path)
+    assert len(state) == 32 and all(torch.isfinite(v).all() for v in state.values())

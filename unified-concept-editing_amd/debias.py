@@ -7,6 +7,10 @@ concepts, turn the observed ratios into `direction_scale = desired - observed` (
 |diff| < max_diff), stop when everything is balanced, otherwise re-solve the closed form with the
 CUMULATIVE drift (the reference adds the drift in place to its cached guide outputs, so it
 accumulates; `step_size` is parsed but never used there - kept that way).
+
+Multi-GPU: launched with torch.distributed.run, the sampling +
+classification of the edit concepts is sharded round-robin over the ranks and the ratio matrix is
+all-reduced; the closed-form solve is replicated (it is < 1 ms; "replicas only").
 """
 from __future__ import annotations
 
@@ -31,20 +35,33 @@ def ratios_from_labels(labels: Sequence[str], debias_concepts: Sequence[str], de
 
 
 def get_ratios(pipe, classify: Callable, slab: E.WeightSlab, edit_concepts, debias_concepts, desired_ratios, max_diff,
-               num_images_per_prompt=10, num_inference_steps=20, guidance_scale=7.5) -> np.ndarray:
-    """uce_sd_debias.py:14-35 (images are sampled UNSEEDED there too)."""
+               num_images_per_prompt=10, num_inference_steps=20, guidance_scale=7.5, rank: int = 0, world: int = 1,
+               reduce_device=None) -> np.ndarray:
+    """uce_sd_debias.py:14-35 (images are sampled UNSEEDED there too).
+
+    Sharded over the ranks of one node: edit concept i is sampled and classified on rank i % world (its
+    `num_images_per_prompt` images are one U-Net batch), every rank fills its own rows of the
+    [N_edit, N_debias] float64 `direction_scale` matrix, and ONE all-reduce (sum; the rows are disjoint)
+    gives every rank the whole matrix - a few hundred bytes over RCCL/xGMI (gloo on CPU)."""
     state = slab.state_dict()
     if hasattr(pipe.unet, "cfg"):
         sdp.patch_unet(pipe, state)
     else:
         pipe.unet.load_state_dict(state, strict=False)
-    direction_scale = []
-    for concept in edit_concepts:
+    direction_scale = np.zeros((len(edit_concepts), len(debias_concepts)), dtype=np.float64)
+    for i, concept in enumerate(edit_concepts):
+        if i % world != rank:
+            continue
         images = pipe(concept, num_inference_steps=num_inference_steps, num_images_per_prompt=num_images_per_prompt,
                       guidance_scale=guidance_scale).images
         labels = classify(images, debias_concepts)
-        direction_scale.append(ratios_from_labels(labels, debias_concepts, desired_ratios, max_diff))
-    return np.array(direction_scale)
+        direction_scale[i] = ratios_from_labels(labels, debias_concepts, desired_ratios, max_diff)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.from_numpy(direction_scale).to(reduce_device if reduce_device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        direction_scale = t.cpu().numpy()
+    return direction_scale
 
 
 def clip_zero_shot_classifier(device):
@@ -64,7 +81,13 @@ def UCE(pipe, classify, edit_concepts, debias_concepts, preserve_concepts, edit_
     """Same positional signature as the reference's debias UCE() (:37); `desired_ratios`,
     `max_iterations`, `device` replace the module globals it reads; `ratios_fn` lets a test script
     the (unseeded, irreproducible) sampling step."""
+    from .generate import dist_env, init_distributed
+    rank, world, local = dist_env()
+    if world > 1 and torch.device(device).type == "cuda":      # one process per GPU
+        device = f"cuda:{local}"
+        torch.cuda.set_device(local)
     handle = E.UceHandle.get(device)
+    init_distributed(handle.device)
     modules = E.collect_uce_modules(pipe.unet)
     slab = E.WeightSlab.from_modules(modules, handle.device)
     embeds = E.last_token_embeddings(pipe, list(edit_concepts) + list(debias_concepts) + list(preserve_concepts),
@@ -81,12 +104,16 @@ def UCE(pipe, classify, edit_concepts, debias_concepts, preserve_concepts, edit_
             direction_scale = ratios_fn(iteration=iteration, slab=state.current)
         else:
             direction_scale = get_ratios(pipe, classify, state.current, edit_concepts, debias_concepts, desired_ratios,
-                                         max_diff, num_images_per_prompt, num_inference_steps, guidance_scale)
+                                         max_diff, num_images_per_prompt, num_inference_steps, guidance_scale,
+                                         rank=rank, world=world, reduce_device=handle.device)
         if np.abs(direction_scale).max() == 0:                 # :110-112
-            print("All concepts are debiased")
+            if rank == 0:
+                print("All concepts are debiased")
             break
         state.step(direction_scale)
     end_time = time.time()
-    path = E.save_uce_state(state.current, save_dir, exp_name)
-    print(f"\n\nDebiased concepts using UCE\nModel edited in {end_time - start_time} seconds\n")
+    # every rank holds the same weights (same direction_scale history, bit-repeatable solve): rank 0 writes
+    path = E.save_uce_state(state.current, save_dir, exp_name) if rank == 0 else None
+    if rank == 0:
+        print(f"\n\nDebiased concepts using UCE\nModel edited in {end_time - start_time} seconds\n")
     return state.current, path

@@ -9,12 +9,15 @@ Reference behaviour kept: bf16 pipeline, optional patch of the U-Net with the ed
 Added: when launched with WORLD_SIZE > 1 (one process per GPU, torch.distributed; backend nccl =
 RCCL over xGMI on ROCm, gloo on CPU) rank 0 reads the edited-weight file and BROADCASTS the blob
 to the other ranks (one collective, ~77 MB fp32 for SD-1.4), then rank r generates the selected
-rows with `index % world == r`: no data-path collective after that.
+rows with `index % world == r`: no data-path collective after that.  `--batch_prompts B` denoises B
+rows per U-Net call (at batch 2 = one prompt's CFG pair the U-Net is launch-bound on an MI355X; rows are
+independent, so batching is free throughput) and PNG encoding overlaps the next batch on worker threads.
 """
 from __future__ import annotations
 
 import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -81,7 +84,11 @@ def select_rows(df, from_case: int, till_case: int, rank: int, world: int):
 def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name="test", device="cuda:0",
                     torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=100,
                     num_images_per_prompt=10, from_case=0, till_case=1000000, model_dir=None, synthetic=False,
-                    latents_only=False, skip_existing=False, pipe=None) -> Dict[str, float]:
+                    latents_only=False, skip_existing=False, pipe=None, batch_prompts: int = 1,
+                    png_workers: int = 4) -> Dict[str, float]:
+    """evalscripts/generate-images-sd.py:10-46.  `batch_prompts` CSV rows are denoised as one batch (each row
+    still draws its latents from its own CPU generator seeded with `evaluation_seed`, exactly the draw the
+    reference makes row by row); file names and contents per image are those of the row-by-row loop."""
     import pandas as pd
     rank, world, local = dist_env()
     dev = torch.device(device)
@@ -109,23 +116,38 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
 
     t0 = time.perf_counter()
     n_img = 0
-    for _, row in mine:
-        prompt = str(row.prompt)
-        seed = int(row.evaluation_seed)
-        case_number = row.case_number
-        if skip_existing and os.path.exists(f"{folder_path}/{case_number}_0.png"):
-            continue
-        out = pipe(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                   num_images_per_prompt=num_images_per_prompt,
-                   generator=torch.Generator().manual_seed(seed),
+    todo = [row for _, row in mine
+            if not (skip_existing and os.path.exists(f"{folder_path}/{row.case_number}_0.png"))]
+    batch_prompts = max(1, int(batch_prompts))
+    # PNG encoding (host, ~30 ms per 512x512 image) runs on worker threads behind the next batch's denoising
+    writer = ThreadPoolExecutor(max_workers=png_workers) if (png_workers > 0 and not latents_only) else None
+    pending = []
+    for lo in range(0, len(todo), batch_prompts):
+        rows = todo[lo:lo + batch_prompts]
+        prompts = [str(r.prompt) for r in rows]
+        gens = [torch.Generator().manual_seed(int(r.evaluation_seed)) for r in rows]   # generate-images-sd.py:36
+        single = len(rows) == 1
+        out = pipe(prompt=prompts[0] if single else prompts, num_inference_steps=num_inference_steps,
+                   guidance_scale=guidance_scale, num_images_per_prompt=num_images_per_prompt,
+                   generator=gens[0] if single else gens,
                    **({"output_type": "latent"} if latents_only else {}))
-        if latents_only:
-            lat = out.latents if hasattr(out, "latents") else out.images
-            torch.save(lat.cpu(), f"{folder_path}/{case_number}.pt")
-        else:
-            for num, im in enumerate(out.images):
-                im.save(f"{folder_path}/{case_number}_{num}.png")
-        n_img += num_images_per_prompt
+        for i, r in enumerate(rows):
+            sl = slice(i * num_images_per_prompt, (i + 1) * num_images_per_prompt)
+            if latents_only:
+                lat = out.latents if hasattr(out, "latents") else out.images
+                torch.save(lat[sl].cpu(), f"{folder_path}/{r.case_number}.pt")
+            else:
+                for num, im in enumerate(out.images[sl]):
+                    path = f"{folder_path}/{r.case_number}_{num}.png"
+                    if writer is None:
+                        im.save(path)
+                    else:
+                        pending.append(writer.submit(im.save, path))
+        n_img += num_images_per_prompt * len(rows)
+    for f in pending:
+        f.result()                                            # surface encode / disk errors
+    if writer is not None:
+        writer.shutdown()
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0

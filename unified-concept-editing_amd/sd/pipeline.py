@@ -24,6 +24,11 @@ import torch.nn.functional as F
 from torch import nn
 
 from .scheduler import PNDMScheduler
+
+# MIOpen times every applicable solver the first time it meets a convolution; its reference
+# ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
+# batch 2 (48 ms average over 384 calls in profiles/r01), far more at larger batches.  It never wins.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 from .unet import UNet2DConditionModel, UNetConfig
 
 MAX_LEN = 77
@@ -184,6 +189,62 @@ class PipeOutput:
     latents: torch.Tensor
 
 
+class _GraphedStep:
+    """One denoising evaluation - cat(latents) -> U-Net -> classifier-free-guidance combine - captured
+    once in a hipGraph and replayed per step.  At batch 2 the eager U-Net is launch-bound (~1 900
+    launches of a few microseconds each per call); a replay issues them back to back.  Inputs live in
+    fixed buffers: the latents, the timestep (device tensor), the text context and the hoisted K/V of
+    every attn2 (rewritten per prompt by `set_context`).  Parameters are captured by address, so an
+    in-place weight patch (`patch_unet`) is picked up without re-capturing."""
+
+    def __init__(self, pipe, n: int, hh: int, ww: int, cfg: bool, guidance_scale: float, ctx: torch.Tensor):
+        from .unet import Attention
+        unet, dev = pipe.unet, pipe.device
+        self.unet = unet
+        self.lat = torch.zeros((n, unet.cfg.in_channels, hh, ww), device=dev, dtype=pipe.dtype)
+        self.t = torch.zeros((1,), device=dev, dtype=torch.long)
+        self.ctx = ctx.clone()
+        self.cross = [m for m in unet.modules() if isinstance(m, Attention) and m.is_cross]
+        self.kv = [(m.to_k(self.ctx), m.to_v(self.ctx)) for m in self.cross]
+        self._bind()
+
+        def body():
+            x = torch.cat([self.lat] * 2) if cfg else self.lat
+            eps = unet(x, self.t, self.ctx)
+            if cfg:
+                eu, ec = eps.chunk(2)
+                eps = eu + guidance_scale * (ec - eu)
+            return eps
+
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                      # warm-up off the capture: kernel selection, workspaces
+            for _ in range(2):
+                body()
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.eps = body()
+
+    def _bind(self):
+        for m, kv in zip(self.cross, self.kv):
+            m.kv_cache = kv
+
+    def set_context(self, ctx: torch.Tensor) -> None:
+        self.ctx.copy_(ctx)
+        for m, (k, v) in zip(self.cross, self.kv):
+            k.copy_(m.to_k(self.ctx))                      # the same GEMM call as the eager path: bitwise equal
+            v.copy_(m.to_v(self.ctx))
+        self._bind()
+
+    def __call__(self, latents: torch.Tensor, t: int) -> torch.Tensor:
+        self.lat.copy_(latents)
+        self.t.fill_(int(t))
+        self.graph.replay()
+        return self.eps.clone()                            # PNDM keeps a history of past outputs
+
+
 class StableDiffusionPipeline:
     def __init__(self, unet: UNet2DConditionModel, text_encoder, tokenizer, vae: Optional[VaeDecoder],
                  scheduler: Optional[PNDMScheduler] = None):
@@ -192,11 +253,15 @@ class StableDiffusionPipeline:
         self.device = torch.device("cpu")
         self.dtype = torch.float32
         self.hoist_context = True        # K/V of the (step-invariant) text context computed once per prompt
+        self.use_graph = True            # on a GPU: replay the denoising evaluation from a hipGraph
+        self.channels_last = True        # on a GPU: NHWC weights/activations for the convolutions
+        self._graphs: Dict[tuple, _GraphedStep] = {}
 
     # -- same call the reference makes: DiffusionPipeline.from_pretrained(...).to(device)
     def to(self, device=None, dtype=None):
         if isinstance(device, torch.dtype):
             device, dtype = None, device
+        self._graphs.clear()             # parameter storage may move: captured addresses are stale
         for m in (self.unet, self.text_encoder, self.vae):
             if m is not None:
                 m.to(device=device, dtype=dtype)
@@ -204,6 +269,11 @@ class StableDiffusionPipeline:
             self.device = torch.device(device)
         if dtype is not None:
             self.dtype = dtype
+        if self.device.type == "cuda" and self.channels_last:
+            # MIOpen's bf16 implicit-GEMM kernels are NHWC: NCHW activations cost two transposes per conv
+            for m in (self.unet, self.vae):
+                if m is not None:
+                    m.to(memory_format=torch.channels_last)
         return self
 
     def set_progress_bar_config(self, **kw):
@@ -229,32 +299,63 @@ class StableDiffusionPipeline:
             ne = enc(neg)
         return pe, ne
 
+    def _draw_latents(self, n_prompts: int, n: int, hh: int, ww: int, generator) -> torch.Tensor:
+        """diffusers' randn_tensor: a CPU generator draws on the CPU in the target dtype, then moves.
+        One generator -> one draw of the whole batch (what generate-images-sd.py:37-42 gets for its single
+        prompt).  A list with one generator per PROMPT -> each draws its prompt's [n, C, h, w] block, so a
+        batch of prompts reproduces exactly the latents the reference draws prompt by prompt; a list with one
+        generator per IMAGE is diffusers' own list form ([1, C, h, w] each)."""
+        C = self.unet.cfg.in_channels
+
+        def draw(g, k):
+            gdev = g.device if g is not None else self.device
+            return torch.randn((k, C, hh, ww), generator=g, device=gdev, dtype=self.dtype).to(self.device)
+
+        if isinstance(generator, (list, tuple)):
+            if len(generator) == n_prompts:
+                return torch.cat([draw(g, n) for g in generator])
+            if len(generator) == n_prompts * n:
+                return torch.cat([draw(g, 1) for g in generator])
+            raise ValueError(f"got {len(generator)} generators for {n_prompts} prompts x {n} images")
+        return draw(generator, n_prompts * n)
+
     @torch.no_grad()
     def __call__(self, prompt, num_inference_steps: int = 50, guidance_scale: float = 7.5,
-                 num_images_per_prompt: int = 1, generator: Optional[torch.Generator] = None,
+                 num_images_per_prompt: int = 1, generator=None,
                  output_type: str = "pil", height: int = None, width: int = None, **kw) -> PipeOutput:
+        """`prompt` may be a list: the prompts are denoised as ONE batch (images are independent units, so
+        this is the same result per image as calling prompt by prompt, at a multiple of the throughput)."""
         n = num_images_per_prompt
         cfg = guidance_scale > 1.0
+        n_prompts = 1 if isinstance(prompt, str) else len(prompt)
         pe, ne = self.encode_prompt(prompt, self.device, n, cfg)
         ctx = torch.cat([ne, pe]) if cfg else pe
         s = self.unet.cfg.sample_size
         hh, ww = (height // 8 if height else s), (width // 8 if width else s)
-        # diffusers' randn_tensor: a CPU generator draws on the CPU in the target dtype, then moves
-        gdev = generator.device if generator is not None else self.device
-        latents = torch.randn((n, self.unet.cfg.in_channels, hh, ww), generator=generator, device=gdev,
-                              dtype=self.dtype).to(self.device)
+        latents = self._draw_latents(n_prompts, n, hh, ww, generator)
+        n = n_prompts * n                                  # batch of the denoising loop from here on
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, device="cpu")
         latents = latents * sch.init_noise_sigma
-        if self.hoist_context:
+        graphed = None
+        if self.use_graph and self.hoist_context and self.device.type == "cuda":
+            key = (n, hh, ww, cfg, float(guidance_scale), tuple(ctx.shape), self.dtype)
+            graphed = self._graphs.get(key)
+            if graphed is None:
+                graphed = self._graphs[key] = _GraphedStep(self, n, hh, ww, cfg, float(guidance_scale), ctx)
+            graphed.set_context(ctx)
+        elif self.hoist_context:
             self.unet.cache_context(ctx)
         try:
             for t in sch.timesteps.tolist():
-                x = torch.cat([latents] * 2) if cfg else latents
-                eps = self.unet(x, torch.tensor([t], device=self.device), ctx)
-                if cfg:
-                    eu, ec = eps.chunk(2)
-                    eps = eu + guidance_scale * (ec - eu)
+                if graphed is not None:
+                    eps = graphed(latents, t)
+                else:
+                    x = torch.cat([latents] * 2) if cfg else latents
+                    eps = self.unet(x, torch.tensor([t], device=self.device), ctx)
+                    if cfg:
+                        eu, ec = eps.chunk(2)
+                        eps = eu + guidance_scale * (ec - eu)
                 latents = sch.step(eps, t, latents)
         finally:
             self.unet.cache_context(None)
