@@ -272,7 +272,7 @@ def main() -> None:
     # ---- per-kernel timing of the dominant kernel, HIP events on the launch stream
     use_dual = (algo == 2) or (algo == 0 and ((N + 63) // 64) * 64 < d)
     iters = max(20, min(200, args.steps))
-    if use_dual and 33 <= n_e <= 256 and d in (768, 1024, 2048):
+    if use_dual and 1 <= n_e <= 256 and d in (768, 1024, 2048) and rows >= 1024:
         # uce_edit's path here: projection (+ riders) -> triangular solves -> update; the update is the
         # HBM-bound pass over the weights and the longest kernel
         Dm, R = H.dual_factors(C, G, s, 0.5)
@@ -280,7 +280,7 @@ def main() -> None:
         ms = time_kernel(lambda: H.lowrank_update(W, T, R, out=out), iters)
         nep = T.shape[1]
         alg_bytes = 8.0 * rows * d + 4.0 * rows * nep + 4.0 * n_e * d      # W in + W out, T in, R once
-        roof = dict(kernel="k_lr_update_r16" if n_e <= 64 else "k_lr_update", bound="hbm",
+        roof = dict(kernel="k_lr_update_s" if n_e <= 128 else "k_lr_update", bound="hbm",
                     achieved=round(alg_bytes / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     avg_ms=round(ms, 5), algorithmic_bytes=alg_bytes)
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)

@@ -515,6 +515,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// update, single-buffered R, buffer addressing.
+//  * The register holding k-step t's R fragment is reloaded IN PLACE with the next column group's
+//    fragment right after the MFMAs of step t have consumed it.  Program order of the vector-memory
+//    stream per group g is   W prefetch(g+1) | R(g+1)[0..NK-1] (between the MFMA steps) | stores(g),
+//    so the wait for R(g+1)[t] at step t of group g+1 covers only loads issued a whole MFMA loop
+//    earlier: the in-order vmcnt never makes a step wait for a load issued during the current group.
+//    Half the registers of the double-buffered r16 form.
+//  * Every stream is a buffer load/store: ONE 32-bit lane offset for all of them, the per-step /
+//    per-row / per-group displacement folded into the (scalar) resource base, and the resource's
+//    num_records doing the bounds work: concept rows >= N_edit read as 0 and weight rows >= rows are
+//    neither read nor written - no clamped 64-bit address pairs (2 VGPRs per stream with flat
+//    addressing), no per-row branches.  (The scalar offset operand is not part of the hardware range
+//    check, hence base shifting instead of soffset.)
+// ---------------------------------------------------------------------------------------------
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0 ? bytes : 0, 0x00020000);
+}
+
+template <int D, int UP_MT, int WPE, int NK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_update_s(
+    const float* __restrict__ W_old, const float* __restrict__ T, const float* __restrict__ R,
+    float* __restrict__ W_new, long rows, int Ne, int NEP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int d = D;
+  constexpr int SR = UP_MT * 16;
+  const int tld = NEP + 2;
+  float* Ts = (float*)smem_raw;                       // [SR][tld]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long R0 = (long)blockIdx.x * SR;
+  constexpr int MG = D / 256;
+
+  const float* Wb = W_old + R0 * d;                   // workgroup-uniform bases
+  float* Ob = W_new + R0 * d;
+  const int w_bytes = (int)((rows - R0) < SR ? (rows - R0) : SR) * d * 4;   // this tile's valid weight bytes
+  const int r_bytes = Ne * d * 4;
+  // the one lane offset (bytes): R row lk / W row 4*lk of the step's / tile's base, columns w*64 + 4*li
+  const unsigned vo_r = (unsigned)((lk * d + w * 64 + 4 * li) * 4);
+  const unsigned vo_w = (unsigned)((4 * lk * d + w * 64 + 4 * li) * 4);
+
+  auto ld_r = [&](int t, int gi) -> float4_t {
+    const int sh = (4 * t * d + gi * 256) * 4;
+    return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(R + 4 * t * d + gi * 256, r_bytes - sh), vo_r, 0, 0));
+  };
+  auto ld_w = [&](int m, int r, int gi) -> float4_t {
+    const int sh = ((m * 16 + r) * d + gi * 256) * 4;
+    return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+        make_rsrc(Wb + (m * 16 + r) * d + gi * 256, w_bytes - sh), vo_w, 0, 0));
+  };
+
+  float4_t rr[NK];
+  float4_t res[UP_MT][4];
+#pragma unroll
+  for (int t = 0; t < NK; ++t) rr[t] = ld_r(t, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) res[m][r] = ld_w(m, r, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const int f4_row = NEP >> 2;
+    for (int e = tid; e < SR * f4_row; e += 256) {
+      const int r = e / f4_row, c = (e - r * f4_row) << 2;
+      long gr = R0 + r;
+      gr = gr < rows ? gr : rows - 1;
+      const float4_t v = *(const float4_t*)(T + gr * NEP + c);
+      Ts[r * tld + c] = c < Ne ? v[0] : 0.f;          // pad columns -> 0: the k loop reads unconditionally
+      Ts[r * tld + c + 1] = c + 1 < Ne ? v[1] : 0.f;
+      Ts[r * tld + c + 2] = c + 2 < Ne ? v[2] : 0.f;
+      Ts[r * tld + c + 3] = c + 3 < Ne ? v[3] : 0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int gi = 0; gi < MG; ++gi) {
+    float4_t acc[UP_MT][4];                           // acc[m][q][r]: row m*16 + 4*lk + r, column 4*li + q
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q][r] = res[m][r][q];
+    if (gi + 1 < MG) {
+#pragma unroll
+      for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[m][r] = ld_w(m, r, gi + 1);
+    }
+    float a[UP_MT];                                   // T fragments, read from LDS one step ahead
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m) a[m] = Ts[(m * 16 + li) * tld + lk];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+      float an[UP_MT];
+#pragma unroll
+      for (int m = 0; m < UP_MT; ++m) an[m] = (t + 1 < NK) ? Ts[(m * 16 + li) * tld + 4 * (t + 1) + lk] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < UP_MT; ++m)
+          acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], rr[t][q], acc[m][q], 0, 0, 0);
+      if (gi + 1 < MG) rr[t] = ld_r(t, gi + 1);       // reload in place: next group's fragment for step t
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < UP_MT; ++m) a[m] = an[m];
+    }
+#pragma unroll
+    for (int m = 0; m < UP_MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4_t o = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+        const int sh = ((m * 16 + r) * d + gi * 256) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o),
+                                               make_rsrc(Ob + (m * 16 + r) * d + gi * 256, w_bytes - sh), vo_w, 0,
+                                               2 /* nt */);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // rows / 16 tiles over 256 CUs with MT tiles per workgroup: time ~ ceil(workgroups / 256) * MT
 int pick_mt2(long rows) {
   const long t16 = (rows + 15) / 16;
@@ -592,10 +717,46 @@ int launch_update_r16(const float* W_old, const float* T, const float* R, float*
   return UCE_OK;
 }
 
+template <int D, int UP_MT, int WPE>
+int launch_update_s(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
+                    int NEP64, hipStream_t st) {
+  const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
+  const dim3 grid((unsigned)((rows + UP_MT * 16 - 1) / (UP_MT * 16))), block(256);
+  const int nks = (N_edit + 3) / 4;
+  if (nks <= 8)
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 8>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else if (nks <= 13)
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 13>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else if (nks <= 16)
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 16>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else if (nks <= 25)
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 25>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else if (nks <= 32)
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 32>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+  else
+    return UCE_EINVAL;
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
 template <int D>
 int launch_update_d(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
                     int NEP64, hipStream_t st) {
-  static const int variant = getenv("UCE_UPDATE_VARIANT") ? atoi(getenv("UCE_UPDATE_VARIANT")) : 10;
+  static const int variant = getenv("UCE_UPDATE_VARIANT") ? atoi(getenv("UCE_UPDATE_VARIANT")) : 20;
+  if (N_edit <= 128) {
+    switch (variant) {
+      case 20:   // default (measured best at N_edit 16..128 on MI355X, tools/sweep_update.sh)
+        return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 21: return launch_update_s<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 22: return launch_update_s<D, 3, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 23: return launch_update_s<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 24: return launch_update_s<D, 2, 1>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 25: return launch_update_s<D, 2, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 26: return launch_update_s<D, 1, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      case 27: return launch_update_s<D, 1, 4>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
+      default: break;
+    }
+  }
   if (N_edit <= 64) {
     switch (variant) {
       case 10:   // default: the widest tile whose register-resident R set does not spill
