@@ -320,14 +320,18 @@ def test_lowrank_project_and_update(H, Ne, d, rows_):
     assert O.rel_fro(fused.cpu(), want) < 1e-6
 
 
-@pytest.mark.parametrize("N_e,N_p,d,rows_", [(40, 10, 1024, 4096), (36, 4, 2048, 2600), (120, 30, 768, 5000)])
+@pytest.mark.parametrize("N_e,N_p,d,rows_", [(40, 10, 1024, 4096), (36, 4, 2048, 2600), (120, 30, 768, 5000),
+                                             (65, 0, 768, 1024), (100, 0, 768, 24960), (100, 28, 768, 2048),
+                                             (60, 30, 1024, 2048), (70, 50, 2048, 1300), (128, 64, 768, 1500)])
 def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
-    """uce_edit's forked path (N_edit >= 33, rows >= 1024) at SD-2.x / SDXL widths vs torch fp64 on the GPU,
-    run twice back to back (the side stream re-uses the handle's workspace)."""
+    """uce_edit's project / solve / update path (rows >= 1024) vs torch fp64 on the GPU, run twice back to back
+    (the handle's workspace and the riders' ticket word are re-used): N <= 64 and 64 < N <= 128 take the
+    Gram + Cholesky rider blocks inside the projection launch (one and three system tiles), larger N the
+    launch chain; SD-1.x / SD-2.x / SDXL widths; non-uniform scales."""
     N = N_e + N_p
     Call = O.clip_like_embeddings(N + 1, d, seed=N + d)
     C, G = Call[:N], np.repeat(Call[N:N + 1], N_e, axis=0)
-    s = np.ones(N, dtype=np.float32)
+    s = (0.5 + np.random.Generator(np.random.PCG64(7 * N + d)).random(N)).astype(np.float32)
     rng = np.random.Generator(np.random.PCG64(N))
     Cd, Gd, sd = _dev(C), _dev(G), _dev(s)
     for rep in range(2):
@@ -335,6 +339,23 @@ def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
         Wd = _dev(W)
         out = H.edit(Cd, Gd, sd, 0.5, Wd, check=True)
         C64, W64 = Cd.double(), Wd.double()
-        A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda:0") + C64.T @ C64
-        Delta = torch.linalg.solve(A, C64[:N_e].T @ (Gd - Cd[:N_e]).double()).T
+        s64 = sd.double()
+        A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda:0") + C64.T @ (s64[:, None] * C64)
+        Delta = torch.linalg.solve(A, (s64[:N_e, None] * C64[:N_e]).T @ (Gd - Cd[:N_e]).double()).T
         assert O.rel_fro(out.cpu(), (W64 + W64 @ Delta).cpu()) < EPS_BUILD
+
+
+def test_rider_path_reports_indefinite_system(H):
+    """A non-positive scale in the SECOND 64-block of a 100-concept dual system: the rider blocks' in-launch
+    factorisation must flag it through uce_status (the reference would return an LU garbage inverse)."""
+    N, d = 100, 768
+    Call = O.clip_like_embeddings(N + 1, d, seed=5)
+    C, G = Call[:N], np.repeat(Call[N:N + 1], N, axis=0)
+    s = np.ones(N, dtype=np.float32)
+    s[70] = -1.0
+    W = _dev(O.linear_default_weight(2048, d, np.random.Generator(np.random.PCG64(1))))
+    with pytest.raises(L.UceError):
+        H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, check=True)
+    s[70] = 1.0                                                  # and the handle recovers
+    out = H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, check=True)
+    assert torch.isfinite(out).all()

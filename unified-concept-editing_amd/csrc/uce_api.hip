@@ -238,15 +238,15 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   if (rc) return rc;
   static const int no_split = getenv("UCE_NO_SPLIT") ? atoi(getenv("UCE_NO_SPLIT")) : 0;
   if (!no_split && N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
-    // N <= 64: THREE launches on the caller's stream, no events:
-    //   1 projection T = W_old (G - C_e)^T   ||   block 0 of the same launch: K = lambda S^-1 + C C^T and
-    //     its 64x64 Cholesky + inverse (hidden under the GEMM)
+    // N <= 128: THREE launches on the caller's stream, no events:
+    //   1 projection T = W_old (G - C_e)^T   ||   rider blocks of the same launch: K = lambda S^-1 + C C^T and
+    //     its (blocked) Cholesky + block inverses (hidden under the GEMM)
     //   2 triangular solves -> R     3 update W_new = W_old + T R
-    // N > 64: Gram launch + potrf launch chain first, then the same three without the rider.
+    // N > 128: Gram launch + potrf launch chain first, then the same three without the riders.
     rc = uce_ensure_T(h, rows, N_edit);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (n_pad == 64) {
+    if (n_pad <= lr_rider_max_n()) {
       rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st, h, C, s, N, lamb);
       if (rc) return rc;
     } else {

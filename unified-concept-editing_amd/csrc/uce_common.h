@@ -71,6 +71,7 @@ int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d
                               hipStream_t st);
 int launch_sub_rows(const float* G, const float* C, float* Dm, long n, hipStream_t st);
 bool lowrank_split_supported(int d, int N_edit);
+int lr_rider_max_n();   // largest dual system (rows, multiple of 64) the projection launch's riders factor
 int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
                       int N_edit, hipStream_t st, uce_ctx* h = nullptr, const float* C = nullptr,
                       const float* s = nullptr, int N = 0, float lamb = 0.f);

@@ -146,54 +146,66 @@ struct GramPotrfJob {
   const float* s;       // [N]
   int N;
   float lamb;
-  double* slabs;        // [GP_NB][64][64] partial Grams
+  double* slabs;        // [tiles * GP_NB][64][64] partial Grams
   unsigned* ticket;     // one word, zero between launches
-  double* Lmat;         // [64, 64] (ld 64)
-  double* Linv;         // [64, 64]
+  double* Lmat;         // [n, n], n = 64 * nb
+  double* Linv;         // [nb][64][64]
   int* status;
+  double* M;            // [n, n] assembled system (nb > 1 only)
+  int nb;               // 64-blocks of the dual system handled by the riders: 1 or 2
 };
 
-constexpr int GP_NB = 4;        // rider blocks
+constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of the system (split over the feature axis)
+constexpr int GP_MAXB = 2;      // largest system the riders take: 128 x 128 (3 lower tiles)
 constexpr int GP_LD = 40;       // floats, k-contiguous NT tile stride (conflict-free b128)
 constexpr int GP_TLD = 66;      // doubles
 
+__host__ __device__ constexpr int gp_riders(int nb) { return GP_NB * nb * (nb + 1) / 2; }
+
 template <int D>
 __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned char* smem_raw) {
-  float* As = (float*)smem_raw;                                   // [2 halves][64][GP_LD]
-  double* P1 = (double*)(smem_raw + 2 * 64 * GP_LD * sizeof(float));   // [64][GP_TLD]
-  Potrf64Scratch* sc = (Potrf64Scratch*)(smem_raw + 2 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double));
+  float* As = (float*)smem_raw;                                   // [2 halves][64][GP_LD]  rows of block ti
+  float* Bs = As + 2 * 64 * GP_LD;                                // [2 halves][64][GP_LD]  rows of block tk
+  constexpr size_t AB_BYTES = (size_t)4 * 64 * GP_LD * sizeof(float);
+  double* P1 = (double*)(smem_raw + AB_BYTES);                    // [64][GP_TLD]
+  Potrf64Scratch* sc = (Potrf64Scratch*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double));
   // (all LDS in the dynamic region: a static __shared__ would shift its 16-byte alignment)
-  unsigned* s_last_p = (unsigned*)(smem_raw + 2 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch));
+  unsigned* s_last_p = (unsigned*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch));
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = w >> 2, wq = w & 3;
   const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
   const int ht = tid & 255;                                       // thread index within its half
-  const int blk = blockIdx.x;                                     // 0 .. GP_NB-1
+  const int tile = blockIdx.x / GP_NB, blk = blockIdx.x % GP_NB;  // tile of the system, feature slice
+  const int ti = tile == 0 ? 0 : 1, tk = tile == 2 ? 1 : 0;       // lower tiles in order (0,0) (1,0) (1,1)
+  const int nriders = gp_riders(j.nb);
   double4_t acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
   float* Ah = As + half * 64 * GP_LD;
+  float* Bh = Bs + half * 64 * GP_LD;
   const int lrow = ht >> 3, lc4 = (ht & 7) * 4;
   constexpr int KS = D / (2 * GP_NB);                             // features per (block, half) slice
   constexpr int NCH = KS / 32;                                    // 32-feature chunks (3 / 4 / 8)
   const int kbeg = (blk * 2 + half) * KS;
   // the whole slice is fetched up front (one memory round trip instead of one per chunk)
-  float4_t pre[NCH][2];
+  float4_t pre[NCH][2], preb[NCH][2];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int r = p * 32 + lrow;
-      pre[ch][p] = *(const float4_t*)(j.C + (size_t)(r < j.N ? r : j.N - 1) * D + kbeg + ch * 32 + lc4);
+      const int ra = ti * 64 + p * 32 + lrow, rb = tk * 64 + p * 32 + lrow;
+      pre[ch][p] = *(const float4_t*)(j.C + (size_t)(ra < j.N ? ra : j.N - 1) * D + kbeg + ch * 32 + lc4);
+      preb[ch][p] = *(const float4_t*)(j.C + (size_t)(rb < j.N ? rb : j.N - 1) * D + kbeg + ch * 32 + lc4);
     }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int r = p * 32 + lrow;
-      *(float4_t*)&Ah[r * GP_LD + lc4] = (r < j.N) ? pre[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
+      *(float4_t*)&Ah[r * GP_LD + lc4] = (ti * 64 + r < j.N) ? pre[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
+      *(float4_t*)&Bh[r * GP_LD + lc4] = (tk * 64 + r < j.N) ? preb[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 #pragma unroll
@@ -201,8 +213,8 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
       const int kofs = u * 16 + 4 * (lane >> 4);
       const float4_t fa0 = *(const float4_t*)&Ah[(wr + (lane & 15)) * GP_LD + kofs];
       const float4_t fa1 = *(const float4_t*)&Ah[(wr + 16 + (lane & 15)) * GP_LD + kofs];
-      const float4_t fb0 = *(const float4_t*)&Ah[(wc + (lane & 15)) * GP_LD + kofs];
-      const float4_t fb1 = *(const float4_t*)&Ah[(wc + 16 + (lane & 15)) * GP_LD + kofs];
+      const float4_t fb0 = *(const float4_t*)&Bh[(wc + (lane & 15)) * GP_LD + kofs];
+      const float4_t fb1 = *(const float4_t*)&Bh[(wc + 16 + (lane & 15)) * GP_LD + kofs];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         acc[0][0] = mfma_f64((double)fa0[t], (double)fb0[t], acc[0][0]);
@@ -224,7 +236,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
         for (int r = 0; r < 4; ++r) P1[(wr + m * 16 + rq + 4 * r) * GP_TLD + wc + n * 16 + c] = acc[m][n][r];
   }
   __syncthreads();
-  double* myslab = j.slabs + (size_t)blk * 64 * 64;
+  double* myslab = j.slabs + (size_t)blockIdx.x * 64 * 64;
   if (half == 0) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -243,8 +255,8 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(j.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_last_p = (t == GP_NB - 1) ? 1u : 0u;
-    if (t == GP_NB - 1) {
+    *s_last_p = (t == (unsigned)nriders - 1) ? 1u : 0u;
+    if (t == (unsigned)nriders - 1) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(j.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       *j.status = 0;
@@ -252,49 +264,72 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   }
   __syncthreads();
   if (!*s_last_p) return;
-  // last arriver: all 8 waves factor - waves 0-3 carry the matrix tiles, waves 4-7 the tiles of L^-1
-  {
+  auto diag_term = [&](int row) -> double {
+    const float sv = (row < j.N) ? j.s[row] : 1.f;
+    return (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
+  };
+  if (j.nb == 1) {
+    // last arriver: all 8 waves factor - waves 0-3 carry the matrix tiles, waves 4-7 the tiles of L^-1
     const int t256 = tid & 255;
-    const int ti = t256 >> 4, tj = t256 & 15;
+    const int tti = t256 >> 4, ttj = t256 & 15;
     double tt[4][4];
     if (half == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          const int row = 4 * ti + r, col = 4 * tj + cc;
+          const int row = 4 * tti + r, col = 4 * ttj + cc;
           double v = j.slabs[row * 64 + col];
 #pragma unroll
           for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)b * 64 * 64 + row * 64 + col];   // fixed order
-          if (row == col) {
-            const float sv = (row < j.N) ? j.s[row] : 1.f;
-            v += (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
-          }
+          if (row == col) v += diag_term(row);
           tt[r][cc] = v;
         }
       potrf64_reg8<0>(tt, sc, t256, j.status, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) j.Lmat[(4 * ti + r) * 64 + 4 * tj + cc] = tt[r][cc];
+        for (int cc = 0; cc < 4; ++cc) j.Lmat[(4 * tti + r) * 64 + 4 * ttj + cc] = tt[r][cc];
     } else {
       potrf64_reg8<1>(tt, sc, t256, j.status, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) j.Linv[(4 * ti + r) * 64 + 4 * tj + cc] = tt[r][cc];
+        for (int cc = 0; cc < 4; ++cc) j.Linv[(4 * tti + r) * 64 + 4 * ttj + cc] = tt[r][cc];
+    }
+    return;
+  }
+  // nb == 2: the last arriver assembles the 128 x 128 system and runs the blocked factorisation that
+  // uce_solve.hip spreads over a chain of launches (same tile bodies), alone, under the projection GEMM:
+  // factor (0,0) -> tile (1,1) of step 0 (forms L_10, updates and factors block 1).
+  const int n = 64 * j.nb;
+  for (int t = 0; t < 3; ++t) {
+    const int gi = t == 0 ? 0 : 1, gk = t == 2 ? 1 : 0;
+    for (int e = tid; e < 64 * 64; e += 512) {
+      const int r = e >> 6, cc = e & 63;
+      double v = j.slabs[(size_t)(t * GP_NB) * 4096 + e];
+#pragma unroll
+      for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)(t * GP_NB + b) * 4096 + e];        // fixed order
+      const int grow = gi * 64 + r, gcol = gk * 64 + cc;
+      if (grow == gcol) v += diag_term(grow);
+      j.M[(size_t)grow * n + gcol] = v;
     }
   }
+  __syncthreads();                                    // the block's own global writes -> visible to the block
+  potrf_first_body8(j.M, n, 1, 0, j.Lmat, j.Linv, j.status, (Potrf64Scratch*)smem_raw);
+  __syncthreads();
+  potrf_step_tile(j.M, n, 0, 1, 1, j.Lmat, j.Linv, j.status, smem_raw);
 }
 
-constexpr size_t GP_SMEM = 2 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch) + 16;
+constexpr size_t GP_SMEM = (size_t)4 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch) + 16;
+static_assert(GP_SMEM >= POTRF_STEP_SMEM, "the step tile body aliases the rider's LDS");
 
 template <int D, int MT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_project(
     const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ Csub,
     float* __restrict__ T, long rows, int Ne, int NEP, GramPotrfJob job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int has_rider = job.C ? GP_NB : 0;
+  const int has_rider = job.C ? gp_riders(job.nb) : 0;
   if ((int)blockIdx.x < has_rider) {
     gram_potrf_rider<D>(job, smem_raw);
     return;
@@ -664,7 +699,7 @@ int launch_project(const float* W_old, const float* Dm, const float* Csub, float
                                     160 * 1024));
     attr_set = true;
   }
-  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? GP_NB : 0);
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) : 0);
   hipLaunchKernelGGL((k_lr_project<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
                      N_edit, NEP64, job);
   UCE_LAUNCH_CHECK();
@@ -781,6 +816,11 @@ int launch_update_d(const float* W_old, const float* T, const float* R, float* W
 
 }  // namespace
 
+int lr_rider_max_n() {
+  static const int cap = getenv("UCE_RIDER_MAX_N") ? atoi(getenv("UCE_RIDER_MAX_N")) : 64 * GP_MAXB;
+  return cap < 64 * GP_MAXB ? cap : 64 * GP_MAXB;
+}
+
 bool lowrank_split_supported(int d, int N_edit) {
   return (d == 768 || d == 1024 || d == 2048) && N_edit >= 1 && N_edit <= 256;
 }
@@ -792,7 +832,11 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
                       int N_edit, hipStream_t st, uce_ctx* h, const float* C, const float* s, int N, float lamb) {
   const int NEP64 = (N_edit + 63) / 64 * 64;
   GramPotrfJob job{};
-  if (h) job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status};
+  if (h) {
+    const int nb = (N + 63) / 64;
+    if (nb < 1 || nb > GP_MAXB) return UCE_EINVAL;
+    job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, h->M, nb};
+  }
   if (d == 768) return launch_project_d<768>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
   if (d == 1024) return launch_project_d<1024>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
   if (d == 2048) return launch_project<2048, 5>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);

@@ -316,4 +316,142 @@ static __device__ __forceinline__ void potrf_first_body(const double* __restrict
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// One trailing tile (i, k), j < k <= i, of step j of the blocked right-looking Cholesky (block 64), by
+// one 512-thread workgroup:  P_i = M_ij L_jj^-T (= L_ij),  P_k = M_kj L_jj^-T,  M_ik -= P_i P_k^T;
+// tile (i, j+1) publishes L_ij; tile (j+1, j+1) then factors itself (-> L, L^-1 of block j+1).
+// Called once per workgroup by k_potrf_step (uce_solve.hip) and in a loop by the last rider block of
+// the projection launch (uce_lowrank2.hip).  smem_raw: POTRF_STEP_SMEM bytes.
+// ---------------------------------------------------------------------------------------------
+constexpr int LD = 66;  // row stride (doubles) of the 64x64 LDS tiles: conflict-free ds_read_b64
+constexpr size_t POTRF_STEP_SMEM = 3 * 64 * LD * sizeof(double);
+
+// one wave's 32x32 quadrant of  acc += sign * P[rows] * Q[cols]^T  (both tiles row-major in LDS,
+// contraction index contiguous)
+__device__ __forceinline__ void quad_nt(double4_t (&acc)[2][2], const double (*P)[LD],
+                                        const double (*Q)[LD], int row0, int col0, int lane,
+                                        double sign) {
+  const int r = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+  for (int kb = 0; kb < 16; ++kb) {
+    const int t = kb * 4 + kk;
+    const double a0 = sign * P[row0 + r][t], a1 = sign * P[row0 + 16 + r][t];
+    const double b0 = Q[col0 + r][t], b1 = Q[col0 + 16 + r][t];
+    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+  }
+}
+
+__device__ __forceinline__ void quad_zero(double4_t (&acc)[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+}
+
+// accumulator quadrant <-> memory (D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4r, col = lane&15)
+template <typename F>
+__device__ __forceinline__ void quad_foreach(int row0, int col0, int lane, F f) {
+  const int c = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(m, n, r, row0 + m * 16 + rq + 4 * r, col0 + n * 16 + c);
+}
+
+static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, int n, int j, int i, int k,
+                                                       double* __restrict__ Lmat, double* __restrict__ Linv,
+                                                       int* status, unsigned char* smem_raw) {
+  double (*Li)[LD] = (double (*)[LD])smem_raw;                       // L_jj^-1
+  double (*Mi)[LD] = (double (*)[LD])(smem_raw + 64 * LD * 8);       // M_ij  -> P_i
+  double (*Mk)[LD] = (double (*)[LD])(smem_raw + 2 * 64 * LD * 8);   // M_kj  -> P_k
+
+  // 8 waves: quadrant = w & 3, half = w >> 2.  Half 0 forms P_i while half 1 forms P_k; half 0 does the
+  // tile update; the diagonal tile is then factored by all 8 waves (potrf64_reg8).
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int half = w >> 2, wq = w & 3;
+  const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
+  const bool diag = (i == k);
+
+  const double* Linv_j = Linv + (size_t)j * 64 * 64;
+  for (int e = tid; e < 64 * 64; e += 512) {
+    const int r = e >> 6, c = e & 63;
+    Li[r][c] = Linv_j[e];
+    Mi[r][c] = M[(size_t)(i * 64 + r) * n + j * 64 + c];
+    if (!diag) Mk[r][c] = M[(size_t)(k * 64 + r) * n + j * 64 + c];
+  }
+  __syncthreads();
+
+  // P_i = M_ij L_jj^-T (half 0) ; P_k likewise (half 1)
+  double4_t pp[2][2];
+  quad_zero(pp);
+  if (half == 0) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0);
+  else if (!diag) quad_nt(pp, Mk, Li, wr, wc, lane, 1.0);
+  __syncthreads();
+  if (half == 0)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pp[m][nn][r]; });
+  else if (!diag)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pp[m][nn][r]; });
+  __syncthreads();
+
+  // tile (i, j+1) publishes L_ij
+  if (k == j + 1) {
+    for (int e = tid; e < 64 * 64; e += 512) {
+      const int r = e >> 6, c = e & 63;
+      Lmat[(size_t)(i * 64 + r) * n + j * 64 + c] = Mi[r][c];
+    }
+  }
+
+  // M_ik -= P_i P_k^T   (half 0)
+  const bool factor_here = diag && i == j + 1;
+  double4_t acc[2][2];
+  if (half == 0) {
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+      acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
+    });
+    quad_nt(acc, Mi, diag ? Mi : Mk, wr, wc, lane, -1.0);
+    if (!factor_here) {
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+        M[(size_t)(i * 64 + row) * n + k * 64 + col] = acc[m][nn][r];
+      });
+    }
+  }
+  if (!factor_here) return;
+  // the next diagonal block: factor it now (accumulators -> LDS tile -> 4x4 register sub-blocks)
+  __syncthreads();
+  if (half == 0)
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
+  __syncthreads();
+  Potrf64Scratch* sc = (Potrf64Scratch*)&Mi[0][0];   // P_i / P_k regions (66 KB) are dead now
+  const int t256 = tid & 255;
+  const int ti = t256 >> 4, tj = t256 & 15;
+  double tt[4][4];
+  if (half == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tt[r][c] = Li[4 * ti + r][4 * tj + c];
+  }
+  __syncthreads();                                   // Li fully read before the scratch (which overlaps nothing of Li) is used
+  if (half == 0) {
+    potrf64_reg8<0>(tt, sc, t256, status, i * 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Lmat[(size_t)(i * 64 + 4 * ti + r) * n + i * 64 + 4 * tj + c] = tt[r][c];
+  } else {
+    potrf64_reg8<1>(tt, sc, t256, status, i * 64);
+    double* Linv_n = Linv + (size_t)i * 64 * 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Linv_n[(4 * ti + r) * 64 + 4 * tj + c] = tt[r][c];
+  }
+}
+
 }  // namespace
