@@ -168,38 +168,28 @@ def generation_leg(device, world, n_images, steps, edited_slab, inp, batch=8):
             "data": "synthetic weights, synthetic prompts, CPU-seeded latents", "seconds": round(el, 3)}
 
 
-def xattn_leg(device):
-    """Cross-attention kernel alone at SD-1.4's four attn2 shapes (B = 2: the CFG pair of one image,
-    H = 8, Lk = 77, bf16): algorithmic bytes = Q + O + K + V once, per launch, vs the HBM peak."""
+def xattn_leg(device, batches=(2, 16)):
+    """Cross-attention kernel alone at SD-1.4's four attn2 shapes (H = 8, Lk = 77, bf16) at B = 2 (the CFG pair
+    of one prompt) and at the batch the generation leg runs (2 x prompts per U-Net call): algorithmic bytes =
+    Q + O + K + V once, per launch, vs the HBM peak."""
     from uce_amd import edit as E
     H = E.UceHandle.get(device)
     out = []
-    for Lq, dh in ((4096, 40), (1024, 80), (256, 160), (64, 160)):
-        C = 8 * dh
-        q = torch.randn(2, Lq, C, device=device).bfloat16()
-        k = torch.randn(2, 77, C, device=device).bfloat16()
-        v = torch.randn_like(k)
-        o = torch.empty_like(q)
-        ms = time_kernel(lambda: H.xattn(q, k, v, 8, out=o), 100)
-        byts = 2.0 * (2 * Lq * C * 2) + 2.0 * (2 * 77 * C * 2)
-        out.append({"Lq": Lq, "dh": dh, "avg_us": round(ms * 1e3, 2), "bytes": byts,
-                    "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    for B in batches:
+        for Lq, dh in ((4096, 40), (1024, 80), (256, 160), (64, 160)):
+            C = 8 * dh
+            q = torch.randn(B, Lq, C, device=device).bfloat16()
+            k = torch.randn(B, 77, C, device=device).bfloat16()
+            v = torch.randn_like(k)
+            o = torch.empty_like(q)
+            ms = time_kernel(lambda: H.xattn(q, k, v, 8, out=o), 100)
+            byts = 2.0 * (B * Lq * C * 2) + 2.0 * (B * 77 * C * 2)
+            out.append({"B": B, "Lq": Lq, "dh": dh, "avg_us": round(ms * 1e3, 2), "bytes": byts,
+                        "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1),
+                        "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     return {"kernel": "k_xattn", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shapes": out,
-            "note": "batch-2 launches move 1.4-10.7 MB each: launch/latency-bound, not bandwidth-bound"}
-
-
-def time_kernel(fn, iters: int):
-    """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
-    back-to-back launches (the library enqueues on torch's current stream)."""
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+            "note": "B = 2 launches move 1.4-10.7 MB each (launch/latency-bound); the batched rows are the ones "
+                    "the generation leg issues"}
 
 
 def main() -> None:
@@ -341,7 +331,7 @@ def main() -> None:
     if gen is not None:
         result["generate"] = gen
     if rank == 0 and args.gen_images > 0:
-        result["xattn"] = xattn_leg(device)
+        result["xattn"] = xattn_leg(device, (2, 2 * max(1, min(args.gen_batch, args.gen_images))))
     if rank == 0:
         _log("gpu part: " + json.dumps(result))
         if not args.no_cpu_baseline and world == 1:

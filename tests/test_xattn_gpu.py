@@ -39,6 +39,8 @@ def test_xattn_golden(H, name):
     (2, 8, 1024, 77, 80, torch.bfloat16),
     (2, 8, 256, 77, 160, torch.bfloat16),
     (2, 8, 64, 77, 160, torch.bfloat16),
+    (16, 8, 4096, 77, 40, torch.bfloat16),    # the batch the generation loop issues: 4 query tiles per workgroup
+    (40, 8, 1000, 77, 40, torch.bfloat16),    # 2 tiles per workgroup, ragged last tile
     (1, 5, 100, 77, 64, torch.bfloat16),      # ragged Lq (not a multiple of 128 or 32)
     (3, 2, 33, 1, 40, torch.bfloat16),        # a single key: softmax == 1, O == V
     (1, 4, 200, 128, 128, torch.bfloat16),    # 4 key tiles

@@ -2,14 +2,19 @@
 // (reference: diffusers AttnProcessor2_0 -> F.scaled_dot_product_attention(q, k, v), reached from
 // evalscripts/generate-images-sd.py:37-42; SD-1.4 shapes: Lk = 77, dh in {40, 80, 160}).
 //
-// One workgroup = 4 waves = 128 query rows of one (batch, head); K_h and V_h^T (<= 128 keys) are
-// staged once in LDS.  Each wave owns 32 query rows:
+// One workgroup = 4 waves of one (batch, head); K_h and V_h^T (<= 128 keys) are staged once in LDS and
+// the workgroup then walks `iters` consecutive 128-row query tiles (so the staging and its latency are
+// paid once per 128*iters rows, and the next tile's Q fragments are in flight while the current tile
+// is computed: at large batch this is a streaming kernel).  Each wave owns 32 query rows of a tile:
 //   S^T = K Q^T   "swapped" so a lane's accumulator column is ONE query row: softmax over the
 //                 keys is in-register plus a single exchange with lane^32;
-//   O   = P V     P fragments come straight out of the S^T accumulators (the contraction order over
-//                 keys is permuted identically on the V side), V^T fragments are 8-byte LDS reads.
+//   O^T = V^T P^T P fragments come straight out of the S^T accumulators (the contraction order over
+//                 keys is permuted identically on the V side), V^T fragments are 8-byte LDS reads; the
+//                 output column is again the lane's query row: 1/sum, the bf16 conversion
+//                 (v_cvt_pk_bf16_f32) and the 8-byte stores of 4 consecutive dims are all per lane.
 // bf16/f16 MFMA 32x32x16, f32 softmax and accumulation, no online rescaling (all keys resident).
-// HBM-bound: Q is read once, O written once (through LDS so global stores are 16 B per lane).
+// Q is read once, O written once; at SD-1.4's dh = 40 the per-row VALU work of the softmax (96 padded
+// keys) is of the same order as the memory time, so the instruction count per row matters as much.
 #include "uce_common.h"
 
 namespace {
@@ -29,17 +34,18 @@ __device__ __forceinline__ float16_t mfma32(uint4_t a, uint4_t b, float16_t c) {
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// two f32 -> one packed pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 / v_cvt_pkrtz is NOT used)
 template <bool F16>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  if constexpr (F16) {
-    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-  } else {
-    unsigned ul = __float_as_uint(lo), uh = __float_as_uint(hi);
-    ul = (ul + 0x7fffu + ((ul >> 16) & 1u)) >> 16;   // RNE (inputs are finite)
-    uh = (uh + 0x7fffu + ((uh >> 16) & 1u)) >> 16;
-    return ul | (uh << 16);
-  }
+  const float2_t v = {lo, hi};
+  if constexpr (F16)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  else
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 // DHP: head dim padded to a multiple of 16; KT: key tiles of 32 (3 -> up to 96 keys, 4 -> 128)
@@ -48,39 +54,37 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
                                                const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ V,
                                                unsigned short* __restrict__ O, int H, int Lq, int Lk,
-                                               int dh, float scale_log2e) {
+                                               int dh, float scale_log2e, int iters) {
   constexpr int NDV = (DHP + 31) / 32;      // output column tiles
   constexpr int DVP = NDV * 32;
   constexpr int LKP = KT * 32;
   constexpr int KLD = DHP + 8;              // K_lds row stride (elements): odd multiple of 16 B
   constexpr int VLD = LKP + 4;              // Vt row stride (elements)
-  constexpr int OLD = DHP + 8;              // O staging row stride
   constexpr int NS = DHP / 16;              // contraction steps of S^T = K Q^T
   constexpr int KV_BYTES = (LKP * KLD + DVP * VLD) * 2;
-  constexpr int O_BYTES = 4 * 32 * OLD * 2;
-  constexpr int SMEM = KV_BYTES > O_BYTES ? KV_BYTES : O_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KV_BYTES];
   unsigned short* Ks = (unsigned short*)smem;                 // [LKP][KLD]
   unsigned short* Vt = Ks + LKP * KLD;                        // [DVP][VLD]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = H * dh;
-  const long q0 = (long)blockIdx.x * 128 + w * 32;
   const int lq = lane & 31, lh = lane >> 5;
+  const long tile0 = (long)blockIdx.x * iters;
 
-  // ---- this lane's Q fragments (row q0 + lq, dims 16s + 8*lh .. +7), straight from HBM
-  uint4_t qf[NS];
-  {
-    long row = q0 + lq;
+  // this lane's Q fragments of tile t (row q0 + lq, dims 16s + 8*lh .. +7), straight from HBM
+  auto load_q = [&](long t, uint4_t (&f)[NS]) {
+    long row = t * 128 + w * 32 + lq;
     if (row > Lq - 1) row = Lq - 1;
     const unsigned short* qrow = Q + ((size_t)b * Lq + row) * C + (size_t)h * dh;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int dim = 16 * s + 8 * lh;
-      qf[s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
+      f[s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
     }
-  }
+  };
+  uint4_t qf[NS];
+  load_q(tile0, qf);
 
   // ---- stage K_h (zero padded) and V_h^T
   {
@@ -107,6 +111,9 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
   }
   __syncthreads();
 
+  for (int it = 0; it < iters; ++it) {
+  const long q0 = (tile0 + it) * 128 + w * 32;
+  if ((tile0 + it) * 128 >= Lq) break;                         // workgroup-uniform
   // ---- S^T = K Q^T : accumulator column = query lq, register r of tile kt = key kt*32 + (r&3) + 8*(r>>2) + 4*lh
   float16_t sacc[KT];
 #pragma unroll
@@ -120,46 +127,55 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
     }
   }
 
-  // ---- softmax over keys (f32), masked beyond Lk
+  if (it + 1 < iters) load_q(tile0 + it + 1, qf);              // next tile's Q: in flight under softmax / PV / store
+
+  // ---- softmax over keys (f32): a key tile is masked only if it holds padding (scalar test per tile)
   float m = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
+  for (int kt = 0; kt < KT; ++kt) {
+    if ((kt + 1) * 32 > Lk) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float sv = (key < Lk) ? sacc[kt][r] : -INFINITY;
-      sacc[kt][r] = sv;
-      m = fmaxf(m, sv);
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sacc[kt][r] = (key < Lk) ? sacc[kt][r] : -INFINITY;
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
+  }
   m = fmaxf(m, __shfl_xor(m, 32));
+  const float mc = m * scale_log2e;
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = exp2f((sacc[kt][r] - m) * scale_log2e);
+      const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, -mc));   // in [0, 1]; exp2(-inf) = 0
       sacc[kt][r] = p;
       sum += p;
     }
   sum += __shfl_xor(sum, 32);
   const float inv = 1.0f / sum;
 
-  // ---- P fragments: slot e of step s of tile kt <- register 8s + e
+  // ---- P fragments (unnormalised, in [0, 1]): slot e of step s of tile kt <- register 8s + e
   uint4_t pf[KT][2];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        pf[kt][s][t] = pack2<F16>(sacc[kt][8 * s + 2 * t] * inv, sacc[kt][8 * s + 2 * t + 1] * inv);
+      for (int t = 0; t < 4; ++t) pf[kt][s][t] = pack2<F16>(sacc[kt][8 * s + 2 * t], sacc[kt][8 * s + 2 * t + 1]);
 
-  // ---- O = P V : B operand slot e <-> key kt*32 + 16s + 4*lh + (e&3) + 8*(e>>2)
-  float16_t oacc[NDV];
+  // ---- O^T = V^T P^T : swapped again, so the accumulator column stays this lane's query row and the 1/sum
+  // and the output conversion are per lane; slot e <-> key kt*32 + 16s + 4*lh + (e&3) + 8*(e>>2) on both sides.
+  // Register r of tile nt = output dim nt*32 + (r&3) + 8*(r>>2) + 4*lh: four consecutive dims = one 8-byte store.
+  const long row = q0 + lq;
+  unsigned short* orow = O + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
 #pragma unroll
   for (int nt = 0; nt < NDV; ++nt) {
+    float16_t oacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
     const unsigned short* vrow = Vt + (nt * 32 + lq) * VLD + 4 * lh;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -168,52 +184,40 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
         const uint2_t lo = *(const uint2_t*)(vrow + kt * 32 + 16 * s);
         const uint2_t hi = *(const uint2_t*)(vrow + kt * 32 + 16 * s + 8);
         const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
-        oacc[nt] = mfma32<F16>(pf[kt][s], vf, oacc[nt]);
+        oacc = mfma32<F16>(vf, pf[kt][s], oacc);
       }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dv = nt * 32 + 8 * g + 4 * lh;
+      if (dv < dh && row < Lq) {
+        const uint2_t o2 = {pack2<F16>(oacc[4 * g] * inv, oacc[4 * g + 1] * inv),
+                            pack2<F16>(oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv)};
+        *(uint2_t*)(orow + dv) = o2;
+      }
+    }
   }
-
-  // ---- O tile -> LDS (reusing the K/V region) -> 16-byte global stores
-  __syncthreads();
-  unsigned short* Os = (unsigned short*)smem + w * 32 * OLD;   // [32][OLD] per wave
-#pragma unroll
-  for (int nt = 0; nt < NDV; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int dv = nt * 32 + lq;
-      if (dv < DHP) {
-        float x = oacc[nt][r];
-        unsigned short hv;
-        if constexpr (F16) { const _Float16 t = (_Float16)x; hv = __builtin_bit_cast(unsigned short, t); }
-        else { unsigned u = __float_as_uint(x); hv = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
-        Os[qr * OLD + dv] = hv;
-      }
-    }
-  __syncthreads();
-  {
-    const int chunks = dh >> 3;  // 16-byte chunks per output row
-    for (int e = lane; e < 32 * chunks; e += 64) {
-      const int qr = e / chunks, ch = e - qr * chunks;
-      const long row = q0 + qr;
-      if (row < Lq) {
-        const uint4_t val = *(const uint4_t*)(Os + qr * OLD + ch * 8);
-        *(uint4_t*)(O + ((size_t)b * Lq + row) * C + (size_t)h * dh + ch * 8) = val;
-      }
-    }
   }
 }
 
 template <int DHP, int KT>
 int launch_cfg(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
                float scale, int dtype, hipStream_t st) {
-  const dim3 grid((Lq + 127) / 128, H, B);
+  // query tiles per workgroup: amortise the K/V staging once there are more than ~4 workgroups per CU
+  const long tiles_q = (Lq + 127) / 128;
+  const long total = tiles_q * H * B;
+  int iters = (int)(total / 1024);
+  iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+  if (iters > tiles_q) iters = (int)tiles_q;
+  const dim3 grid((unsigned)((tiles_q + iters - 1) / iters), H, B);
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_xattn<DHP, KT, true>), grid, dim3(256), 0, st, (const unsigned short*)q,
-                       (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, H, Lq, Lk, dh, sl2);
+                       (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, H, Lq, Lk, dh, sl2,
+                       iters);
   else
     hipLaunchKernelGGL((k_xattn<DHP, KT, false>), grid, dim3(256), 0, st, (const unsigned short*)q,
-                       (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, H, Lq, Lk, dh, sl2);
+                       (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, H, Lq, Lk, dh, sl2,
+                       iters);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
