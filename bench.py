@@ -192,6 +192,20 @@ def xattn_leg(device, batches=(2, 16)):
                     "the generation leg issues"}
 
 
+def time_kernel(fn, iters: int):
+    """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
+    back-to-back launches (the library enqueues on torch's current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,9 +214,9 @@ def main() -> None:
     ap.add_argument("--workload", default="sd14_erase50", choices=sorted(WORKLOADS))
     ap.add_argument("--algo", default="auto", choices=["auto", "primal", "dual"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gen-images", type=int, default=16,
+    ap.add_argument("--gen-images", type=int, default=32,
                     help="images per rank for the secondary images/s figure (0 = skip)")
-    ap.add_argument("--gen-batch", type=int, default=8, help="prompts denoised per U-Net call")
+    ap.add_argument("--gen-batch", type=int, default=16, help="prompts denoised per U-Net call")
     ap.add_argument("--gen-steps", type=int, default=50)
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()

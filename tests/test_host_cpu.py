@@ -10,6 +10,7 @@ import torch
 from oracle import uce_oracle as O
 from tests import fakepipe
 from tests.golden_io import Case
+from uce_amd import REPO_ROOT
 from uce_amd import edit as E
 
 
@@ -136,3 +137,23 @@ def test_batched_embedding_extraction_matches_per_string_path():
     assert list(one) == list(bat) and len(one) == 5
     for k in one:
         assert torch.allclose(one[k], bat[k], atol=1e-5, rtol=1e-5), k
+
+
+def test_bench_module_is_self_consistent():
+    """bench.py imports on a CPU box and every helper its main() calls exists (the GPU legs only run on the GPU box)."""
+    import ast
+    import importlib.util
+    path = os.path.join(REPO_ROOT, "bench.py")
+    spec = importlib.util.spec_from_file_location("bench_under_test", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tree = ast.parse(open(path).read())
+    called = {n.func.id for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)}
+    local = {n.name for f in ast.walk(tree) if isinstance(f, ast.FunctionDef) for n in ast.walk(f)
+             if isinstance(n, ast.FunctionDef) and n is not f}                       # nested closures
+    local |= {a.arg for f in ast.walk(tree) if isinstance(f, (ast.FunctionDef, ast.Lambda)) for a in f.args.args}
+    local |= {t.id for n in ast.walk(tree) if isinstance(n, ast.Assign) for t in n.targets if isinstance(t, ast.Name)}
+    import builtins
+    missing = [c for c in called if not hasattr(mod, c) and not hasattr(builtins, c) and c not in local]
+    assert not missing, missing
+    assert "sd14_erase50" in mod.WORKLOADS and mod.WORKLOADS["sd14_erase50"][0] == 50
