@@ -146,22 +146,37 @@ def generation_leg(device, world, n_images, steps, edited_slab, inp, batch=8):
                     generator=gens if count > 1 else gens[0])
 
     chunks = [(lo, min(batch, n_images - lo)) for lo in range(0, n_images, batch)]
-    for count in sorted({c for _, c in chunks}):                  # warm-up: solver search, hipGraph capture
-        run(0, count, 2)
+    # A rank that fails must still reach every collective (the others would wait for it until the RCCL
+    # time-out): errors are recorded, the barriers are always passed, and the flag is reduced at the end.
+    failure = None
+    try:
+        for count in sorted({c for _, c in chunks}):              # warm-up: solver search, hipGraph capture
+            run(0, count, 2)
+    except Exception as err:  # noqa: BLE001
+        failure = f"warm-up: {err!r}"
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for lo, count in chunks:
-        run(lo, count, steps)                                     # -> PIL images on the host, as pipe(...).images
+    if failure is None:
+        try:
+            for lo, count in chunks:
+                run(lo, count, steps)                             # -> PIL images on the host, as pipe(...).images
+        except Exception as err:  # noqa: BLE001
+            failure = f"timed loop: {err!r}"
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
+        t = torch.tensor([el, 0.0 if failure is None else 1.0], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+        el = float(t[0].item())
+        if failure is None and t[1].item() > 0:
+            failure = "another rank failed"
+    if failure is not None:
+        _log("generation leg failed: " + failure)
+        return {"metric": "images/sec 512x512 50-step", "value": None, "error": failure, "n_gpus": world}
     return {"metric": "images/sec 512x512 50-step", "value": round(world * n_images / el, 4), "unit": "images/s",
             "n_gpus": world, "images_per_rank": n_images, "prompts_per_unet_call": batch, "steps": steps, "dtype": "bf16",
             "scaling": "weak",
@@ -352,6 +367,7 @@ def main() -> None:
             result["cpu_baseline"] = cpu_baseline(inp, args.cpu_budget)
         print(json.dumps(result), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

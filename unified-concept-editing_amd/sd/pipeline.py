@@ -224,7 +224,9 @@ class _GraphedStep:
                 body()
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: other threads of the process (the RCCL watchdog of a multi-GPU run
+        # polls events) must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.eps = body()
 
     def _bind(self):
@@ -342,9 +344,16 @@ class StableDiffusionPipeline:
             key = (n, hh, ww, cfg, float(guidance_scale), tuple(ctx.shape), self.dtype)
             graphed = self._graphs.get(key)
             if graphed is None:
-                graphed = self._graphs[key] = _GraphedStep(self, n, hh, ww, cfg, float(guidance_scale), ctx)
-            graphed.set_context(ctx)
-        elif self.hoist_context:
+                try:
+                    graphed = self._graphs[key] = _GraphedStep(self, n, hh, ww, cfg, float(guidance_scale), ctx)
+                except RuntimeError as err:               # capture refused: same kernels, eager launches
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the denoising step failed ({err}); launching eagerly")
+                    self.use_graph = False
+                    torch.cuda.synchronize(self.device)
+            if graphed is not None:
+                graphed.set_context(ctx)
+        if graphed is None and self.hoist_context:
             self.unet.cache_context(ctx)
         try:
             for t in sch.timesteps.tolist():
