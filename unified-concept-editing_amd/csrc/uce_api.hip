@@ -8,11 +8,12 @@
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 static void free_ws(uce_ctx* h) {
-  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->DeltaT, h->Dm, h->R};  // (T is separate)
+  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->DeltaT, h->DeltaP, h->Dm, h->R};  // (T is separate)
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->M = h->Lmat = h->Linv = h->slabs = h->Bt = h->Yg = nullptr;
   h->DeltaT = h->Dm = h->R = nullptr;
+  h->DeltaP = nullptr;
   h->slabs_bytes = 0;
   h->d_cap = h->n_cap = 0;
 }
@@ -54,6 +55,7 @@ int uce_ensure(uce_ctx* h, int d, int n) {
   alloc((void**)&h->Bt, dd * sizeof(double));
   alloc((void**)&h->Yg, nc > 1024 ? (size_t)nc * dc * sizeof(double) : 16);
   alloc((void**)&h->DeltaT, dd * sizeof(float));
+  alloc((void**)&h->DeltaP, 3 * dd * sizeof(unsigned short));
   alloc((void**)&h->Dm, (size_t)nc * dc * sizeof(float));
   alloc((void**)&h->R, (size_t)nc * dc * sizeof(float));
   if (e != hipSuccess) {
@@ -177,7 +179,13 @@ int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_
               uce_stream_t stream) {
   if (!h || !W_old || !DeltaT || !W_new || rows < 0 || d <= 0 || d % 64 || W_old == W_new) return UCE_EINVAL;
   if (rows == 0) return UCE_OK;
-  return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
+  // default: bf16 matrix cores with a three-way split of both operands (fp32-equivalent products, 2.7x the
+  // f32-MFMA rate); UCE_APPLY_VARIANT=0 selects the exact-f32 MFMA kernel
+  static const int variant = getenv("UCE_APPLY_VARIANT") ? atoi(getenv("UCE_APPLY_VARIANT")) : 1;
+  if (variant == 0) return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
+  const int rc = uce_ensure(h, d, 64);
+  if (rc) return rc;
+  return launch_apply_b3(W_old, DeltaT, h->DeltaP, W_new, rows, d, (hipStream_t)stream);
 }
 
 int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,

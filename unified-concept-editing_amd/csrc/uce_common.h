@@ -38,6 +38,7 @@ struct uce_ctx {
   double* Bt;     // [d_cap, d_cap] right-hand side of the primal solve
   double* Yg;     // [n_cap, d_cap] global scratch for the triangular solves when n > 1024
   float* DeltaT;  // [d_cap, d_cap]
+  unsigned short* DeltaP;  // [3][d_cap, d_cap] bf16 planes of Delta^T (uce_apply_b3.hip)
   float* Dm;      // [n_cap, d_cap]
   float* R;       // [n_cap, d_cap]
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
@@ -64,6 +65,8 @@ int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st);
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
                     float* out, int out_rows, hipStream_t st);
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
+int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* planes, float* W_new, long rows, int d,
+                    hipStream_t st);
 int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, float* W_new, long rows,
                          int d, int N_edit, hipStream_t st);
 bool apply_lowrank_fits(int d, int N_edit);
