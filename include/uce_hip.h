@@ -73,7 +73,10 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
 
 /* a5 - apply (replaces `mat1 @ inverse` of uce_sd_erase.py:82 for ALL modules in one launch):
  *   W_new [rows,d] = W_old + W_old Delta ; rows = sum of the modules' out_features (the host
- *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  fp32 MFMA, exact f32 products. */
+ *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  Products carry fp32 accuracy: both operands
+ *   are split exactly into three bf16 terms and the six significant partial products run on the bf16 matrix
+ *   cores with fp32 accumulation (error <= one fp32 rounding per product; UCE_APPLY_VARIANT=0 selects the
+ *   f32-MFMA kernel whose products are bit-exact fmaf chains). */
 int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,
               uce_stream_t stream);
 

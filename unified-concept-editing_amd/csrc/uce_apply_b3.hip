@@ -147,14 +147,19 @@ __global__ __launch_bounds__(256, 2) void k_apply_b3(const float* __restrict__ W
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) g_load(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // all twelve fragments are requested up front, in the order the terms consume them
     uint4_t fa[2][3], fb[2][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    auto rd_a = [&](int p) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) fa[mt][p] = *(const uint4_t*)(a_plane(cur, p) + (wm + mt * 32 + fr) * PLD + fk);
+    };
+    auto rd_b = [&](int p) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) fb[nt][p] = *(const uint4_t*)(b_plane(cur, p) + (wn + nt * 32 + fr) * PLD + fk);
-    }
+    };
+    rd_a(2); rd_b(0); rd_a(0); rd_b(2); rd_a(1); rd_b(1);
+    __builtin_amdgcn_sched_barrier(0);
     // six partial products per tile, small terms first; the four tiles are interleaved so that consecutive
     // MFMAs never depend on each other
 #pragma unroll
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_b3(const float* __restrict__ W
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(fa[mt][PA[term]], fb[nt][PB[term]], acc[mt][nt]);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) s_store(cur ^ 1);
     __syncthreads();
   }
