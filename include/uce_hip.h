@@ -132,6 +132,13 @@ int uce_cast_bf16(uce_handle_t h, const float* src, void* dst_bf16, long n, uce_
 int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H,
                   int Lq, int Lk, int dh, float scale, int dtype, uce_stream_t stream);
 
+/* SURVEY section 8(f) row 3 - the U-Net's SELF-attention (attn1) at inference, same call site and layout as
+ * uce_xattn_fwd but any Lk (flash-style streaming over key tiles, online softmax):
+ *   q,o: [B, Lq, H*dh]   k,v: [B, Lk, H*dh],  dh a multiple of 8, <= 160, B*H <= 65535, bf16 or f16 I/O.
+ * Uses a V^T scratch in the handle (grown on demand: the first call at a larger shape allocates). */
+int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H,
+                  int Lq, int Lk, int dh, float scale, int dtype, uce_stream_t stream);
+
 /* e - broadcast of the edited blob over RCCL/xGMI.  `comm` is an ncclComm_t.  librccl is
  * dlopen()ed on first use; returns UCE_ENOSYS when it cannot be loaded. */
 int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream);

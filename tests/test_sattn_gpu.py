@@ -1,0 +1,102 @@
+"""GPU parity of the self-attention (flash-style, any Lk) kernel through the C ABI against an fp64 evaluation
+of softmax(Q K^T / sqrt(dh)) V (the oracle's xattn_ref: the arithmetic F.scaled_dot_product_attention performs
+inside diffusers' AttnProcessor2_0 for attn1)."""
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# bf16 output rounding (2^-9 relative per element) dominates; P is rounded to bf16 before P.V
+TOL_BF16 = 8e-3
+TOL_F16 = 1.5e-3
+
+
+@pytest.fixture(scope="module")
+def H():
+    from uce_amd import edit as E
+    return E.UceHandle.get("cuda:0")
+
+
+def _ref_gpu(q, k, v, heads, scale=None):
+    """fp64 attention on the GPU (the CPU oracle is too slow at Lq = Lk = 4096); checked against the oracle below."""
+    B, Lq, C = q.shape
+    dh = C // heads
+    sp = lambda t: t.double().view(B, t.shape[1], heads, dh).transpose(1, 2)
+    s = sp(q) @ sp(k).transpose(-1, -2) * (dh ** -0.5 if scale is None else scale)
+    return (torch.softmax(s, dim=-1) @ sp(v)).transpose(1, 2).reshape(B, Lq, C)
+
+
+@pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
+    (2, 8, 4096, 4096, 40, torch.bfloat16),     # SD-1.4 attn1 shapes (B = 2: one prompt's CFG pair)
+    (2, 8, 1024, 1024, 80, torch.bfloat16),
+    (2, 8, 256, 256, 160, torch.bfloat16),
+    (2, 8, 64, 64, 160, torch.bfloat16),
+    (16, 8, 1024, 1024, 40, torch.bfloat16),    # batched prompts
+    (1, 5, 100, 77, 64, torch.bfloat16),        # ragged Lq and Lk (neither a multiple of the tile sizes)
+    (3, 2, 33, 1, 40, torch.bfloat16),          # a single key: softmax == 1, O == V
+    (1, 4, 200, 130, 128, torch.bfloat16),      # three key tiles, the last one nearly empty
+    (2, 10, 130, 97, 64, torch.float16),        # f16 path
+    (1, 2, 70, 191, 16, torch.bfloat16),        # the tiny test U-Net's head dim
+    (1, 3, 50, 65, 96, torch.float16),
+])
+def test_sattn_shapes(H, B, H_, Lq, Lk, dh, dtype):
+    g = torch.Generator().manual_seed(Lq * 7 + dh + Lk)
+    C = H_ * dh
+    q = torch.randn(B, Lq, C, generator=g).to(dtype)
+    k = torch.randn(B, Lk, C, generator=g).to(dtype)
+    v = torch.randn(B, Lk, C, generator=g).to(dtype)
+    o = H.sattn(q.cuda(), k.cuda(), v.cuda(), H_)
+    ref = _ref_gpu(q.cuda(), k.cuda(), v.cuda(), H_)
+    assert torch.isfinite(o.float()).all()
+    assert O.rel_fro(o.double().cpu(), ref.cpu()) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
+    if Lk == 1:
+        assert torch.equal(o.cpu(), v.expand(B, Lq, C).contiguous())
+    if Lq * Lk <= 256 * 256:                     # small enough for the CPU oracle: pins the GPU reference too
+        assert O.rel_fro(ref.cpu(), O.xattn_ref(q, k, v, H_)) < 1e-12
+
+
+def test_sattn_peaked_logits_and_running_max(H):
+    """Keys ordered so that the running maximum keeps rising across the key tiles (every tile rescales the
+    accumulators), with large logits and a custom scale."""
+    g = torch.Generator().manual_seed(11)
+    B, H_, Lq, Lk, dh = 1, 4, 128, 640, 40
+    C = H_ * dh
+    q = (torch.randn(B, Lq, C, generator=g).abs() * 3).to(torch.bfloat16)
+    ramp = torch.linspace(0.1, 3.0, Lk)[None, :, None]
+    k = (torch.randn(B, Lk, C, generator=g).abs() * ramp).to(torch.bfloat16)
+    v = torch.randn(B, Lk, C, generator=g).to(torch.bfloat16)
+    o = H.sattn(q.cuda(), k.cuda(), v.cuda(), H_, scale=0.5)
+    ref = _ref_gpu(q.cuda(), k.cuda(), v.cuda(), H_, scale=0.5)
+    assert torch.isfinite(o.float()).all()
+    assert O.rel_fro(o.double().cpu(), ref.cpu()) < TOL_BF16
+
+
+def test_sattn_matches_xattn_on_short_contexts(H):
+    """Same problem through both kernels (Lk = 77 fits the cross-attention kernel)."""
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(2, 300, 320, generator=g).bfloat16().cuda()
+    k = torch.randn(2, 77, 320, generator=g).bfloat16().cuda()
+    v = torch.randn(2, 77, 320, generator=g).bfloat16().cuda()
+    a, b = H.sattn(q, k, v, 8), H.xattn(q, k, v, 8)
+    assert O.rel_fro(a.double().cpu(), b.double().cpu()) < 4e-3
+
+
+def test_sattn_scratch_growth_keeps_old_buffers_valid(H):
+    """The V^T scratch grows on demand; a smaller call after a larger one (and vice versa) stays correct."""
+    g = torch.Generator().manual_seed(9)
+    for B, L in ((1, 64), (4, 512), (1, 64), (8, 1024)):
+        q = torch.randn(B, L, 320, generator=g).bfloat16().cuda()
+        o = H.sattn(q, q, q, 8)
+        assert O.rel_fro(o.double().cpu(), _ref_gpu(q, q, q, 8).cpu()) < TOL_BF16
+
+
+def test_sattn_rejects_bad_arguments(H):
+    from uce_amd import lib as L
+    q = torch.zeros(1, 8, 8 * 36, dtype=torch.bfloat16, device="cuda:0")      # dh = 36 is not a multiple of 8
+    with pytest.raises(L.UceError):
+        H.sattn(q, q, q, 8)
+    q = torch.zeros(1, 8, 8 * 168, dtype=torch.bfloat16, device="cuda:0")     # dh > 160
+    with pytest.raises(L.UceError):
+        H.sattn(q, q, q, 8)

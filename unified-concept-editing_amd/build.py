@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libuce_hip.so")
-SOURCES = ["uce_gram.hip", "uce_solve.hip", "uce_apply.hip", "uce_apply_b3.hip", "uce_lowrank2.hip", "uce_xattn.hip", "uce_api.hip"]
+SOURCES = ["uce_gram.hip", "uce_solve.hip", "uce_apply.hip", "uce_apply_b3.hip", "uce_lowrank2.hip", "uce_xattn.hip", "uce_sattn.hip", "uce_api.hip"]
 HEADERS = ["uce_common.h", os.path.join("..", "..", "include", "uce_hip.h")]
 
 
@@ -37,8 +37,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950 reads/writes them there directly).  Left to
+    # its heuristics the compiler parks them in AGPRs and pays a v_accvgpr_read/write pair around every VALU
+    # touch of an accumulator - 128 extra moves per key tile in the attention kernels' softmax.
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+           "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print("[uce_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

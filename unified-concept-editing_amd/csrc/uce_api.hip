@@ -81,9 +81,26 @@ int uce_ensure_T(uce_ctx* h, long rows, int N_edit) {
   return UCE_OK;
 }
 
+int uce_ensure_Vt(uce_ctx* h, size_t elems) {
+  if (elems <= h->Vt_elems) return UCE_OK;
+  UCE_HIP_TRY(hipSetDevice(h->device));
+  // grow geometrically; the old buffer is retired, not freed: a captured hipGraph may still launch with it
+  size_t want = h->Vt_elems ? h->Vt_elems : (size_t)1 << 20;
+  while (want < elems) want *= 2;
+  void* p = nullptr;
+  if (hipMalloc(&p, want * sizeof(unsigned short)) != hipSuccess) return UCE_ENOMEM;
+  if (h->Vt) {
+    if (h->n_retired < 32) h->retired[h->n_retired++] = h->Vt;
+    else { UCE_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(h->Vt); }
+  }
+  h->Vt = p;
+  h->Vt_elems = want;
+  return UCE_OK;
+}
+
 extern "C" {
 
-int uce_version(void) { return 101; }
+int uce_version(void) { return 102; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -124,6 +141,8 @@ int uce_destroy(uce_handle_t h) {
   free_ws(h);
   if (h->status) (void)hipFree(h->status);
   if (h->T) (void)hipFree(h->T);
+  if (h->Vt) (void)hipFree(h->Vt);
+  for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
   if (h->ticket) (void)hipFree(h->ticket);
   delete h;
   return UCE_OK;

@@ -45,6 +45,10 @@ struct uce_ctx {
   unsigned* ticket;  // arrival counter of the rider blocks (zero between launches)
   float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply
   size_t T_elems;
+  void* Vt;       // V^T scratch of uce_sattn_fwd ([B, H, DVP, LkP] 16-bit elements)
+  size_t Vt_elems;
+  void* retired[32];   // outgrown Vt buffers: kept alive until uce_destroy (captured hipGraphs may still name them)
+  int n_retired;
 };
 
 // ---- internal launchers (defined across the .hip files) -------------------------------------
@@ -81,6 +85,10 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
 int uce_ensure_T(uce_ctx* h, long rows, int N_edit);
+int uce_ensure_Vt(uce_ctx* h, size_t elems);
+size_t sattn_vt_elems(int B, int H, int Lk, int dh);
+int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
+                 float scale, int dtype, hipStream_t st);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
                  int dh, float scale, int dtype, hipStream_t st);
 

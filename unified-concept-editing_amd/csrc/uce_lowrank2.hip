@@ -441,123 +441,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 }
 
 // ---------------------------------------------------------------------------------------------
-// update, N_edit <= 64 (<= 16 k-steps): ALL R fragments of a column group sit in registers, the set
-// for group g+1 is fetched during group g and - this is the point - is issued BEFORE the prefetch of
-// group g+1's W rows.  vmcnt retires in order on gfx950, so a wait on any load issued after a big HBM
-// prefetch also waits for that prefetch: with the ring-buffered variant below every group stalled
-// at its 4th k-step until the next group's 64 KB of W had landed, and MFMA time simply added to
-// memory time (41 us = 25 + 16 at N_edit = 50).  Here the MFMA loop of a group waits for nothing.
-// ---------------------------------------------------------------------------------------------
-template <int D, int UP_MT, int WPE, int NK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_update_r16(
-    const float* __restrict__ W_old, const float* __restrict__ T, const float* __restrict__ R,
-    float* __restrict__ W_new, long rows, int Ne, int NEP) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int d = D;
-  constexpr int SR = UP_MT * 16;
-  const int tld = NEP + 2;
-  float* Ts = (float*)smem_raw;                       // [SR][tld]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const long R0 = (long)blockIdx.x * SR;
-  constexpr int MG = D / 256;                         // column groups per wave (3 / 4 / 8)
-
-  // 32-bit per-lane offsets off wave-uniform bases (SGPR base + VGPR offset addressing): one VGPR per
-  // stream instead of a 64-bit pointer per load
-  const float* Wb = W_old + R0 * d;                   // workgroup-uniform
-  const int rows_left = (int)((rows - R0) < SR ? (rows - R0) : SR);
-  unsigned roff[NK];
-#pragma unroll
-  for (int t = 0; t < NK; ++t) {
-    const int e = 4 * t + lk;
-    roff[t] = (unsigned)((e < Ne ? e : Ne - 1) * d + w * 64 + 4 * li);
-  }
-  unsigned woff[UP_MT][4];
-#pragma unroll
-  for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = m * 16 + 4 * lk + r;
-      woff[m][r] = (unsigned)((lr < rows_left ? lr : rows_left - 1) * d + w * 64 + 4 * li);
-    }
-
-  float4_t rr[2][NK];
-  float4_t res[UP_MT][4];
-#pragma unroll
-  for (int t = 0; t < NK; ++t) rr[0][t] = *(const float4_t*)(R + roff[t]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) res[m][r] = *(const float4_t*)(Wb + woff[m][r]);
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    const int f4_row = NEP >> 2;
-    for (int e = tid; e < SR * f4_row; e += 256) {
-      const int r = e / f4_row, c = (e - r * f4_row) << 2;
-      long gr = R0 + r;
-      gr = gr < rows ? gr : rows - 1;
-      const float4_t v = *(const float4_t*)(T + gr * NEP + c);
-      Ts[r * tld + c] = v[0];
-      Ts[r * tld + c + 1] = v[1];
-      Ts[r * tld + c + 2] = v[2];
-      Ts[r * tld + c + 3] = v[3];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int gi = 0; gi < MG; ++gi) {
-    float4_t acc[UP_MT][4];                           // acc[m][q][r]: row m*16 + 4*lk + r, column 4*li + q
-#pragma unroll
-    for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[m][q][r] = res[m][r][q];
-    if (gi + 1 < MG) {
-      // next group's R fragments FIRST (older than the W prefetch: their waits never include it)
-#pragma unroll
-      for (int t = 0; t < NK; ++t) rr[(gi + 1) & 1][t] = *(const float4_t*)(R + roff[t] + (gi + 1) * 256);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) res[m][r] = *(const float4_t*)(Wb + woff[m][r] + (gi + 1) * 256);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < NK; ++t) {
-      const int e = 4 * t + lk;
-      float a[UP_MT];                                 // T fragments: LDS (lgkmcnt, independent of vmcnt)
-#pragma unroll
-      for (int m = 0; m < UP_MT; ++m) a[m] = (e < Ne) ? Ts[(m * 16 + li) * tld + e] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int m = 0; m < UP_MT; ++m)
-          acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], rr[gi & 1][t][q], acc[m][q], 0, 0, 0);
-    }
-#pragma unroll
-    for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long gr = R0 + m * 16 + 4 * lk + r;
-        if (gr < rows) {
-          const float4_t o = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-          __builtin_nontemporal_store(o, (float4_t*)(W_new + gr * d + (w + 4 * gi) * 64 + 4 * li));
-        }
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // update, single-buffered R, buffer addressing.
 //  * The register holding k-step t's R fragment is reloaded IN PLACE with the next column group's
 //    fragment right after the MFMAs of step t have consumed it.  Program order of the vector-memory
 //    stream per group g is   W prefetch(g+1) | R(g+1)[0..NK-1] (between the MFMA steps) | stores(g),
 //    so the wait for R(g+1)[t] at step t of group g+1 covers only loads issued a whole MFMA loop
 //    earlier: the in-order vmcnt never makes a step wait for a load issued during the current group.
-//    Half the registers of the double-buffered r16 form.
+//    Half the registers of a double-buffered fragment set (the predecessor of this kernel: 34.6 us vs 30 us).
 //  * Every stream is a buffer load/store: ONE 32-bit lane offset for all of them, the per-step /
 //    per-row / per-group displacement folded into the (scalar) resource base, and the resource's
 //    num_records doing the bounds work: concept rows >= N_edit read as 0 and weight rows >= rows are
@@ -735,24 +625,6 @@ int launch_update_v(const float* W_old, const float* T, const float* R, float* W
 }
 
 template <int D, int UP_MT, int WPE>
-int launch_update_r16(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
-                      int NEP64, hipStream_t st) {
-  const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
-  const dim3 grid((unsigned)((rows + UP_MT * 16 - 1) / (UP_MT * 16))), block(256);
-  const int nks = (N_edit + 3) / 4;
-  if (nks <= 4)
-    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 4>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
-  else if (nks <= 8)
-    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 8>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
-  else if (nks <= 13)
-    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 13>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
-  else
-    hipLaunchKernelGGL((k_lr_update_r16<D, UP_MT, WPE, 16>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
-  UCE_LAUNCH_CHECK();
-  return UCE_OK;
-}
-
-template <int D, int UP_MT, int WPE>
 int launch_update_s(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
                     int NEP64, hipStream_t st) {
   const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
@@ -783,35 +655,10 @@ int launch_update_d(const float* W_old, const float* T, const float* R, float* W
       case 20:   // default (measured best at N_edit 16..128 on MI355X, tools/sweep_update.sh)
         return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
       case 21: return launch_update_s<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 22: return launch_update_s<D, 3, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 23: return launch_update_s<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 24: return launch_update_s<D, 2, 1>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 25: return launch_update_s<D, 2, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 26: return launch_update_s<D, 1, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 27: return launch_update_s<D, 1, 4>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
       default: break;
     }
   }
-  if (N_edit <= 64) {
-    switch (variant) {
-      case 10:   // default: the widest tile whose register-resident R set does not spill
-        if (N_edit <= 32) return launch_update_r16<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-        return launch_update_r16<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 15: return launch_update_r16<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 11: return launch_update_r16<D, 2, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 12: return launch_update_r16<D, 1, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 13: return launch_update_r16<D, 3, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 14: return launch_update_r16<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      default: break;
-    }
-  }
-  switch (variant) {
-    case 1: return launch_update_v<D, 2, 3>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-    case 2: return launch_update_v<D, 2, 4>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-    case 3: return launch_update_v<D, 1, 4>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-    case 4: return launch_update_v<D, 3, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-    default: return launch_update_v<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-  }
+  return launch_update_v<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);   // 129 <= N_edit <= 256: ring-buffered form
 }
 
 }  // namespace

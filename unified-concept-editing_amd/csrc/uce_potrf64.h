@@ -237,6 +237,12 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
     }
 }
 
+// (A four-pivots-per-barrier variant was tried and is SLOWER on MI355X - ~20 us vs ~14 us for the 64x64 factor +
+// inverse: the step time is set by the f64 VALU instruction count (f64 FMA issues at half rate on gfx950, ~8
+// cycles per wave instruction), not by the barrier / LDS / reciprocal latencies, and the rank-4 form needs ~170
+// f64 operations per thread per step (4x4 block inverse, W = C Q, update) against ~50 per pair step.  A faster
+// factor has to move the rank-k update onto v_mfma_f64_16x16x4_f64 with the accumulators in D layout.)
+
 // 512-thread version of potrf_first_body (waves 0-3: matrix tiles, waves 4-7: tiles of L^-1)
 static __device__ __forceinline__ void potrf_first_body8(const double* __restrict__ M, int n, int nsplit,
                                                          size_t slab_stride, double* __restrict__ Lmat,
@@ -427,7 +433,7 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
   if (half == 0)
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
   __syncthreads();
-  Potrf64Scratch* sc = (Potrf64Scratch*)&Mi[0][0];   // P_i / P_k regions (66 KB) are dead now
+  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;    // all three tile regions are dead once tt is in registers
   const int t256 = tid & 255;
   const int ti = t256 >> 4, tj = t256 & 15;
   double tt[4][4];

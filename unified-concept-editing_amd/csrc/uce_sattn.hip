@@ -1,0 +1,320 @@
+// Self-attention forward (no mask) for the U-Net's attn1 layers at inference: O = softmax(Q K^T * scale) V per
+// (batch, head), any Lk (SD-1.4: Lq = Lk in {4096, 1024, 256, 64}, dh in {40, 80, 160}).  This is "the rest of
+// the U-Net step" of SURVEY.md section 8(f) row 3 - diffusers' AttnProcessor2_0 -> F.scaled_dot_product_attention
+// for attn1, reached from evalscripts/generate-images-sd.py:37-42 - built as the streaming sibling of k_xattn.
+//
+//   k_vt        V [B, Lk, H*dh] -> V^T [B, H, DVP, LkP] (16-bit elements, zero padded): the P V product needs the
+//               key index contiguous per lane on the V side; one extra pass over V (a few % of the attention).
+//   k_sattn     one workgroup = 4 waves = 128 query rows of one (b, h); keys in tiles of 64, K tile and V^T tile
+//               double-buffered in LDS (straight 16-byte copies, register prefetch of the next tile).
+//               Per wave 32 query rows:  S^T = K Q^T "swapped", so a lane's accumulator column is ONE query:
+//               the running max / sum of the online softmax, the rescale of the output accumulators and the
+//               final 1/sum are all per lane (one lane^32 exchange per tile for the max, none for the sum);
+//               O^T = V^T P^T with the P fragments straight out of the S^T accumulators (k_xattn's key
+//               permutation).  bf16/f16 MFMA 32x32x16, f32 softmax and accumulation.
+// The loop is VALU-bound on the softmax (32 exp2 per lane per 64 keys at quarter rate), not MFMA-bound.
+#include "uce_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+
+template <bool F16>
+__device__ __forceinline__ float16_t mfma32(uint4_t a, uint4_t b, float16_t c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0,
+                                                  0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                   0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const float2_t v = {lo, hi};
+  if constexpr (F16)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  else
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+constexpr int KT = 64;            // keys per tile
+
+// V [B, Lk, C] -> Vt [B, H, DVP, LkP]; 64 keys x 64 dims per workgroup through LDS
+__global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V, unsigned short* __restrict__ Vt, int H,
+                                            int Lk, int dh, int DVP, int LkP) {
+  __shared__ unsigned short tile[64][66];
+  const int b = blockIdx.z / H, h = blockIdx.z % H;
+  const int k0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+  const int C = H * dh;
+  const int tid = threadIdx.x;
+  {
+    const int dv = tid & 63, kk = tid >> 6;          // coalesced along the head dims
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int key = k0 + kk + 4 * p;
+      unsigned short v = 0;
+      if (key < Lk && d0 + dv < dh) v = V[((size_t)b * Lk + key) * C + (size_t)h * dh + d0 + dv];
+      tile[kk + 4 * p][dv] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int key = tid & 63, dd = tid >> 6;         // coalesced along the keys
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int dv = d0 + dd + 4 * p;
+      if (dv < DVP) Vt[(((size_t)b * H + h) * DVP + dv) * LkP + k0 + key] = tile[key][dd + 4 * p];
+    }
+  }
+}
+
+// DHP: head dim padded to a multiple of 16
+template <int DHP, bool F16>
+__global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
+                                               const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
+                                               int H, int Lq, int Lk, int LkP, int dh, float scale_log2e) {
+  constexpr int NDV = (DHP + 31) / 32;      // output row tiles (of O^T)
+  constexpr int DVP = NDV * 32;
+  constexpr int KLD = DHP + 8;              // K tile row stride (elements): odd multiple of 16 B
+  constexpr int VLD = KT + 4;               // V^T tile row stride (elements)
+  constexpr int NS = DHP / 16;              // contraction steps of S^T = K Q^T
+  constexpr int KCH = DHP / 8;              // 16-byte chunks per key row
+  constexpr int NKL = (KT * KCH + 255) / 256;     // K chunks per thread per tile
+  constexpr int VCH = KT / 8;               // 16-byte chunks per V^T row (8)
+  constexpr int NVL = (DVP * VCH + 255) / 256;    // V^T chunks per thread per tile
+  constexpr int BUF = KT * KLD + DVP * VLD;       // elements per buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // 2 buffers of BUF elements
+  unsigned short* smem = (unsigned short*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * dh;
+  const int lq = lane & 31, lh = lane >> 5;
+  const long q0 = (long)blockIdx.x * 128 + w * 32;
+  const long row = q0 + lq;
+
+  // ---- this lane's Q fragments (row q0 + lq, dims 16s + 8*lh .. +7)
+  uint4_t qf[NS];
+  {
+    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int dim = 16 * s + 8 * lh;
+      qf[s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
+    }
+  }
+
+  const unsigned short* kbase = K + (size_t)b * Lk * C + (size_t)h * dh;
+  const unsigned short* vbase = Vt + ((size_t)b * H + h) * DVP * LkP;
+  uint4_t rk[NKL], rv[NVL];
+  auto g_load = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int e = tid + 256 * i;
+      const int key = e / KCH, dim = (e - key * KCH) * 8;
+      rk[i] = (uint4_t){0u, 0u, 0u, 0u};
+      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * C + dim);
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int e = tid + 256 * i;
+      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+      if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+    }
+  };
+  auto s_store = [&](int buf) {
+    unsigned short* Ks = smem + buf * BUF;
+    unsigned short* Vs = Ks + KT * KLD;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int e = tid + 256 * i;
+      const int key = e / KCH, dim = (e - key * KCH) * 8;
+      if (e < KT * KCH) *(uint4_t*)(Ks + key * KLD + dim) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int e = tid + 256 * i;
+      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+      if (e < DVP * VCH) {
+        // VLD * 2 bytes is a multiple of 8 but not of 16: two 8-byte stores
+        *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
+        *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+      }
+    }
+  };
+
+  float m = -INFINITY, lsum = 0.f;          // running max (shared by lane and lane^32), this lane's partial sum
+  float16_t oacc[NDV];
+#pragma unroll
+  for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.f;
+
+  const int ntiles = (Lk + KT - 1) / KT;
+  g_load(0);
+  s_store(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const unsigned short* Ks = smem + cur * BUF;
+    const unsigned short* Vs = Ks + KT * KLD;
+    if (t + 1 < ntiles) g_load(t + 1);
+
+    // ---- S^T = K Q^T for the 64 keys: register r of sub-tile j = key 32j + (r&3) + 8*(r>>2) + 4*lh
+    float16_t sacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint4_t kf = *(const uint4_t*)(Ks + (j * 32 + lq) * KLD + 16 * s + 8 * lh);
+        sacc[j] = mfma32<F16>(kf, qf[s], sacc[j]);
+      }
+    }
+    if ((t + 1) * KT > Lk) {                 // the last tile may hold padding keys
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          sacc[j][r] = (key < Lk) ? sacc[j][r] : -INFINITY;
+        }
+    }
+    // ---- online softmax
+    float mt = sacc[0][0];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[j][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m, mt);                              // finite: every tile holds at least one real key
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first tile
+    const float mc = m_new * scale_log2e;
+    m = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale_log2e, -mc));
+        sacc[j][r] = p;
+        ps += p;
+      }
+    lsum = fmaf(lsum, alpha, ps);
+    if (__any(alpha != 1.0f)) {               // the max rarely moves after the first tiles: skip the rescale
+#pragma unroll
+      for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[nt][r] *= alpha;
+    }
+    // ---- P fragments (unnormalised): slot e of step s2 of sub-tile j <- register 8*s2 + e
+    uint4_t pf[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pf[j][s2][q] = pack2<F16>(sacc[j][8 * s2 + 2 * q], sacc[j][8 * s2 + 2 * q + 1]);
+    // ---- O^T += V^T P^T : slot e <-> key 32j + 16*s2 + 4*lh + (e&3) + 8*(e>>2) on both sides
+#pragma unroll
+    for (int nt = 0; nt < NDV; ++nt) {
+      const unsigned short* vrow = Vs + (nt * 32 + lq) * VLD + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint2_t lo = *(const uint2_t*)(vrow + j * 32 + 16 * s2);
+          const uint2_t hi = *(const uint2_t*)(vrow + j * 32 + 16 * s2 + 8);
+          const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
+          oacc[nt] = mfma32<F16>(vf, pf[j][s2], oacc[nt]);
+        }
+    }
+    if (t + 1 < ntiles) s_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- 1/sum, convert, store: register r of tile nt = output dim nt*32 + (r&3) + 8*(r>>2) + 4*lh
+  const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
+  unsigned short* orow = O + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+#pragma unroll
+  for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dv = nt * 32 + 8 * g + 4 * lh;
+      if (dv < dh && row < Lq) {
+        const uint2_t o2 = {pack2<F16>(oacc[nt][4 * g] * inv, oacc[nt][4 * g + 1] * inv),
+                            pack2<F16>(oacc[nt][4 * g + 2] * inv, oacc[nt][4 * g + 3] * inv)};
+        *(uint2_t*)(orow + dv) = o2;
+      }
+    }
+}
+
+template <int DHP>
+int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
+               float scale, int dtype, hipStream_t st) {
+  const dim3 grid((Lq + 127) / 128, H, B);
+  const float sl2 = scale * 1.4426950408889634f;
+  constexpr int NDV = (DHP + 31) / 32;
+  const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL((k_sattn<DHP, true>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+  else
+    hipLaunchKernelGGL((k_sattn<DHP, false>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+}  // namespace
+
+int sattn_dvp(int dh) {
+  const int dhp = dh <= 48 ? 48 : dh <= 64 ? 64 : dh <= 80 ? 80 : dh <= 96 ? 96 : dh <= 128 ? 128 : 160;
+  return (dhp + 31) / 32 * 32;
+}
+
+size_t sattn_vt_elems(int B, int H, int Lk, int dh) {
+  return (size_t)B * H * sattn_dvp(dh) * ((Lk + KT - 1) / KT * KT);
+}
+
+int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
+                 float scale, int dtype, hipStream_t st) {
+  const int LkP = (Lk + KT - 1) / KT * KT;
+  const int DVP = sattn_dvp(dh);
+  hipLaunchKernelGGL(k_vt, dim3(LkP / 64, (DVP + 63) / 64, B * H), dim3(256), 0, st, (const unsigned short*)v,
+                     (unsigned short*)vt, H, Lk, dh, DVP, LkP);
+  UCE_LAUNCH_CHECK();
+  if (dh <= 48) return launch_cfg<48>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 64) return launch_cfg<64>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 80) return launch_cfg<80>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 96) return launch_cfg<96>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 128) return launch_cfg<128>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  return launch_cfg<160>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+}
+
+extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
+                             int Lk, int dh, float scale, int dtype, uce_stream_t stream) {
+  if (!h || !q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return UCE_EINVAL;
+  if (dh <= 0 || dh > 160 || (dh & 7)) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  if (B > 65535 || H > 65535 || (long)B * H > 65535) return UCE_EINVAL;
+  const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, Lk, dh));
+  if (rc) return rc;
+  return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream);
+}

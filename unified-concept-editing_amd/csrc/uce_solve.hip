@@ -213,7 +213,7 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
   const int nb = n / 64;
   const size_t smem = 3 * 64 * LD * sizeof(double);
   const size_t smem_first = sizeof(Potrf64Scratch);
-  static_assert(sizeof(Potrf64Scratch) <= 2 * 64 * LD * sizeof(double), "scratch must fit the P_i/P_k regions");
+  static_assert(sizeof(Potrf64Scratch) <= POTRF_STEP_SMEM, "scratch must fit the three tile regions");
   static bool attr_set = false;
   if (!attr_set) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize,

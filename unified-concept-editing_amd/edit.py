@@ -193,6 +193,19 @@ class UceHandle:
                                           float(scale), dt, _stream_ptr(self.device)), "uce_xattn_fwd")
         return out
 
+    def sattn(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Self-attention (any Lk) through uce_sattn_fwd; [B, L, H*dh] in and out."""
+        B, Lq, Cc = q.shape
+        Lk = k.shape[1]
+        dh = Cc // heads
+        scale = dh ** -0.5 if scale is None else scale
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[q.dtype]
+        out = torch.empty_like(q) if out is None else out
+        _lib.check(self.lib.uce_sattn_fwd(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Lq, Lk, dh,
+                                          float(scale), dt, _stream_ptr(self.device)), "uce_sattn_fwd")
+        return out
+
 
 # --------------------------------------------------------------------------------------------
 # module discovery + the weight slab  (uce_sd_erase.py:15-22)

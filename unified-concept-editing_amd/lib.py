@@ -35,6 +35,7 @@ SIGNATURES = {
     "uce_debias_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "uce_cast_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
     "uce_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "uce_sattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "uce_bcast": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
 }
 

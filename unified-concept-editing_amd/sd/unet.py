@@ -114,12 +114,21 @@ class Attention(nn.Module):
         return self.to_out[0](o)
 
 
+USE_HIP_SELF_ATTENTION = True     # attn1 through uce_sattn_fwd on a GPU in bf16/f16 (False: torch SDPA)
+
+
 def _attention_core(q, k, v, heads: int, is_cross: bool):
-    """[B, L, C] in / out.  Cross-attention on a GPU in bf16/f16 -> the HIP kernel; otherwise SDPA."""
-    if is_cross and q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.shape[1] <= 128 \
-            and (q.shape[2] // heads) % 8 == 0 and q.shape[2] // heads <= 160:
+    """[B, L, C] in / out.  On a GPU in bf16/f16: cross-attention -> uce_xattn_fwd, self-attention -> uce_sattn_fwd;
+    otherwise torch SDPA."""
+    dh = q.shape[2] // heads
+    if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and dh % 8 == 0 and dh <= 160 \
+            and q.shape[0] * heads <= 65535:
         from .. import edit as _edit
-        return _edit.UceHandle.get(q.device).xattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+        handle = _edit.UceHandle.get(q.device)
+        if is_cross and k.shape[1] <= 128:
+            return handle.xattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+        if USE_HIP_SELF_ATTENTION:
+            return handle.sattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
     B, Lq, C = q.shape
     dh = C // heads
 
