@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak
+BF16_MFMA_PEAK_TF = 2500.0    # dense bf16 MFMA peak (no sparsity)
 
 WORKLOADS = {
     # name: (N_edit, N_preserve, d, module table)
@@ -207,6 +208,28 @@ def xattn_leg(device, batches=(2, 16)):
                     "the generation leg issues"}
 
 
+def sattn_leg(device, B):
+    """Self-attention kernel (attn1 of the U-Net, uce_sattn_fwd) at SD-1.4's four shapes and the generation batch,
+    beside torch's scaled_dot_product_attention on the same tensors; 4*B*H*L^2*dh flop per call vs the dense bf16
+    MFMA peak (the loop is VALU-bound on the online softmax, not MFMA-bound)."""
+    import torch.nn.functional as F
+    from uce_amd import edit as E
+    H = E.UceHandle.get(device)
+    out = []
+    for L, dh in ((4096, 40), (1024, 80), (256, 160), (64, 160)):
+        C = 8 * dh
+        q = torch.randn(B, L, C, device=device).bfloat16()
+        k, v = torch.randn_like(q), torch.randn_like(q)
+        o = torch.empty_like(q)
+        ms = time_kernel(lambda: H.sattn(q, k, v, 8, out=o), 10)
+        sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)
+        ms_t = time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), 10)
+        fl = 4.0 * B * 8 * L * L * dh
+        out.append({"B": B, "L": L, "dh": dh, "avg_us": round(ms * 1e3, 1), "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
+                    "frac": round(fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4), "torch_sdpa_us": round(ms_t * 1e3, 1)})
+    return {"kernel": "k_sattn (+ k_vt)", "bound": "mfma", "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "shapes": out}
+
+
 def time_kernel(fn, iters: int):
     """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
     back-to-back launches (the library enqueues on torch's current stream)."""
@@ -360,7 +383,9 @@ def main() -> None:
     if gen is not None:
         result["generate"] = gen
     if rank == 0 and args.gen_images > 0:
-        result["xattn"] = xattn_leg(device, (2, 2 * max(1, min(args.gen_batch, args.gen_images))))
+        gb = 2 * max(1, min(args.gen_batch, args.gen_images))
+        result["xattn"] = xattn_leg(device, (2, gb))
+        result["sattn"] = sattn_leg(device, gb)
     if rank == 0:
         _log("gpu part: " + json.dumps(result))
         if not args.no_cpu_baseline and world == 1:

@@ -139,6 +139,15 @@ int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, v
 int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H,
                   int Lq, int Lk, int dh, float scale, int dtype, uce_stream_t stream);
 
+/* SURVEY section 8(f) row 3 - GroupNorm (+ SiLU) of the U-Net / VAE at inference (diffusers ResnetBlock2D:
+ * conv(silu(group_norm(x)))) for channels-last activations:  x, y [N, HW, C] (an NCHW tensor in
+ * torch.channels_last memory format), gamma, beta [C], all bf16 or f16; G <= 64 groups of C/G consecutive
+ * channels, C % 8 == 0, C <= 4096; statistics in f32/f64.  ws: N * uce_groupnorm_chunks(HW) * G * 2 floats of
+ * caller-owned scratch. */
+int uce_groupnorm_chunks(int HW);
+int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* gamma, const void* beta, void* y, float* ws,
+                           int N, int HW, int C, int G, float eps, int silu, int dtype, uce_stream_t stream);
+
 /* e - broadcast of the edited blob over RCCL/xGMI.  `comm` is an ncclComm_t.  librccl is
  * dlopen()ed on first use; returns UCE_ENOSYS when it cannot be loaded. */
 int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream);

@@ -1,0 +1,219 @@
+// GroupNorm (+ SiLU) forward for channels-last activations of the U-Net / VAE at inference - SURVEY.md section
+// 8(f) row 3, "the rest of the U-Net step".  diffusers' ResnetBlock2D computes conv(silu(group_norm(x))): torch
+// runs that as three GroupNorm kernels (moments, fused parameters, a STRIDED element-wise apply for NHWC tensors)
+// plus a SiLU pass - five trips over the activation.  Here: two kernels, three trips, all 16-byte coalesced.
+//
+//   x, y : [N, H*W, C] (= NCHW tensors in torch.channels_last memory format), bf16 or f16; gamma, beta : [C], same
+//          dtype; G groups of C/G consecutive channels; statistics and arithmetic in f32 (final reduction in f64).
+//   k_gn_stats : grid (chunks, N).  A workgroup walks its chunk of pixels; thread t owns channel octet(s) t % OC
+//                of pixel rows t / OC + k*RPI, accumulates per-channel sum / sum of squares in registers, the
+//                workgroup folds them per group through LDS -> partial[n][chunk][g] = (sum, sumsq).
+//   k_gn_apply : grid (chunks, N).  Folds the partials of its n (fixed order: bit-repeatable) into mean / rstd,
+//                builds per-channel scale and shift, streams its chunk:  y = silu?(x * a_c + b_c).
+#include "uce_common.h"
+
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
+template <bool F16>
+__device__ __forceinline__ void unpack8(const uint4_t v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (F16) {
+      const unsigned u = v[i];
+      f[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+    } else {
+      f[2 * i] = __uint_as_float(v[i] << 16);
+      f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const float2_t v = {lo, hi};
+  if constexpr (F16)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  else
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+constexpr int MAXO = 2;     // channel octets per thread: C <= 8 * 256 * MAXO = 4096
+
+struct GnMap {
+  int OC, RPI, NO, active;  // octets per pixel, pixel rows per iteration, octets per thread, active threads
+};
+__host__ __device__ inline GnMap gn_map(int C) {
+  GnMap m;
+  m.OC = C / 8;
+  m.NO = (m.OC + 255) / 256;
+  const int tpr = (m.OC + m.NO - 1) / m.NO;          // threads per pixel row
+  m.RPI = 256 / tpr;
+  m.active = m.RPI * tpr;
+  return m;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, float* __restrict__ partial,
+                                                  int HW, int C, int G, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [RPI][C][2]
+  const GnMap mp = gn_map(C);
+  const int tpr = mp.active / mp.RPI;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, ch = blockIdx.x;
+  const int p0 = (int)((long)HW * ch / chunks), p1 = (int)((long)HW * (ch + 1) / chunks);
+  const int oc0 = tid % tpr, prow = tid / tpr;
+  float s[MAXO][8], q[MAXO][8];
+#pragma unroll
+  for (int j = 0; j < MAXO; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[j][i] = q[j][i] = 0.f;
+  if (tid < mp.active) {
+    const unsigned short* base = x + (size_t)n * HW * C;
+    for (int p = p0 + prow; p < p1; p += mp.RPI) {
+#pragma unroll
+      for (int j = 0; j < MAXO; ++j) {
+        const int oc = oc0 + j * tpr;
+        if (j < mp.NO && oc < mp.OC) {
+          float f[8];
+          unpack8<F16>(*(const uint4_t*)(base + (size_t)p * C + oc * 8), f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            s[j][i] += f[i];
+            q[j][i] = fmaf(f[i], f[i], q[j][i]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) {
+      const int oc = oc0 + j * tpr;
+      if (j < mp.NO && oc < mp.OC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[((size_t)prow * C + oc * 8 + i) * 2] = s[j][i];
+          red[((size_t)prow * C + oc * 8 + i) * 2 + 1] = q[j][i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // one thread per group: fixed summation order (pixel rows outer, channels inner)
+  if (tid < G) {
+    const int cpg = C / G;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < mp.RPI; ++r)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+        a += (double)red[((size_t)r * C + c) * 2];
+        b += (double)red[((size_t)r * C + c) * 2 + 1];
+      }
+    float* out = partial + (((size_t)n * chunks + ch) * G + tid) * 2;
+    out[0] = (float)a;
+    out[1] = (float)b;
+  }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ gamma,
+                                                  const unsigned short* __restrict__ beta, const float* __restrict__ partial,
+                                                  unsigned short* __restrict__ y, int HW, int C, int G, int chunks,
+                                                  float eps, int silu) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const GnMap mp = gn_map(C);
+  const int tpr = mp.active / mp.RPI;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, ch = blockIdx.x;
+  const int cpg = C / G;
+  if (tid < G) {
+    double a = 0.0, b = 0.0;
+    for (int c = 0; c < chunks; ++c) {                 // fixed order
+      const float* p = partial + (((size_t)n * chunks + c) * G + tid) * 2;
+      a += (double)p[0];
+      b += (double)p[1];
+    }
+    const double cnt = (double)HW * cpg;
+    const double mu = a / cnt;
+    double var = b / cnt - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean_s[tid] = (float)mu;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (tid >= mp.active) return;
+  const int p0 = (int)((long)HW * ch / chunks), p1 = (int)((long)HW * (ch + 1) / chunks);
+  const int oc0 = tid % tpr, prow = tid / tpr;
+  float sa[MAXO][8], sb[MAXO][8];
+#pragma unroll
+  for (int j = 0; j < MAXO; ++j) {
+    const int oc = oc0 + j * tpr;
+    if (j < mp.NO && oc < mp.OC) {
+      float g8[8], b8[8];
+      unpack8<F16>(*(const uint4_t*)(gamma + oc * 8), g8);
+      unpack8<F16>(*(const uint4_t*)(beta + oc * 8), b8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int grp = (oc * 8 + i) / cpg;
+        sa[j][i] = g8[i] * rstd_s[grp];
+        sb[j][i] = fmaf(-mean_s[grp], sa[j][i], b8[i]);
+      }
+    }
+  }
+  const unsigned short* xb = x + (size_t)n * HW * C;
+  unsigned short* yb = y + (size_t)n * HW * C;
+  for (int p = p0 + prow; p < p1; p += mp.RPI) {
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) {
+      const int oc = oc0 + j * tpr;
+      if (j < mp.NO && oc < mp.OC) {
+        float f[8];
+        unpack8<F16>(*(const uint4_t*)(xb + (size_t)p * C + oc * 8), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v = fmaf(f[i], sa[j][i], sb[j][i]);
+          if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          f[i] = v;
+        }
+        const uint4_t o = {pack2<F16>(f[0], f[1]), pack2<F16>(f[2], f[3]), pack2<F16>(f[4], f[5]), pack2<F16>(f[6], f[7])};
+        *(uint4_t*)(yb + (size_t)p * C + oc * 8) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int uce_groupnorm_chunks(int HW) {
+  int c = HW / 16;                       // >= 16 pixels per workgroup; small feature maps still fill the chip
+  return c < 1 ? 1 : (c > 64 ? 64 : c);
+}
+
+// ws: N * uce_groupnorm_chunks(HW) * G * 2 floats, owned by the caller
+extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* gamma, const void* beta, void* y,
+                                      float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
+                                      uce_stream_t stream) {
+  if (!h || !x || !gamma || !beta || !y || !ws || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64) return UCE_EINVAL;
+  if (C % 8 || C % G || C > 8 * 256 * MAXO || N > 65535) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  const int chunks = uce_groupnorm_chunks(HW);
+  const GnMap mp = gn_map(C);
+  const size_t smem = (size_t)mp.RPI * C * 2 * sizeof(float);
+  if (smem > 64 * 1024) return UCE_EINVAL;
+  const dim3 grid(chunks, N), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UCE_DTYPE_F16) {
+    hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, ws, HW, C, G, chunks);
+    hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)gamma,
+                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu);
+  } else {
+    hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, ws, HW, C, G, chunks);
+    hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)gamma,
+                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu);
+  }
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}

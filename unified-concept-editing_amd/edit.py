@@ -206,6 +206,19 @@ class UceHandle:
                                           float(scale), dt, _stream_ptr(self.device)), "uce_sattn_fwd")
         return out
 
+    def groupnorm_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float,
+                       silu: bool) -> torch.Tensor:
+        """GroupNorm (+ SiLU) of a channels-last [N, C, H, W] tensor through uce_groupnorm_nhwc_fwd."""
+        N, Cc, Hh, Ww = x.shape
+        hw = Hh * Ww
+        y = torch.empty_like(x)                                    # keeps the channels_last strides
+        ws = torch.empty(N * self.lib.uce_groupnorm_chunks(hw) * groups * 2, dtype=torch.float32, device=x.device)
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        _lib.check(self.lib.uce_groupnorm_nhwc_fwd(self._h, _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(ws), N, hw,
+                                                   Cc, groups, float(eps), int(silu), dt, _stream_ptr(self.device)),
+                   "uce_groupnorm_nhwc_fwd")
+        return y
+
 
 # --------------------------------------------------------------------------------------------
 # module discovery + the weight slab  (uce_sd_erase.py:15-22)

@@ -29,7 +29,7 @@ from .scheduler import PNDMScheduler
 # ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
 # batch 2 (48 ms average over 384 calls in profiles/r01), far more at larger batches.  It never wins.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
-from .unet import UNet2DConditionModel, UNetConfig
+from .unet import UNet2DConditionModel, UNetConfig, group_norm_act
 
 MAX_LEN = 77
 BOS, EOS = 49406, 49407
@@ -98,7 +98,7 @@ class _VaeResnet(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x):
-        h = self.conv2(F.silu(self.norm2(self.conv1(F.silu(self.norm1(x))))))
+        h = self.conv2(group_norm_act(self.norm2, self.conv1(group_norm_act(self.norm1, x, True)), True))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 
@@ -165,7 +165,7 @@ class _Decoder(nn.Module):
         x = self.mid_block(self.conv_in(z))
         for u in self.up_blocks:
             x = u(x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(group_norm_act(self.conv_norm_out, x, True))
 
 
 class VaeDecoder(nn.Module):
