@@ -148,6 +148,10 @@ int uce_groupnorm_chunks(int HW);
 int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* gamma, const void* beta, void* y, float* ws,
                            int N, int HW, int C, int G, float eps, int silu, int dtype, uce_stream_t stream);
 
+/* GEGLU of the transformer feed-forward (diffusers GEGLU, exact erf GELU): x [rows, 2*inner] -> y [rows, inner] =
+ * x[:, :inner] * gelu(x[:, inner:]), bf16 or f16, inner % 8 == 0. */
+int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, int inner, int dtype, uce_stream_t stream);
+
 /* e - broadcast of the edited blob over RCCL/xGMI.  `comm` is an ncclComm_t.  librccl is
  * dlopen()ed on first use; returns UCE_ENOSYS when it cannot be loaded. */
 int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream);

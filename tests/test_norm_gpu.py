@@ -85,3 +85,15 @@ def test_unet_uses_the_kernel_and_matches_torch_groupnorm():
     finally:
         U.USE_HIP_GROUPNORM = True
     assert O.rel_fro(a.cpu(), b.cpu()) < 3e-2
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 4096, 2560), torch.bfloat16), ((3, 77, 512), torch.float16),
+                                         ((1, 5, 16), torch.bfloat16), ((32, 1024, 5120), torch.bfloat16)])
+def test_geglu(H, shape, dtype):
+    g = torch.Generator().manual_seed(shape[-1])
+    x = (torch.randn(*shape, generator=g) * 2).to(dtype).cuda()
+    y = H.geglu(x)
+    h, gate = x.double().chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    assert y.shape == ref.shape
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < (4e-3 if dtype == torch.bfloat16 else 6e-4)

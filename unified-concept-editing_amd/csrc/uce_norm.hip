@@ -217,3 +217,44 @@ extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void*
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
+
+// -------------------------------------------------------------------------------------------------------------
+// GEGLU of the transformer feed-forward (diffusers GEGLU: hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate),
+// exact erf form): torch runs a strided gelu and a strided multiply on the two halves; here one pass.
+//   x [rows, 2*inner] -> y [rows, inner], 16-bit, inner % 8 == 0
+// -------------------------------------------------------------------------------------------------------------
+namespace {
+template <bool F16>
+__global__ __launch_bounds__(256) void k_geglu(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                               long rows, int inner) {
+  const int oct = inner / 8;
+  const long total = rows * oct;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / oct;
+    const int c = (int)(e - r * oct) * 8;
+    float hv[8], gv[8];
+    unpack8<F16>(*(const uint4_t*)(x + r * 2 * inner + c), hv);
+    unpack8<F16>(*(const uint4_t*)(x + r * 2 * inner + inner + c), gv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hv[i] *= 0.5f * gv[i] * (1.0f + erff(gv[i] * 0.70710678118654752f));
+    const uint4_t o = {pack2<F16>(hv[0], hv[1]), pack2<F16>(hv[2], hv[3]), pack2<F16>(hv[4], hv[5]), pack2<F16>(hv[6], hv[7])};
+    *(uint4_t*)(y + r * inner + c) = o;
+  }
+}
+}  // namespace
+
+extern "C" int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, int inner, int dtype, uce_stream_t stream) {
+  if (!h || !x || !y || rows <= 0 || inner <= 0 || inner % 8) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  const long total = rows * (inner / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL(k_geglu<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       (unsigned short*)y, rows, inner);
+  else
+    hipLaunchKernelGGL(k_geglu<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       (unsigned short*)y, rows, inner);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}

@@ -219,6 +219,16 @@ class UceHandle:
                    "uce_groupnorm_nhwc_fwd")
         return y
 
+    def geglu(self, x: torch.Tensor) -> torch.Tensor:
+        """x [..., 2*inner] -> x[..., :inner] * gelu(x[..., inner:]) through uce_geglu_fwd."""
+        inner = x.shape[-1] // 2
+        rows = x.numel() // x.shape[-1]
+        y = torch.empty(*x.shape[:-1], inner, dtype=x.dtype, device=x.device)
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        _lib.check(self.lib.uce_geglu_fwd(self._h, _ptr(x), _ptr(y), rows, inner, dt, _stream_ptr(self.device)),
+                   "uce_geglu_fwd")
+        return y
+
 
 # --------------------------------------------------------------------------------------------
 # module discovery + the weight slab  (uce_sd_erase.py:15-22)

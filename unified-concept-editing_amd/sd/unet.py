@@ -161,7 +161,12 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim, inner * 2)
 
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
+        p = self.proj(x)
+        if USE_HIP_GROUPNORM and p.is_cuda and p.dtype in (torch.bfloat16, torch.float16) and p.is_contiguous() \
+                and (p.shape[-1] // 2) % 8 == 0:
+            from .. import edit as _edit
+            return _edit.UceHandle.get(p.device).geglu(p)          # one pass instead of a strided gelu + multiply
+        h, gate = p.chunk(2, dim=-1)
         return h * F.gelu(gate)
 
 
