@@ -159,6 +159,46 @@ def uce_edit_exact64(
 
 
 # --------------------------------------------------------------------------------------
+# FLUX variant (uce_flux_edit.py:71-113): the edited nn.Linear modules HAVE a bias, so the guide
+# outputs are v* = W g + b and W_new = W + W Delta + b u^T with u = A^-1 sum_i s_i c_i (the bias
+# itself is not edited).  One embedding family per module (T5 last token for context_embedder,
+# pooled CLIP for time_text_embed.text_embedder.linear_1).
+# --------------------------------------------------------------------------------------
+
+def uce_edit_bias_ref(w_old: torch.Tensor, bias: torch.Tensor, edit: Sequence[torch.Tensor],
+                      guide: Sequence[torch.Tensor], preserve: Sequence[torch.Tensor], erase_scale: float,
+                      preserve_scale: float, lamb: float, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """One module in the reference's op order (uce_flux_edit.py:86-113)."""
+    w_old, bias = w_old.to(dtype), bias.to(dtype)
+    d = w_old.shape[1]
+    lin = lambda t: torch.nn.functional.linear(t.to(dtype), w_old, bias)      # module(t_emb), :81
+    mat1 = lamb * w_old
+    mat2 = lamb * torch.eye(d, dtype=dtype)
+    for c, g in zip(edit, guide):
+        c_i, v = c.to(dtype).T, lin(g).T
+        mat1 += erase_scale * (v @ c_i.T)
+        mat2 += erase_scale * (c_i @ c_i.T)
+    for p_ in preserve:
+        c_i, v = p_.to(dtype).T, lin(p_).T
+        mat1 += preserve_scale * (v @ c_i.T)
+        mat2 += preserve_scale * (c_i @ c_i.T)
+    return mat1 @ torch.inverse(mat2.float()).to(dtype)
+
+
+def uce_edit_bias_exact64(w_old: torch.Tensor, bias: torch.Tensor, edit, guide, preserve, erase_scale: float,
+                          preserve_scale: float, lamb: float) -> torch.Tensor:
+    C = torch.cat([e.double() for e in edit] + [p_.double() for p_ in preserve], 0)
+    G = torch.cat([g.double() for g in guide] + [p_.double() for p_ in preserve], 0)
+    s = torch.tensor([erase_scale] * len(edit) + [preserve_scale] * len(preserve), dtype=torch.float64)
+    d = C.shape[1]
+    w, b = w_old.double(), bias.double()
+    A = lamb * torch.eye(d, dtype=torch.float64) + C.T @ (s[:, None] * C)
+    V = G @ w.T + b[None, :]                                   # [N, o] guide outputs incl. bias
+    mat1 = lamb * w + V.T @ (s[:, None] * C)
+    return torch.linalg.solve(A, mat1.T).T
+
+
+# --------------------------------------------------------------------------------------
 # debias  (uce_sd_debias.py:95-141)
 # --------------------------------------------------------------------------------------
 

@@ -133,3 +133,84 @@ def uce_weights(unet: nn.Module) -> List[Tuple[str, torch.Tensor]]:
         if "attn2" in name and (name.endswith("to_v") or name.endswith("to_k")):
             out.append((name, m.weight.detach().clone()))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# FLUX stand-ins (uce_flux_edit.py:12-66): the reference calls DiffusionPipeline.from_pretrained twice -
+# once for the transformer (text encoders = None), once for the text side (transformer = None).
+# ----------------------------------------------------------------------------------------------------
+FLUX_T5_DIM, FLUX_POOL_DIM = 4096, 768
+
+
+def build_flux_transformer(out_rows: int, rng: np.random.Generator) -> nn.Module:
+    """named_modules() yields `context_embedder` (Linear 4096 -> out_rows, bias) and
+    `time_text_embed.text_embedder.linear_1` (Linear 768 -> out_rows, bias) plus decoys the name predicate
+    (uce_flux_edit.py:25) must skip.  out_rows stands in for 3072 (rows are independent)."""
+    root = _Node()
+
+    def linear(o, i):
+        lin = nn.Linear(i, o, bias=True)
+        bound = 1.0 / math.sqrt(i)
+        lin.weight.data = torch.from_numpy(rng.uniform(-bound, bound, size=(o, i)).astype(np.float32))
+        lin.bias.data = torch.from_numpy(rng.uniform(-bound, bound, size=(o,)).astype(np.float32))
+        return lin
+
+    root.add_module("x_embedder", linear(8, 8))
+    root.add_module("context_embedder", linear(out_rows, FLUX_T5_DIM))
+    tte = _Node()
+    te = _Node()
+    te.add_module("linear_1", linear(out_rows, FLUX_POOL_DIM))
+    te.add_module("linear_2", linear(8, 8))
+    tte.add_module("text_embedder", te)
+    tte.add_module("guidance_embedder", _Node())
+    root.add_module("time_text_embed", tte)
+    return root
+
+
+class FakeFluxTransformerPipe:
+    def __init__(self, transformer: nn.Module):
+        self.transformer = transformer
+
+    def to(self, *a, **k):
+        return self
+
+
+class FakeFluxTextPipe:
+    """encode_prompt -> (T5 states [1, L, 4096] with the string's embedding at the reference's last-token index
+    and different vectors elsewhere, pooled CLIP [1, 768], text ids)."""
+
+    def __init__(self):
+        rp = np.random.Generator(np.random.PCG64(78))
+        self._pos = rp.standard_normal(FLUX_T5_DIM).astype(np.float32)
+        self.encode_calls: List[str] = []
+        outer = self
+
+        class _Tok2:
+            def __call__(self, text, padding=None, max_length=None, return_overflowing_tokens=False, truncation=True,
+                         return_length=False, return_tensors=None):
+                n = min(len(text.split()) + 2, max_length)
+                mask = torch.zeros(1, max_length, dtype=torch.long)
+                mask[0, :n] = 1
+                return {"attention_mask": mask, "input_ids": mask.clone()}
+
+        self.tokenizer_2 = _Tok2()
+
+    @staticmethod
+    def t5_embedding(prompt: str) -> np.ndarray:
+        return prompt_embedding("t5:" + prompt, FLUX_T5_DIM, norm=12.0, cosine=0.5)
+
+    @staticmethod
+    def pooled_embedding(prompt: str) -> np.ndarray:
+        return prompt_embedding("pool:" + prompt, FLUX_POOL_DIM, norm=28.0, cosine=0.64)
+
+    def encode_prompt(self, prompt=None, prompt_2=None, device=None, num_images_per_prompt=1, max_sequence_length=512, **kw):
+        self.encode_calls.append(prompt)
+        e = torch.from_numpy(self.t5_embedding(prompt))
+        idx = min(len(prompt.split()) + 2, max_sequence_length) - 2
+        pos = torch.arange(max_sequence_length, dtype=torch.float32) - idx
+        t = e[None, :] + 0.25 * pos[:, None] * torch.from_numpy(self._pos)[None, :]
+        pooled = torch.from_numpy(self.pooled_embedding(prompt))[None]
+        return t[None].contiguous(), pooled, None
+
+    def to(self, *a, **k):
+        return self

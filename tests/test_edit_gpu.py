@@ -359,3 +359,30 @@ def test_rider_path_reports_indefinite_system(H):
     s[70] = 1.0                                                  # and the handle recovers
     out = H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, check=True)
     assert torch.isfinite(out).all()
+
+
+def test_flux_variant_matches_reference_golden(H, tmp_path):
+    """uce_amd.flux.UCE (biased Linear modules, T5 / pooled-CLIP embedding families) on the fakes
+    the golden was generated with, against the reference's uce_flux_edit.py output."""
+    from safetensors.torch import load_file
+    from tests import fakepipe
+    from uce_amd import flux
+    c = Case("flux_n6p3")
+    m = c.meta
+    rng = np.random.Generator(np.random.PCG64(21))
+    tr = fakepipe.build_flux_transformer(24, rng)
+    mods = dict(tr.named_modules())
+    for i, n in enumerate(m["modules"]):
+        assert torch.equal(mods[n].weight.detach(), c.t(f"W_old_{i}")) and torch.equal(mods[n].bias.detach(), c.t(f"b_{i}"))
+    text = fakepipe.FakeFluxTextPipe()
+    state, path = flux.UCE("black-forest-labs/FLUX.1-schnell", m["edit"], m["guide"], m["preserve"], m["erase_scale"],
+                           m["preserve_scale"], m["lamb"], str(tmp_path), "flux", torch.float32, "cuda:0", 256,
+                           load_transformer=lambda: fakepipe.FakeFluxTransformerPipe(tr), load_text=lambda: text)
+    assert text.encode_calls == m["encode_calls"]
+    saved = load_file(path)
+    assert sorted(saved) == sorted(n + ".weight" for n in m["modules"])
+    for i, n in enumerate(m["modules"]):
+        ref, ex = c.t(f"W_ref32_{i}"), c.t(f"W_exact64_{i}")
+        got = saved[n + ".weight"]
+        assert O.rel_fro(got, ex) < EPS_BUILD
+        assert O.rel_fro(got, ref) < max(1e-4, 1.5 * O.rel_fro(ref, ex))

@@ -157,3 +157,22 @@ def test_bench_module_is_self_consistent():
     missing = [c for c in called if not hasattr(mod, c) and not hasattr(builtins, c) and c not in local]
     assert not missing, missing
     assert "sd14_erase50" in mod.WORKLOADS and mod.WORKLOADS["sd14_erase50"][0] == 50
+
+
+def test_flux_module_predicate_embeddings_and_cli():
+    """uce_flux_edit.py:25 name predicate, :44-66 embedding extraction (T5 last token + pooled), :124-171 flags."""
+    from uce_amd import cli, flux
+    rng = np.random.Generator(np.random.PCG64(0))
+    tr = fakepipe.build_flux_transformer(8, rng)
+    names = [n for n, _ in flux.collect_flux_modules(tr)]
+    assert names == ["context_embedder", "time_text_embed.text_embedder.linear_1"]
+    text = fakepipe.FakeFluxTextPipe()
+    emb = flux.flux_embeddings(text, ["Van Gogh", "art", "Van Gogh", ""], "cpu", 256)
+    assert list(emb) == ["Van Gogh", "art", ""] and text.encode_calls == ["Van Gogh", "art", ""]
+    t5, pooled = emb["Van Gogh"]
+    assert t5.shape == (4096,) and pooled.shape == (768,)
+    assert np.allclose(t5.numpy(), text.t5_embedding("Van Gogh")) and np.allclose(pooled.numpy(), text.pooled_embedding("Van Gogh"))
+    a = cli.parse_flux_args(["--edit_concepts", "Van Gogh; Picasso", "--concept_type", "art"])
+    assert a.model_id == "black-forest-labs/FLUX.1-schnell" and cli.flux_max_sequence_length(a.model_id) == 256
+    assert cli.flux_max_sequence_length("black-forest-labs/FLUX.1-dev") == 512
+    assert cli.erase_job_from_args(a).guide_concepts == ["art", "art"]

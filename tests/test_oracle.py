@@ -95,3 +95,31 @@ def test_last_token_index():
     assert O.last_token_index(2) == 0          # '' -> BOS
     assert O.last_token_index(77) == 75        # truncated prompt
     assert O.last_token_index(4) == 2
+
+
+def test_flux_bias_oracle_matches_reference_golden():
+    """uce_flux_edit.py run on the fakes (tools/make_golden.py): the biased-module restatement reproduces the
+    reference's weights, and the fp64 closed form W + W Delta + b u^T agrees to the reference's own fp32 error."""
+    from tests.golden_io import Case
+    c = Case("flux_n6p3")
+    m = c.meta
+    assert m["modules"] == ["context_embedder", "time_text_embed.text_embedder.linear_1"]
+    for i in range(2):
+        te = [r[None] for r in c.t(f"C_edit_{i}")]
+        tg = [r[None] for r in c.t(f"G_edit_{i}")]
+        tp = [r[None] for r in c.t(f"C_pres_{i}")]
+        W, b = c.t(f"W_old_{i}"), c.t(f"b_{i}")
+        ref = O.uce_edit_bias_ref(W, b, te, tg, tp, m["erase_scale"], m["preserve_scale"], m["lamb"])
+        assert O.rel_fro(ref, c.t(f"W_ref32_{i}")) < 2e-6
+        ex = O.uce_edit_bias_exact64(W, b, te, tg, tp, m["erase_scale"], m["preserve_scale"], m["lamb"])
+        assert O.rel_fro(ex, c.t(f"W_exact64_{i}")) < 1e-12
+        # the collapse used by the product path: W + W Delta + b u^T
+        C = torch.cat(te + tp).double()
+        G = torch.cat(tg + tp).double()
+        s = torch.tensor([m["erase_scale"]] * len(te) + [m["preserve_scale"]] * len(tp), dtype=torch.float64)
+        A = m["lamb"] * torch.eye(C.shape[1], dtype=torch.float64) + C.T @ (s[:, None] * C)
+        Ainv = torch.linalg.inv(A)
+        Delta = (G - C).T @ (s[:, None] * C) @ Ainv                    # B A^-1, B = (G - C)^T S C
+        u = Ainv @ (C.T @ s)
+        collapsed = W.double() + W.double() @ Delta + torch.outer(b.double(), u)
+        assert O.rel_fro(collapsed, ex) < 1e-10

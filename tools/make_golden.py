@@ -49,6 +49,9 @@ def _install_diffusers_stub() -> None:
     class DiffusionPipeline:  # noqa: D401 - stand-in
         @staticmethod
         def from_pretrained(model_id, **kw):
+            if _CURRENT_PIPE.get("flux") is not None:      # uce_flux_edit.py loads the model in two halves
+                half = "text" if "transformer" in kw and kw["transformer"] is None else "transformer"
+                return _CURRENT_PIPE["flux"][half]
             return _CURRENT_PIPE["pipe"]
 
     stub.DiffusionPipeline = DiffusionPipeline
@@ -146,6 +149,46 @@ def run_erase_case(erase_mod, case: str, out_dir: str, d: int, edit: List[str], 
         arrays[f"W_ref32_{i}"] = ref.numpy()
         arrays[f"W_exact64_{i}"] = exact[i].numpy()
         print(f"    {n}: eps_ref = relF(ref32, exact64) = {uce_oracle.rel_fro(ref, exact[i]):.3e}")
+    _save(case, out_dir, **arrays)
+
+
+# ---------------------------------------------------------------- FLUX variant (modules with bias)
+
+def run_flux_case(flux_mod, case: str, out_dir: str, out_rows: int, edit: List[str], guide: List[str],
+                  preserve: List[str], erase_scale: float, preserve_scale: float, lamb: float, seed: int) -> None:
+    print(f"[flux] {case}: N_e={len(edit)} N_p={len(preserve)} rows={out_rows}")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tr = fakepipe.build_flux_transformer(out_rows, rng)
+    text = fakepipe.FakeFluxTextPipe()
+    names = ["context_embedder", "time_text_embed.text_embedder.linear_1"]
+    mods = dict(tr.named_modules())
+    w_old = {n: (mods[n].weight.detach().clone(), mods[n].bias.detach().clone()) for n in names}
+    _CURRENT_PIPE["flux"] = {"transformer": fakepipe.FakeFluxTransformerPipe(tr), "text": text}
+    try:
+        with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+            flux_mod.UCE("black-forest-labs/FLUX.1-schnell", list(edit), list(guide), list(preserve), erase_scale,
+                         preserve_scale, lamb, tmp, case, torch.float32, "cpu", 256)
+            state = _load_state(os.path.join(tmp, case + ".safetensors"))
+    finally:
+        _CURRENT_PIPE["flux"] = None
+    assert sorted(state) == sorted(n + ".weight" for n in names), sorted(state)
+    arrays = dict(meta=np.array(json.dumps(dict(
+        kind="flux", lamb=lamb, erase_scale=erase_scale, preserve_scale=preserve_scale, edit=edit, guide=guide,
+        preserve=preserve, modules=names, max_sequence_length=256, encode_calls=text.encode_calls))))
+    for i, n in enumerate(names):
+        emb = text.t5_embedding if i == 0 else text.pooled_embedding
+        Ce = np.stack([emb(p) for p in edit]).astype(np.float32)
+        Ge = np.stack([emb(p) for p in guide]).astype(np.float32)
+        Cp = np.stack([emb(p) for p in preserve]).astype(np.float32) if preserve else np.zeros((0, Ce.shape[1]), np.float32)
+        w, b = w_old[n]
+        te = [torch.from_numpy(r[None]) for r in Ce]
+        tg = [torch.from_numpy(r[None]) for r in Ge]
+        tp = [torch.from_numpy(r[None]) for r in Cp]
+        exact = uce_oracle.uce_edit_bias_exact64(w, b, te, tg, tp, erase_scale, preserve_scale, lamb)
+        ref = state[n + ".weight"]
+        arrays.update({f"C_edit_{i}": Ce, f"G_edit_{i}": Ge, f"C_pres_{i}": Cp, f"W_old_{i}": w.numpy(),
+                       f"b_{i}": b.numpy(), f"W_ref32_{i}": ref.numpy(), f"W_exact64_{i}": exact.numpy()})
+        print(f"    {n}: eps_ref = relF(ref32, exact64) = {uce_oracle.rel_fro(ref, exact):.3e}")
     _save(case, out_dir, **arrays)
 
 
@@ -319,6 +362,12 @@ def main() -> None:
         a500 = _artists(500)
         run_erase_case(erase_mod, "erase_n300p100_d768", args.out, 768, a500[:300], ["art"] * 300,
                        a500[300:400], 1.0, 1.0, 0.5, seed=7)
+
+    # FLUX variant: two biased Linear modules, T5 (4096) / pooled CLIP (768) embeddings
+    if want("flux_n6p3"):
+        flux_mod = _load_ref_module("trainscripts/uce_flux_edit.py", "ref_uce_flux_edit")
+        a = _artists(50)
+        run_flux_case(flux_mod, "flux_n6p3", args.out, 24, a[:6], ["art"] * 6, a[6:9], 1.0, 1.0, 0.5, seed=21)
 
     # debias: scripted direction_scale sequences (get_ratios is unseeded in the reference)
     if want("debias_n4x2_d768"):

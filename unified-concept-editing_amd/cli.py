@@ -118,6 +118,24 @@ def parse_generate_args(argv: Optional[Sequence[str]] = None):
     return generate_parser().parse_args(argv)
 
 
+FLUX_SCHNELL = "black-forest-labs/FLUX.1-schnell"
+FLUX_FLAGS = [(f, dict(kw, default=FLUX_SCHNELL) if f == "--model_id" else kw) for f, kw in ERASE_FLAGS]
+
+
+def flux_parser() -> argparse.ArgumentParser:
+    """trainscripts/uce_flux_edit.py:124-146: the erase flags with FLUX.1-schnell as the default model."""
+    return _parser("TrainUCE", "UCE for erasing concepts in FLUX", [FLUX_FLAGS, EXTRA_EDIT_FLAGS[:1]])
+
+
+def parse_flux_args(argv: Optional[Sequence[str]] = None):
+    return flux_parser().parse_args(argv)
+
+
+def flux_max_sequence_length(model_id: str) -> int:
+    """uce_flux_edit.py:169-171."""
+    return 256 if "schnell" in model_id else 512
+
+
 def split_concepts(text: Optional[str]) -> List[str]:
     """';'-separated, each entry stripped (uce_sd_erase.py:134)."""
     return [] if text is None else [c.strip() for c in text.split(";")]
