@@ -86,7 +86,8 @@ int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_
 int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,
                      int d, float lamb, float* Dm, float* R, uce_stream_t stream);
 
-/* Low-rank apply: W_new = W_old + (W_old Dm^T) R, one fused HBM-bound pass (N_edit <= 256). */
+/* Low-rank apply: W_new = W_old + (W_old Dm^T) R (N_edit <= 256).  For d in {768, 1024, 2048} and >= 1024 rows this
+ * is uce_lowrank_project (into the handle's T) + uce_lowrank_update; otherwise one fused 16-row-tile pass. */
 int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const float* R, float* W_new,
                       long rows, int d, int N_edit, uce_stream_t stream);
 

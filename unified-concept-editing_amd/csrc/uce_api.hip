@@ -239,6 +239,14 @@ int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const
     return UCE_EINVAL;
   if (N_edit > 0 && (!Dm || !R)) return UCE_EINVAL;
   if (rows == 0) return UCE_OK;
+  if (N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
+    // the two-kernel form (projection into the handle's T, then the update pass)
+    int rc = uce_ensure_T(h, rows, N_edit);
+    if (rc) return rc;
+    rc = launch_lr_project(W_old, Dm, nullptr, h->T, rows, d, N_edit, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_lr_update(W_old, h->T, R, W_new, rows, d, N_edit, (hipStream_t)stream);
+  }
   return launch_apply_lowrank(W_old, Dm, R, W_new, rows, d, N_edit, (hipStream_t)stream);
 }
 
