@@ -214,3 +214,83 @@ class FakeFluxTextPipe:
 
     def to(self, *a, **k):
         return self
+
+
+# ----------------------------------------------------------------------------------------------------
+# HiDream stand-ins (uce_hidream_edit.py:14-122): three from_pretrained calls - transformer only, Llama text
+# side, T5 text side.  caption_projection.<i>.linear is edited with the Llama layer llama_layers[i]'s hidden
+# state at the last token; the last projection with the T5 state.
+# ----------------------------------------------------------------------------------------------------
+HIDREAM_DIM = 4096
+
+
+class _Cfg:
+    def __init__(self, llama_layers):
+        self.llama_layers = list(llama_layers)
+
+
+def build_hidream_transformer(out_rows: int, llama_layers: Sequence[int], rng: np.random.Generator, bias: bool = False
+                              ) -> nn.Module:
+    root = _Node()
+    cp = nn.ModuleList()
+    bound = 1.0 / math.sqrt(HIDREAM_DIM)
+    for _ in range(len(llama_layers) + 1):                      # + the T5 projection
+        blk = _Node()
+        lin = nn.Linear(HIDREAM_DIM, out_rows, bias=bias)
+        lin.weight.data = torch.from_numpy(rng.uniform(-bound, bound, size=(out_rows, HIDREAM_DIM)).astype(np.float32))
+        if bias:
+            lin.bias.data = torch.from_numpy(rng.uniform(-bound, bound, size=(out_rows,)).astype(np.float32))
+        blk.add_module("linear", lin)
+        cp.append(blk)
+    root.add_module("caption_projection", cp)
+    root.add_module("x_embedder", nn.Linear(8, 8))
+    root.config = _Cfg(llama_layers)
+    return root
+
+
+class FakeHiDreamTokenizer:
+    def __init__(self, model_max_length: int):
+        self.model_max_length = model_max_length
+
+    def __call__(self, text, padding=None, max_length=None, truncation=True, add_special_tokens=True, return_tensors=None):
+        n = min(len(text.split()) + 2, max_length)
+        mask = torch.zeros(1, max_length, dtype=torch.long)
+        mask[0, :n] = 1
+        return {"attention_mask": mask, "input_ids": mask.clone()}
+
+
+class FakeHiDreamTextPipe:
+    """`_get_llama3_prompt_embeds` -> [n_layers, 1, L, 4096]; `_get_t5_prompt_embeds` -> [1, L, 4096]; each with the
+    string's (family-specific) embedding at the last-token index and different vectors elsewhere."""
+    N_LAYERS = 6
+
+    def __init__(self, tokenizer_4=None):
+        self.tokenizer_4 = tokenizer_4
+        self.tokenizer_3 = FakeHiDreamTokenizer(512)
+        rp = np.random.Generator(np.random.PCG64(79))
+        self._pos = torch.from_numpy(rp.standard_normal(HIDREAM_DIM).astype(np.float32))
+        self.calls: List[str] = []
+
+    @staticmethod
+    def family_embedding(prompt: str, family: str) -> np.ndarray:
+        return prompt_embedding(f"{family}:" + prompt, HIDREAM_DIM, norm=10.0, cosine=0.55)
+
+    def _seq(self, e: np.ndarray, idx: int, L: int) -> torch.Tensor:
+        pos = torch.arange(L, dtype=torch.float32) - idx
+        return torch.from_numpy(e)[None, :] + 0.2 * pos[:, None] * self._pos[None, :]
+
+    def _get_llama3_prompt_embeds(self, prompt, max_sequence_length, device, dtype):
+        self.calls.append("llama:" + prompt)
+        L = min(max_sequence_length, self.tokenizer_4.model_max_length)
+        idx = min(len(prompt.split()) + 2, L) - 2
+        return torch.stack([self._seq(self.family_embedding(prompt, f"llama{layer}"), idx, L)[None]
+                            for layer in range(self.N_LAYERS)])
+
+    def _get_t5_prompt_embeds(self, prompt, max_sequence_length, device, dtype):
+        self.calls.append("t5:" + prompt)
+        L = min(max_sequence_length, self.tokenizer_3.model_max_length)
+        idx = min(len(prompt.split()) + 2, L) - 2
+        return self._seq(self.family_embedding(prompt, "t5"), idx, L)[None]
+
+    def to(self, *a, **k):
+        return self

@@ -386,3 +386,30 @@ def test_flux_variant_matches_reference_golden(H, tmp_path):
         got = saved[n + ".weight"]
         assert O.rel_fro(got, ex) < EPS_BUILD
         assert O.rel_fro(got, ref) < max(1e-4, 1.5 * O.rel_fro(ref, ex))
+
+
+def test_hidream_variant_matches_reference_golden(H, tmp_path):
+    """uce_amd.hidream.UCE (one embedding family per caption projection) on the fakes the golden
+    was generated with, against the reference's uce_hidream_edit.py output."""
+    from safetensors.torch import load_file
+    from tests import fakepipe
+    from uce_amd import hidream
+    c = Case("hidream_n4p2")
+    m = c.meta
+    rng = np.random.Generator(np.random.PCG64(22))
+    tr = fakepipe.build_hidream_transformer(16, m["llama_layers"], rng)
+    mods = dict(tr.named_modules())
+    for i, n in enumerate(m["modules"]):
+        assert torch.equal(mods[n].weight.detach(), c.t(f"W_old_{i}"))
+    text = fakepipe.FakeHiDreamTextPipe(fakepipe.FakeHiDreamTokenizer(131072))
+    state, path = hidream.UCE("HiDream-ai/HiDream-I1-Full", m["edit"], m["guide"], m["preserve"], m["erase_scale"],
+                              m["preserve_scale"], m["lamb"], str(tmp_path), "hd", torch.float32, "cuda:0", 128,
+                              load_transformer=lambda: fakepipe.FakeFluxTransformerPipe(tr), load_llama=lambda: text,
+                              load_t5=lambda: text)
+    saved = load_file(path)
+    assert sorted(saved) == sorted(n + ".weight" for n in m["modules"])
+    for i, n in enumerate(m["modules"]):
+        ref, ex = c.t(f"W_ref32_{i}"), c.t(f"W_exact64_{i}")
+        got = saved[n + ".weight"]
+        assert O.rel_fro(got, ex) < EPS_BUILD
+        assert O.rel_fro(got, ref) < max(1e-4, 1.5 * O.rel_fro(ref, ex))

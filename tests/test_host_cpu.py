@@ -176,3 +176,21 @@ def test_flux_module_predicate_embeddings_and_cli():
     assert a.model_id == "black-forest-labs/FLUX.1-schnell" and cli.flux_max_sequence_length(a.model_id) == 256
     assert cli.flux_max_sequence_length("black-forest-labs/FLUX.1-dev") == 512
     assert cli.erase_job_from_args(a).guide_concepts == ["art", "art"]
+
+
+def test_hidream_module_predicate_embeddings_and_cli():
+    """uce_hidream_edit.py:31 name predicate, :59-116 per-layer Llama + T5 last-token states, :181-214 flags."""
+    from uce_amd import cli, hidream
+    rng = np.random.Generator(np.random.PCG64(0))
+    tr = fakepipe.build_hidream_transformer(8, [1, 3, 4], rng)
+    names = [n for n, _ in hidream.collect_hidream_modules(tr)]
+    assert names == [f"caption_projection.{i}.linear" for i in range(4)]
+    text = fakepipe.FakeHiDreamTextPipe(fakepipe.FakeHiDreamTokenizer(131072))
+    emb = hidream.hidream_embeddings(text, text, ["Van Gogh", "art", "Van Gogh"], [1, 3, 4], "cpu", 128)
+    assert list(emb) == ["Van Gogh", "art"] and text.calls == ["llama:Van Gogh", "llama:art", "t5:Van Gogh", "t5:art"]
+    fam = emb["Van Gogh"]
+    assert len(fam) == 4 and all(v.shape == (4096,) for v in fam)
+    for v, name in zip(fam, ["llama1", "llama3", "llama4", "t5"]):
+        assert np.allclose(v.numpy(), text.family_embedding("Van Gogh", name))
+    a = cli.parse_hidream_args(["--edit_concepts", "Van Gogh", "--concept_type", "art"])
+    assert a.model_id == "HiDream-ai/HiDream-I1-Full" and cli.HIDREAM_MAX_SEQUENCE_LENGTH == 128

@@ -123,3 +123,17 @@ def test_flux_bias_oracle_matches_reference_golden():
         u = Ainv @ (C.T @ s)
         collapsed = W.double() + W.double() @ Delta + torch.outer(b.double(), u)
         assert O.rel_fro(collapsed, ex) < 1e-10
+
+
+def test_hidream_golden_is_the_shared_closed_form_per_family():
+    """uce_hidream_edit.py run on the fakes: module i's weight is the bias-free closed form on embedding family i."""
+    from tests.golden_io import Case
+    c = Case("hidream_n4p2")
+    m = c.meta
+    assert m["families"] == ["llama1", "llama3", "llama4", "t5"] and len(m["modules"]) == 4
+    for i in range(4):
+        te = [r[None] for r in c.t(f"C_edit_{i}")]
+        tg = [r[None] for r in c.t(f"G_edit_{i}")]
+        tp = [r[None] for r in c.t(f"C_pres_{i}")]
+        ref = O.uce_edit_ref([c.t(f"W_old_{i}")], te, tg, tp, m["erase_scale"], m["preserve_scale"], m["lamb"])[0]
+        assert O.rel_fro(ref, c.t(f"W_ref32_{i}")) < 2e-6

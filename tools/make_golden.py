@@ -54,7 +54,20 @@ def _install_diffusers_stub() -> None:
                 return _CURRENT_PIPE["flux"][half]
             return _CURRENT_PIPE["pipe"]
 
+    class HiDreamImagePipeline:  # noqa: D401 - stand-in: uce_hidream_edit.py loads the model in three pieces
+        @staticmethod
+        def from_pretrained(model_id, **kw):
+            parts = _CURRENT_PIPE["hidream"]
+            if "transformer" not in kw:
+                return parts["transformer"]
+            if kw.get("tokenizer_4") is not None:
+                parts["llama"].tokenizer_4 = kw["tokenizer_4"]
+                return parts["llama"]
+            return parts["t5"]
+
     stub.DiffusionPipeline = DiffusionPipeline
+    stub.HiDreamImagePipeline = HiDreamImagePipeline
+    stub.UniPCMultistepScheduler = object
     sys.modules["diffusers"] = stub
 
 
@@ -189,6 +202,61 @@ def run_flux_case(flux_mod, case: str, out_dir: str, out_rows: int, edit: List[s
         arrays.update({f"C_edit_{i}": Ce, f"G_edit_{i}": Ge, f"C_pres_{i}": Cp, f"W_old_{i}": w.numpy(),
                        f"b_{i}": b.numpy(), f"W_ref32_{i}": ref.numpy(), f"W_exact64_{i}": exact.numpy()})
         print(f"    {n}: eps_ref = relF(ref32, exact64) = {uce_oracle.rel_fro(ref, exact):.3e}")
+    _save(case, out_dir, **arrays)
+
+
+# ---------------------------------------------------------------- HiDream variant (one embedding family per module)
+
+def run_hidream_case(hd_mod, case: str, out_dir: str, out_rows: int, llama_layers: List[int], edit: List[str],
+                     guide: List[str], preserve: List[str], erase_scale: float, preserve_scale: float, lamb: float,
+                     seed: int) -> None:
+    print(f"[hidream] {case}: N_e={len(edit)} N_p={len(preserve)} rows={out_rows} layers={llama_layers}")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tr = fakepipe.build_hidream_transformer(out_rows, llama_layers, rng)
+    text = fakepipe.FakeHiDreamTextPipe()
+    names = [n for n, _ in tr.named_modules() if "caption_projection" in n and "linear" in n]
+    mods = dict(tr.named_modules())
+    w_old = {n: mods[n].weight.detach().clone() for n in names}
+
+    class _Tok:
+        @staticmethod
+        def from_pretrained(*a, **k):
+            return fakepipe.FakeHiDreamTokenizer(131072)
+
+    class _Llama:
+        @staticmethod
+        def from_pretrained(*a, **k):
+            return object()
+
+    hd_mod.PreTrainedTokenizerFast, hd_mod.LlamaForCausalLM = _Tok, _Llama
+    _CURRENT_PIPE["hidream"] = {"transformer": fakepipe.FakeFluxTransformerPipe(tr), "llama": text, "t5": text}
+    try:
+        with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+            hd_mod.UCE("HiDream-ai/HiDream-I1-Full", list(edit), list(guide), list(preserve), erase_scale,
+                       preserve_scale, lamb, tmp, case, torch.float32, "cpu", 128)
+            state = _load_state(os.path.join(tmp, case + ".safetensors"))
+    finally:
+        _CURRENT_PIPE["hidream"] = None
+    assert sorted(state) == sorted(n + ".weight" for n in names), sorted(state)
+    fams = [f"llama{layer}" for layer in llama_layers] + ["t5"]
+    arrays = dict(meta=np.array(json.dumps(dict(
+        kind="hidream", lamb=lamb, erase_scale=erase_scale, preserve_scale=preserve_scale, edit=edit, guide=guide,
+        preserve=preserve, modules=names, llama_layers=llama_layers, families=fams, max_sequence_length=128,
+        calls=text.calls))))
+    for i, n in enumerate(names):
+        emb = lambda p: text.family_embedding(p, fams[i])
+        Ce = np.stack([emb(p) for p in edit]).astype(np.float32)
+        Ge = np.stack([emb(p) for p in guide]).astype(np.float32)
+        Cp = np.stack([emb(p) for p in preserve]).astype(np.float32) if preserve else np.zeros((0, Ce.shape[1]), np.float32)
+        w = w_old[n]
+        te = [torch.from_numpy(r[None]) for r in Ce]
+        tg = [torch.from_numpy(r[None]) for r in Ge]
+        tp = [torch.from_numpy(r[None]) for r in Cp]
+        exact = uce_oracle.uce_edit_exact64([w], te, tg, tp, erase_scale, preserve_scale, lamb)[0]
+        ref = state[n + ".weight"]
+        arrays.update({f"C_edit_{i}": Ce, f"G_edit_{i}": Ge, f"C_pres_{i}": Cp, f"W_old_{i}": w.numpy(),
+                       f"W_ref32_{i}": ref.numpy(), f"W_exact64_{i}": exact.numpy()})
+        print(f"    {n} ({fams[i]}): eps_ref = relF(ref32, exact64) = {uce_oracle.rel_fro(ref, exact):.3e}")
     _save(case, out_dir, **arrays)
 
 
@@ -368,6 +436,13 @@ def main() -> None:
         flux_mod = _load_ref_module("trainscripts/uce_flux_edit.py", "ref_uce_flux_edit")
         a = _artists(50)
         run_flux_case(flux_mod, "flux_n6p3", args.out, 24, a[:6], ["art"] * 6, a[6:9], 1.0, 1.0, 0.5, seed=21)
+
+    # HiDream variant: caption_projection.<i>.linear <- Llama layer llama_layers[i] (last one: T5)
+    if want("hidream_n4p2"):
+        hd_mod = _load_ref_module("trainscripts/uce_hidream_edit.py", "ref_uce_hidream_edit")
+        a = _artists(50)
+        run_hidream_case(hd_mod, "hidream_n4p2", args.out, 16, [1, 3, 4], a[:4], ["art"] * 4, a[4:6], 1.0, 1.0, 0.5,
+                         seed=22)
 
     # debias: scripted direction_scale sequences (get_ratios is unseeded in the reference)
     if want("debias_n4x2_d768"):

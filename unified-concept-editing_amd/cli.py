@@ -136,6 +136,20 @@ def flux_max_sequence_length(model_id: str) -> int:
     return 256 if "schnell" in model_id else 512
 
 
+HIDREAM_FULL = "HiDream-ai/HiDream-I1-Full"
+HIDREAM_FLAGS = [(f, dict(kw, default=HIDREAM_FULL) if f == "--model_id" else kw) for f, kw in ERASE_FLAGS]
+HIDREAM_MAX_SEQUENCE_LENGTH = 128                   # uce_hidream_edit.py:214
+
+
+def hidream_parser() -> argparse.ArgumentParser:
+    """trainscripts/uce_hidream_edit.py:181-197: the erase flags with HiDream-I1-Full as the default model."""
+    return _parser("TrainUCE", "UCE for erasing concepts in HiDream", [HIDREAM_FLAGS, EXTRA_EDIT_FLAGS[:1]])
+
+
+def parse_hidream_args(argv: Optional[Sequence[str]] = None):
+    return hidream_parser().parse_args(argv)
+
+
 def split_concepts(text: Optional[str]) -> List[str]:
     """';'-separated, each entry stripped (uce_sd_erase.py:134)."""
     return [] if text is None else [c.strip() for c in text.split(";")]
