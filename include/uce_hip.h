@@ -146,8 +146,13 @@ int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, v
  * channels, C % 8 == 0, C <= 4096; statistics in f32/f64.  ws: N * uce_groupnorm_chunks(HW) * G * 2 floats of
  * caller-owned scratch. */
 int uce_groupnorm_chunks(int HW);
-int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* gamma, const void* beta, void* y, float* ws,
-                           int N, int HW, int C, int G, float eps, int silu, int dtype, uce_stream_t stream);
+int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, const void* gamma, const void* beta, void* y,
+                           float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype, uce_stream_t stream);
+/* `addend` (may be NULL): [N, C], same dtype; x + addend[n][c] is what gets normalised - the time-embedding add of
+ * ResnetBlock2D and the bias of the convolution that produced x, folded into the normalisation.
+ * uce_add_bias_nhwc_fwd: y = a + b + bias[c] over [pixels, C] (b and bias may be NULL): the residual joins. */
+int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const void* bias, void* y, long pixels, int C,
+                          int dtype, uce_stream_t stream);
 
 /* GEGLU of the transformer feed-forward (diffusers GEGLU, exact erf GELU): x [rows, 2*inner] -> y [rows, inner] =
  * x[:, :inner] * gelu(x[:, inner:]), bf16 or f16, inner % 8 == 0. */

@@ -97,3 +97,32 @@ def test_geglu(H, shape, dtype):
     ref = h * F.gelu(gate)
     assert y.shape == ref.shape
     assert O.rel_fro(y.double().cpu(), ref.cpu()) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+
+
+@pytest.mark.parametrize("N,C,Hh,G,dtype", [(2, 320, 64, 32, torch.bfloat16), (3, 2560, 8, 32, torch.bfloat16),
+                                            (2, 64, 5, 8, torch.float16)])
+def test_groupnorm_with_per_channel_addend(H, N, C, Hh, G, dtype):
+    """norm2 of a ResnetBlock2D: silu(group_norm(conv1(.) + (bias + time embedding)[:, :, None, None]))."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, Hh, Hh, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    ad = (torch.randn(N, C, generator=g) * 0.7).to(dtype).cuda()
+    w = (torch.rand(C, generator=g) + 0.5).to(dtype).cuda()
+    b = (torch.randn(C, generator=g) * 0.2).to(dtype).cuda()
+    y = H.groupnorm_nhwc(x, w, b, G, 1e-5, True, addend=ad)
+    ref = F.silu(F.group_norm(x.double() + ad.double()[:, :, None, None], G, w.double(), b.double(), 1e-5))
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 320, 64, 64), torch.bfloat16), ((3, 64, 5, 7), torch.float16),
+                                         ((32, 1280, 16, 16), torch.bfloat16)])
+def test_add_bias_nhwc(H, shape, dtype):
+    g = torch.Generator().manual_seed(shape[1])
+    mk = lambda: torch.randn(*shape, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    a, b = mk(), mk()
+    bias = torch.randn(shape[1], generator=g).to(dtype).cuda()
+    want = a.double() + b.double() + bias.double()[None, :, None, None]
+    y = H.add_bias_nhwc(a, b, bias)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert O.rel_fro(y.double().cpu(), want.cpu()) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+    assert O.rel_fro(H.add_bias_nhwc(a, None, bias).double().cpu(), (a.double() + bias.double()[None, :, None, None]).cpu()) < 4e-3
+    assert O.rel_fro(H.add_bias_nhwc(a, b, None).double().cpu(), (a.double() + b.double()).cpu()) < 4e-3

@@ -58,9 +58,11 @@ __host__ __device__ inline GnMap gn_map(int C) {
   return m;
 }
 
+// `addend` (optional, [N, C], same dtype): x + addend[n][c] is what gets normalised (the ResnetBlock2D's
+// "h + time_emb_proj(...)[:, :, None, None]" and the bias of the convolution that produced x, folded in).
 template <bool F16>
-__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, float* __restrict__ partial,
-                                                  int HW, int C, int G, int chunks) {
+__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
+                                                  float* __restrict__ partial, int HW, int C, int G, int chunks) {
   extern __shared__ __attribute__((aligned(16))) float red[];     // [RPI][C][2]
   const GnMap mp = gn_map(C);
   const int tpr = mp.active / mp.RPI;
@@ -75,6 +77,14 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
     for (int i = 0; i < 8; ++i) s[j][i] = q[j][i] = 0.f;
   if (tid < mp.active) {
     const unsigned short* base = x + (size_t)n * HW * C;
+    float ad[MAXO][8];
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) {
+      const int oc = oc0 + j * tpr;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ad[j][i] = 0.f;
+      if (addend && j < mp.NO && oc < mp.OC) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * C + oc * 8), ad[j]);
+    }
     for (int p = p0 + prow; p < p1; p += mp.RPI) {
 #pragma unroll
       for (int j = 0; j < MAXO; ++j) {
@@ -84,8 +94,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
           unpack8<F16>(*(const uint4_t*)(base + (size_t)p * C + oc * 8), f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            s[j][i] += f[i];
-            q[j][i] = fmaf(f[i], f[i], q[j][i]);
+            const float v = f[i] + ad[j][i];
+            s[j][i] += v;
+            q[j][i] = fmaf(v, v, q[j][i]);
           }
         }
       }
@@ -119,7 +130,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
 }
 
 template <bool F16>
-__global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
+                                                  const unsigned short* __restrict__ gamma,
                                                   const unsigned short* __restrict__ beta, const float* __restrict__ partial,
                                                   unsigned short* __restrict__ y, int HW, int C, int G, int chunks,
                                                   float eps, int silu) {
@@ -155,11 +167,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
       float g8[8], b8[8];
       unpack8<F16>(*(const uint4_t*)(gamma + oc * 8), g8);
       unpack8<F16>(*(const uint4_t*)(beta + oc * 8), b8);
+      float a8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a8[i] = 0.f;
+      if (addend) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * C + oc * 8), a8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int grp = (oc * 8 + i) / cpg;
         sa[j][i] = g8[i] * rstd_s[grp];
-        sb[j][i] = fmaf(-mean_s[grp], sa[j][i], b8[i]);
+        sb[j][i] = fmaf(a8[i] - mean_s[grp], sa[j][i], b8[i]);      // ((x + a) - mean) * rstd * gamma + beta
       }
     }
   }
@@ -193,8 +209,8 @@ extern "C" int uce_groupnorm_chunks(int HW) {
 }
 
 // ws: N * uce_groupnorm_chunks(HW) * G * 2 floats, owned by the caller
-extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* gamma, const void* beta, void* y,
-                                      float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
+extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, const void* gamma, const void* beta,
+                                      void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
                                       uce_stream_t stream) {
   if (!h || !x || !gamma || !beta || !y || !ws || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64) return UCE_EINVAL;
   if (C % 8 || C % G || C > 8 * 256 * MAXO || N > 65535) return UCE_EINVAL;
@@ -206,12 +222,16 @@ extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void*
   const dim3 grid(chunks, N), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == UCE_DTYPE_F16) {
-    hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, ws, HW, C, G, chunks);
-    hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)gamma,
+    hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)addend, ws, HW,
+                       C, G, chunks);
+    hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)addend,
+                       (const unsigned short*)gamma,
                        (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu);
   } else {
-    hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, ws, HW, C, G, chunks);
-    hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)gamma,
+    hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)addend, ws, HW,
+                       C, G, chunks);
+    hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)addend,
+                       (const unsigned short*)gamma,
                        (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu);
   }
   UCE_LAUNCH_CHECK();
@@ -255,6 +275,57 @@ extern "C" int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, 
   else
     hipLaunchKernelGGL(k_geglu<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        (unsigned short*)y, rows, inner);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// y = a + b + bias[c]  for channels-last 16-bit activations [N*HW, C]: the residual join of a ResnetBlock2D /
+// Transformer2DModel with the bias of the (bias-free launched) convolution that produced `b` folded in - one pass
+// instead of MIOpen's separate bias kernel plus a torch add.  b may be null (y = a + bias).
+// -------------------------------------------------------------------------------------------------------------
+namespace {
+template <bool F16>
+__global__ __launch_bounds__(256) void k_add_bias(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                  const unsigned short* __restrict__ bias, unsigned short* __restrict__ y,
+                                                  long pixels, int C) {
+  const int oct = C / 8;
+  const long total = pixels * oct;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int oc = (int)(e % oct);
+    float av[8], bv[8], cv[8];
+    unpack8<F16>(*(const uint4_t*)(a + e * 8), av);
+    if (b) unpack8<F16>(*(const uint4_t*)(b + e * 8), bv);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bv[i] = 0.f;
+    }
+    if (bias) unpack8<F16>(*(const uint4_t*)(bias + oc * 8), cv);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cv[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) av[i] = av[i] + (bv[i] + cv[i]);
+    const uint4_t o = {pack2<F16>(av[0], av[1]), pack2<F16>(av[2], av[3]), pack2<F16>(av[4], av[5]), pack2<F16>(av[6], av[7])};
+    *(uint4_t*)(y + e * 8) = o;
+  }
+}
+}  // namespace
+
+extern "C" int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const void* bias, void* y, long pixels,
+                                     int C, int dtype, uce_stream_t stream) {
+  if (!h || !a || !y || pixels <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  const long total = pixels * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL(k_add_bias<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)a,
+                       (const unsigned short*)b, (const unsigned short*)bias, (unsigned short*)y, pixels, C);
+  else
+    hipLaunchKernelGGL(k_add_bias<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)a,
+                       (const unsigned short*)b, (const unsigned short*)bias, (unsigned short*)y, pixels, C);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

@@ -207,16 +207,26 @@ class UceHandle:
         return out
 
     def groupnorm_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float,
-                       silu: bool) -> torch.Tensor:
-        """GroupNorm (+ SiLU) of a channels-last [N, C, H, W] tensor through uce_groupnorm_nhwc_fwd."""
+                       silu: bool, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """GroupNorm (+ SiLU) of a channels-last [N, C, H, W] tensor through uce_groupnorm_nhwc_fwd; `addend` [N, C]
+        (optional) is added per (sample, channel) before the normalisation."""
         N, Cc, Hh, Ww = x.shape
         hw = Hh * Ww
         y = torch.empty_like(x)                                    # keeps the channels_last strides
         ws = torch.empty(N * self.lib.uce_groupnorm_chunks(hw) * groups * 2, dtype=torch.float32, device=x.device)
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
-        _lib.check(self.lib.uce_groupnorm_nhwc_fwd(self._h, _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(ws), N, hw,
-                                                   Cc, groups, float(eps), int(silu), dt, _stream_ptr(self.device)),
-                   "uce_groupnorm_nhwc_fwd")
+        _lib.check(self.lib.uce_groupnorm_nhwc_fwd(self._h, _ptr(x), _ptr(addend), _ptr(weight), _ptr(bias), _ptr(y),
+                                                   _ptr(ws), N, hw, Cc, groups, float(eps), int(silu), dt,
+                                                   _stream_ptr(self.device)), "uce_groupnorm_nhwc_fwd")
+        return y
+
+    def add_bias_nhwc(self, a: torch.Tensor, b: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> torch.Tensor:
+        """a + b + bias[c] for channels-last [N, C, H, W] tensors (b, bias optional) through uce_add_bias_nhwc_fwd."""
+        N, Cc, Hh, Ww = a.shape
+        y = torch.empty_like(a)
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[a.dtype]
+        _lib.check(self.lib.uce_add_bias_nhwc_fwd(self._h, _ptr(a), _ptr(b), _ptr(bias), _ptr(y), N * Hh * Ww, Cc, dt,
+                                                  _stream_ptr(self.device)), "uce_add_bias_nhwc_fwd")
         return y
 
     def geglu(self, x: torch.Tensor) -> torch.Tensor:

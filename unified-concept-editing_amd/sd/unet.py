@@ -72,17 +72,40 @@ class TimestepEmbedding(nn.Module):
 USE_HIP_GROUPNORM = True          # GroupNorm(+SiLU) of channels-last 16-bit activations through the HIP kernel
 
 
-def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool) -> torch.Tensor:
-    """`silu(norm(x))` / `norm(x)`.  On a GPU, for bf16/f16 activations in channels_last memory format, one fused
-    HIP launch pair (uce_groupnorm_nhwc_fwd) instead of torch's GroupNorm kernels + a SiLU pass."""
-    if USE_HIP_GROUPNORM and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16) \
-            and x.shape[1] % 8 == 0 and x.shape[1] <= 4096 and norm.num_groups <= 64 and x.shape[0] <= 65535 \
-            and x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last) \
-            and norm.weight is not None and norm.weight.dtype == x.dtype:
+def _hip_nhwc_ok(x: torch.Tensor) -> bool:
+    return (USE_HIP_GROUPNORM and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+            and x.shape[1] % 8 == 0 and 1 < x.shape[1] <= 4096 and x.shape[0] <= 65535
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`silu(norm(x + addend[:, :, None, None]))` (silu / addend optional).  On a GPU, for bf16/f16 activations in
+    channels_last memory format, one fused HIP launch pair (uce_groupnorm_nhwc_fwd) instead of torch's broadcast add,
+    GroupNorm kernels and SiLU pass."""
+    if _hip_nhwc_ok(x) and norm.num_groups <= 64 and norm.weight is not None and norm.weight.dtype == x.dtype:
         from .. import edit as _edit
-        return _edit.UceHandle.get(x.device).groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)
+        ad = None if addend is None else addend.to(x.dtype).contiguous()
+        return _edit.UceHandle.get(x.device).groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, ad)
+    if addend is not None:
+        x = x + addend[:, :, None, None].to(x.dtype)
     y = norm(x)
     return F.silu(y) if silu else y
+
+
+def conv_nobias(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """The convolution WITHOUT its bias (MIOpen applies a conv bias as a separate pass over the output; the callers
+    fold it into the next fused kernel instead)."""
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def add_bias(a: torch.Tensor, b: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """a + b + bias[None, :, None, None] in one pass (uce_add_bias_nhwc_fwd) where the tensors allow it."""
+    if _hip_nhwc_ok(a) and (b is None or (b.shape == a.shape and b.dtype == a.dtype and b.is_contiguous(memory_format=torch.channels_last))) \
+            and (bias is None or bias.dtype == a.dtype):
+        from .. import edit as _edit
+        return _edit.UceHandle.get(a.device).add_bias_nhwc(a, b, bias)
+    y = a if b is None else a + b
+    return y if bias is None else y + bias[None, :, None, None].to(y.dtype)
 
 
 class ResnetBlock2D(nn.Module):
@@ -96,12 +119,19 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb):
-        h = self.conv1(group_norm_act(self.norm1, x, True))
-        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(group_norm_act(self.norm2, h, True))
+        # conv biases and the time-embedding add ride in the fused kernels: norm2 sees conv1(.) + (b1 + temb_c),
+        # the residual join adds b2 (+ the shortcut's bias) in the same pass
+        h = conv_nobias(self.conv1, group_norm_act(self.norm1, x, True))
+        ad = self.time_emb_proj(F.silu(temb))
+        if self.conv1.bias is not None:
+            ad = ad + self.conv1.bias[None, :]
+        h = conv_nobias(self.conv2, group_norm_act(self.norm2, h, True, addend=ad))
+        bias = self.conv2.bias
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
-        return x + h
+            x = conv_nobias(self.conv_shortcut, x)
+            if self.conv_shortcut.bias is not None:
+                bias = self.conv_shortcut.bias if bias is None else bias + self.conv_shortcut.bias
+        return add_bias(x, h, bias)
 
 
 class Attention(nn.Module):
@@ -211,7 +241,7 @@ class Transformer2DModel(nn.Module):
         for blk in self.transformer_blocks:
             h = blk(h, context)
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-        return self.proj_out(h) + x
+        return add_bias(x, conv_nobias(self.proj_out, h), self.proj_out.bias)
 
 
 class Downsample2D(nn.Module):
