@@ -126,3 +126,23 @@ def test_add_bias_nhwc(H, shape, dtype):
     assert O.rel_fro(y.double().cpu(), want.cpu()) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
     assert O.rel_fro(H.add_bias_nhwc(a, None, bias).double().cpu(), (a.double() + bias.double()[None, :, None, None]).cpu()) < 4e-3
     assert O.rel_fro(H.add_bias_nhwc(a, b, None).double().cpu(), (a.double() + b.double()).cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,dtype,bias", [
+    (2, 320, 320, 64, 64, torch.bfloat16, True), (3, 64, 32, 5, 7, torch.bfloat16, False),
+    (2, 960, 320, 16, 16, torch.bfloat16, True), (2, 32, 64, 8, 8, torch.float16, True),
+    (5, 128, 128, 40, 24, torch.bfloat16, True),
+])
+def test_conv3x3_im2col_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias):
+    """uce_im2col3x3_nhwc + one GEMM against F.conv2d evaluated in fp32 (borders, ragged sizes, batch chunking)."""
+    g = torch.Generator().manual_seed(Cin + Hh)
+    x = torch.randn(N, Cin, Hh, Ww, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).to("cuda", dtype).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = F.conv2d(x.float(), conv.weight.float(), None if conv.bias is None else conv.bias.float(), padding=1)
+        y = H.conv3x3_nhwc(x, conv.weight, conv.bias)
+        y_chunked = H.conv3x3_nhwc(x, conv.weight, conv.bias, max_cols_bytes=Hh * Ww * 9 * Cin * 2 * 2)   # 2 images per chunk
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
+    assert O.rel_fro(y.float().cpu(), ref.cpu()) < tol
+    assert O.rel_fro(y_chunked.float().cpu(), ref.cpu()) < tol

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libuce_hip.so")
-SOURCES = ["uce_gram.hip", "uce_solve.hip", "uce_apply.hip", "uce_apply_b3.hip", "uce_lowrank2.hip", "uce_xattn.hip", "uce_sattn.hip", "uce_norm.hip", "uce_api.hip"]
+SOURCES = ["uce_gram.hip", "uce_solve.hip", "uce_apply.hip", "uce_apply_b3.hip", "uce_lowrank2.hip", "uce_xattn.hip", "uce_sattn.hip", "uce_norm.hip", "uce_conv.hip", "uce_api.hip"]
 HEADERS = ["uce_common.h", os.path.join("..", "..", "include", "uce_hip.h")]
 
 

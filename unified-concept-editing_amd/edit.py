@@ -229,6 +229,29 @@ class UceHandle:
                                                   _stream_ptr(self.device)), "uce_add_bias_nhwc_fwd")
         return y
 
+    def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                     max_cols_bytes: int = 1 << 30) -> torch.Tensor:
+        """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor: patch matrix through
+        uce_im2col3x3_nhwc, then ONE library GEMM (F.linear -> hipBLASLt) against the channels-last weight viewed as
+        [Cout, 9*C].  The batch is walked in chunks whose patch matrix stays under `max_cols_bytes`."""
+        N, Cc, Hh, Ww = x.shape
+        Cout = weight.shape[0]
+        wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
+        y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        y_rows = y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout)     # NHWC view of the same storage
+        per_image = Hh * Ww * 9 * Cc * x.element_size()
+        step = max(1, min(N, max_cols_bytes // per_image))
+        cols = torch.empty((step * Hh * Ww, 9 * Cc), dtype=x.dtype, device=x.device)
+        xs = x.permute(0, 2, 3, 1)                                    # [N, H, W, C] view, contiguous
+        for n0 in range(0, N, step):
+            nb = min(step, N - n0)
+            _lib.check(self.lib.uce_im2col3x3_nhwc(self._h, xs[n0].data_ptr(), _ptr(cols), nb, Hh, Ww, Cc,
+                                                   _stream_ptr(self.device)), "uce_im2col3x3_nhwc")
+            rows = nb * Hh * Ww
+            torch.addmm(bias, cols[:rows], wmat.t(), out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows]) if bias is not None \
+                else torch.mm(cols[:rows], wmat.t(), out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows])
+        return y
+
     def geglu(self, x: torch.Tensor) -> torch.Tensor:
         """x [..., 2*inner] -> x[..., :inner] * gelu(x[..., inner:]) through uce_geglu_fwd."""
         inner = x.shape[-1] // 2

@@ -29,7 +29,7 @@ from .scheduler import PNDMScheduler
 # ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
 # batch 2 (48 ms average over 384 calls in profiles/r01), far more at larger batches.  It never wins.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
-from .unet import UNet2DConditionModel, UNetConfig, group_norm_act
+from .unet import UNet2DConditionModel, UNetConfig, conv2d, group_norm_act
 
 MAX_LEN = 77
 BOS, EOS = 49406, 49407
@@ -98,7 +98,7 @@ class _VaeResnet(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x):
-        h = self.conv2(group_norm_act(self.norm2, self.conv1(group_norm_act(self.norm1, x, True)), True))
+        h = conv2d(self.conv2, group_norm_act(self.norm2, conv2d(self.conv1, group_norm_act(self.norm1, x, True)), True))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 
@@ -134,7 +134,7 @@ class _UpConv(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return conv2d(self.conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
 class _VaeMid(nn.Module):

@@ -92,10 +92,28 @@ def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Opti
     return F.silu(y) if silu else y
 
 
+USE_HIP_CONV3X3 = True            # 3x3 / stride 1 / pad 1 convolutions as im2col (HIP) + one hipBLASLt GEMM
+
+
+def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    return (USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels >= 32
+            and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Tensor:
+    """`conv(x)`.  3x3 / stride 1 / pad 1 convolutions of channels-last 16-bit activations on a GPU go through
+    uce_im2col3x3_nhwc + one library GEMM (1.7-2.3x MIOpen's implicit GEMM on an MI355X); everything else is MIOpen."""
+    bias = conv.bias if with_bias else None
+    if _conv3x3_fast_ok(conv, x):
+        from .. import edit as _edit
+        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias)
+    return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 def conv_nobias(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """The convolution WITHOUT its bias (MIOpen applies a conv bias as a separate pass over the output; the callers
-    fold it into the next fused kernel instead)."""
-    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    """The convolution WITHOUT its bias (the callers fold it into the next fused kernel)."""
+    return conv2d(conv, x, with_bias=False)
 
 
 def add_bias(a: torch.Tensor, b: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> torch.Tensor:
@@ -259,7 +277,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return conv2d(self.conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
 class DownBlock(nn.Module):
