@@ -99,7 +99,7 @@ class _VaeResnet(nn.Module):
 
     def forward(self, x):
         h = conv2d(self.conv2, group_norm_act(self.norm2, conv2d(self.conv1, group_norm_act(self.norm1, x, True)), True))
-        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+        return (x if self.conv_shortcut is None else conv2d(self.conv_shortcut, x)) + h
 
 
 class _VaeAttention(nn.Module):
@@ -165,7 +165,7 @@ class _Decoder(nn.Module):
         x = self.mid_block(self.conv_in(z))
         for u in self.up_blocks:
             x = u(x)
-        return self.conv_out(group_norm_act(self.conv_norm_out, x, True))
+        return conv2d(self.conv_out, group_norm_act(self.conv_norm_out, x, True))
 
 
 class VaeDecoder(nn.Module):

@@ -97,7 +97,7 @@ USE_HIP_CONV3X3 = True            # 3x3 / stride 1 / pad 1 convolutions as im2co
 
 def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
     return (USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels >= 32
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels >= 4
             and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -108,6 +108,12 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Te
     if _conv3x3_fast_ok(conv, x):
         from .. import edit as _edit
         return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias)
+    if USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) \
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.weight.dtype == x.dtype:
+        # a 1x1 convolution of a channels-last tensor IS a GEMM over the pixel rows: hand it to the GEMM library
+        N, Cin, Hh, Ww = x.shape
+        y = F.linear(x.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cin), conv.weight.reshape(conv.out_channels, Cin), bias)
+        return y.view(N, Hh, Ww, conv.out_channels).permute(0, 3, 1, 2)
     return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
@@ -254,7 +260,7 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         B, C, H, W = x.shape
-        h = self.proj_in(group_norm_act(self.norm, x, False))
+        h = conv2d(self.proj_in, group_norm_act(self.norm, x, False))
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
@@ -390,4 +396,4 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb, encoder_hidden_states)
         for blk in self.up_blocks:
             x = blk(x, skips, temb, encoder_hidden_states)
-        return self.conv_out(group_norm_act(self.conv_norm_out, x, True))
+        return conv2d(self.conv_out, group_norm_act(self.conv_norm_out, x, True))
