@@ -168,9 +168,12 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   float* Bs = As + 2 * 64 * GP_LD;                                // [2 halves][64][GP_LD]  rows of block tk
   constexpr size_t AB_BYTES = (size_t)4 * 64 * GP_LD * sizeof(float);
   double* P1 = (double*)(smem_raw + AB_BYTES);                    // [64][GP_TLD]
-  Potrf64Scratch* sc = (Potrf64Scratch*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double));
+  // the factorisation scratch ALIASES the Gram staging (As, Bs, P1 are dead once the slab is published), so a
+  // single-tile rider needs 74 KB and two workgroups of the launch fit a CU
+  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
+  static_assert(sizeof(Potrf64Scratch) <= AB_BYTES + 64 * GP_TLD * sizeof(double), "scratch must fit the Gram staging");
   // (all LDS in the dynamic region: a static __shared__ would shift its 16-byte alignment)
-  unsigned* s_last_p = (unsigned*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch));
+  unsigned* s_last_p = (unsigned*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double));
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = w >> 2, wq = w & 3;
   const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
@@ -321,8 +324,9 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   potrf_step_tile(j.M, n, 0, 1, 1, j.Lmat, j.Linv, j.status, smem_raw);
 }
 
-constexpr size_t GP_SMEM = (size_t)4 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + sizeof(Potrf64Scratch) + 16;
-static_assert(GP_SMEM >= POTRF_STEP_SMEM, "the step tile body aliases the rider's LDS");
+constexpr size_t GP_SMEM1 = (size_t)4 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + 16;   // one system tile
+constexpr size_t GP_SMEM = GP_SMEM1 > POTRF_STEP_SMEM + 16 ? GP_SMEM1 : POTRF_STEP_SMEM + 16;              // 128 x 128 systems
+__host__ __device__ constexpr size_t gp_smem(int nb) { return nb <= 1 ? GP_SMEM1 : GP_SMEM; }
 
 template <int D, int MT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_project(
@@ -582,7 +586,7 @@ template <int D, int MT>
 int launch_project(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit,
                    int NEP64, const GramPotrfJob& job, hipStream_t st) {
   size_t smem = (size_t)2 * (MT * 16 + 64) * PJ_LD * sizeof(float);
-  if (job.C && smem < GP_SMEM) smem = GP_SMEM;
+  if (job.C && smem < gp_smem(job.nb)) smem = gp_smem(job.nb);
   static bool attr_set = false;
   if (!attr_set) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
