@@ -301,7 +301,7 @@ def test_edit_edge_cases(H):
 @pytest.mark.parametrize("Ne,d,rows_", [(50, 768, 24960), (33, 768, 1500), (64, 1024, 2000), (100, 768, 3000),
                                         (36, 2048, 1300), (200, 768, 1111)])
 def test_lowrank_project_and_update(H, Ne, d, rows_):
-    """The two-kernel low-rank apply (what uce_edit forks over two streams) against fp64."""
+    """The two-kernel low-rank apply (projection, then update: what uce_edit launches) against fp64."""
     rng = np.random.Generator(np.random.PCG64(Ne + d))
     W = O.linear_default_weight(rows_, d, rng)
     Dm = rng.standard_normal((Ne, d)).astype(np.float32)

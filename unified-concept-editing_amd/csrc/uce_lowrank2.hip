@@ -1,17 +1,16 @@
 // Two-kernel form of the low-rank apply  W_new = W_old + (W_old D_e^T) R_e :
 //
-//   k_lr_project<D,MT> : T [rows, NEP] = W_old D_e^T      needs only D_e = G - C_e, not the solve: in
-//                        uce_edit ONE launch carries this GEMM (blocks 1..) and the 64x64 Cholesky of
-//                        the dual system (block 0), so the latency-bound factorisation hides under
-//                        the f32-MFMA-bound projection without any cross-stream event (a HIP event
-//                        hand-off between two streams measured 13-14 us each way on this stack).
-//   k_lr_update<D>     : W_new = W_old + T R_e            one pass over the weights, HBM bound:
-//                        algorithmic bytes 8*rows*d (+ the small T and R).
+//   k_lr_project<D,MT>  : T [rows, NEP] = W_old D_e^T     needs only D_e = G - C_e, not the solve: in uce_edit ONE
+//                         launch carries this GEMM and, in its first 4 / 12 "rider" blocks, the Gram matrix and the
+//                         (blocked) Cholesky + block inverses of the dual system (N <= 64 / N <= 128), so the
+//                         latency-bound factorisation hides under the f32-MFMA-bound projection without any
+//                         cross-stream event (a HIP event hand-off between two streams measured 13-14 us each way).
+//   k_lr_update_s<D,..> : W_new = W_old + T R_e           one pass over the weights (N_edit <= 128; k_lr_update is the
+//                         ring-buffered form for 129..256): algorithmic bytes 8*rows*d (+ the small T and R).
 //
-// Splitting the fused kernel (uce_apply.hip) at T costs 2*4*rows*NEP bytes of extra traffic (6.4 MB
-// at N_edit <= 64 for SD-1.4, 4 %) and buys (a) overlap of the 0.1 GF MFMA-bound projection with the
-// latency-bound small-system chain, (b) an update kernel whose LDS footprint is tiny, so several
-// workgroups per CU stream W with their phases naturally interleaved.
+// Splitting the update at T costs 2*4*rows*NEP bytes of extra traffic (6.4 MB at N_edit <= 64 for SD-1.4, 4 %) and
+// buys (a) overlap of the projection with the latency-bound small-system chain, (b) an update kernel whose LDS
+// footprint is tiny, so several workgroups per CU stream W with their phases naturally interleaved.
 #include "uce_common.h"
 #include "uce_potrf64.h"
 #include <cstdlib>
