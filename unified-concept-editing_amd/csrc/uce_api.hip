@@ -188,8 +188,7 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
   int rc = uce_ensure(h, d, d);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  UCE_HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int), st));
-  rc = launch_potrf(h, A, d, st);
+  rc = launch_potrf(h, A, d, st);                    // k_potrf_first resets the status word
   if (rc) return rc;
   return launch_trisolve(h, d, d, Bt, nullptr, d, DeltaT, d, st);
 }

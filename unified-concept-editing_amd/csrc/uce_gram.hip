@@ -87,24 +87,36 @@ __global__ __launch_bounds__(256) void k_gram_primal(const float* __restrict__ C
 
   const int lrow = tid >> 4;          // 0..15
   const int lc4 = (tid & 15) * 4;     // 0..60
-  for (int k0 = k_begin; k0 < k_end; k0 += KC) {
-    // stage X = C[:, ti tile], Y = C[:, tj tile] (A) or (G - C)[:, tj tile] (Bt)
+  // register prefetch of the next 32-concept chunk: the global loads of chunk k+1 are in flight while chunk k is
+  // multiplied (single-buffered LDS: load -> barrier -> MFMA -> barrier left the f64 MFMA pipe idle half the time)
+  float4_t px[KC / 16], py[KC / 16];
+  float ps = 0.f;
+  auto g_load = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < KC / 16; ++p) {
-      const int kk = p * 16 + lrow;
-      const int n = k0 + kk;
-      float4_t x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+      const int n = k0 + p * 16 + lrow;
+      px[p] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      py[p] = px[p];
       if (n < k_end) {
-        x = *(const float4_t*)(C + (size_t)n * d + ti * 64 + lc4);
+        px[p] = *(const float4_t*)(C + (size_t)n * d + ti * 64 + lc4);
         const float4_t cy = *(const float4_t*)(C + (size_t)n * d + tj * 64 + lc4);
-        if (isA) y = cy;
-        else y = *(const float4_t*)(G + (size_t)n * d + tj * 64 + lc4) - cy;
+        // stage X = C[:, ti tile], Y = C[:, tj tile] (A) or (G - C)[:, tj tile] (Bt)
+        if (isA) py[p] = cy;
+        else py[p] = *(const float4_t*)(G + (size_t)n * d + tj * 64 + lc4) - cy;
       }
-      *(float4_t*)&Xs[kk][lc4] = x;
-      *(float4_t*)&Ys[kk][lc4] = y;
     }
-    if (tid < KC) Ss[tid] = (k0 + tid < k_end) ? s[k0 + tid] : 0.f;
+    if (tid < KC) ps = (k0 + tid < k_end) ? s[k0 + tid] : 0.f;
+  };
+  if (k_begin < k_end) g_load(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += KC) {
+#pragma unroll
+    for (int p = 0; p < KC / 16; ++p) {
+      *(float4_t*)&Xs[p * 16 + lrow][lc4] = px[p];
+      *(float4_t*)&Ys[p * 16 + lrow][lc4] = py[p];
+    }
+    if (tid < KC) Ss[tid] = ps;
     __syncthreads();
+    if (k0 + KC < k_end) g_load(k0 + KC);
 #pragma unroll
     for (int kb = 0; kb < KC / 4; ++kb) {
       const int kk = kb * 4 + (lane >> 4);

@@ -28,6 +28,9 @@ __global__ __launch_bounds__(512) void k_potrf_first(const double* __restrict__ 
                                                      size_t slab_stride, double* __restrict__ Lmat,
                                                      double* __restrict__ Linv, int* status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // every factorisation starts here: reset the status word in this launch (a hipMemsetAsync costs a 4-5 us
+  // fill kernel of its own); the first barrier inside the factor orders it before any failure report
+  if (threadIdx.x == 0) *status = 0;
   potrf_first_body8(M, n, nsplit, slab_stride, Lmat, Linv, status, (Potrf64Scratch*)smem_raw);
 }
 
