@@ -41,6 +41,10 @@ def _f32c(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+# patch-matrix chunk of the im2col + GEMM convolutions (bytes); UCE_CONV_COLS_MB overrides for measurements
+CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "1024")) << 20
+
+
 class UceHandle:
     """One per GPU.  Owns the library workspace (uce_create / uce_destroy)."""
 
@@ -230,7 +234,7 @@ class UceHandle:
         return y
 
     def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                     max_cols_bytes: int = 1 << 30) -> torch.Tensor:
+                     max_cols_bytes: int = CONV_COLS_BYTES) -> torch.Tensor:
         """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor: patch matrix through
         uce_im2col3x3_nhwc, then ONE library GEMM (F.linear -> hipBLASLt) against the channels-last weight viewed as
         [Cout, 9*C].  The batch is walked in chunks whose patch matrix stays under `max_cols_bytes`."""
