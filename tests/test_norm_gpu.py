@@ -131,7 +131,7 @@ def test_add_bias_nhwc(H, shape, dtype):
 @pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,dtype,bias", [
     (2, 320, 320, 64, 64, torch.bfloat16, True), (3, 64, 32, 5, 7, torch.bfloat16, False),
     (2, 960, 320, 16, 16, torch.bfloat16, True), (2, 32, 64, 8, 8, torch.float16, True),
-    (5, 128, 128, 40, 24, torch.bfloat16, True),
+    (5, 128, 128, 40, 24, torch.bfloat16, True), (2, 1920, 64, 8, 6, torch.bfloat16, True),   # C > 1280: flat kernel
 ])
 def test_conv3x3_im2col_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias):
     """uce_im2col3x3_nhwc + one GEMM against F.conv2d evaluated in fp32 (borders, ragged sizes, batch chunking)."""
@@ -146,3 +146,18 @@ def test_conv3x3_im2col_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias)
     tol = 6e-3 if dtype == torch.bfloat16 else 1e-3
     assert O.rel_fro(y.float().cpu(), ref.cpu()) < tol
     assert O.rel_fro(y_chunked.float().cpu(), ref.cpu()) < tol
+
+
+@pytest.mark.parametrize("N,C,Hh,Ww", [(2, 64, 5, 7), (3, 320, 16, 16), (1, 1288, 4, 3), (2, 2560, 3, 5), (1, 8, 1, 1)])
+def test_im2col_patch_matrix_is_bit_exact(H, N, C, Hh, Ww):
+    """Both patch-matrix kernels (row kernel for C <= 1280, flat kernel above) against nine shifted slices of the
+    zero-padded NHWC input: pure data movement, so the comparison is bit-exact."""
+    from uce_amd import lib as L
+    g = torch.Generator().manual_seed(C + Ww)
+    x = torch.randn(N, Hh, Ww, C, generator=g).to(torch.bfloat16).cuda()
+    cols = torch.full((N * Hh * Ww, 9 * C), 7.0, dtype=torch.bfloat16, device="cuda:0")
+    L.check(H.lib.uce_im2col3x3_nhwc(H._h, x.data_ptr(), cols.data_ptr(), N, Hh, Ww, C,
+                                     torch.cuda.current_stream().cuda_stream), "uce_im2col3x3_nhwc")
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+    want = torch.cat([xp[:, ky:ky + Hh, kx:kx + Ww, :] for ky in range(3) for kx in range(3)], dim=-1)
+    assert torch.equal(cols.view(N, Hh, Ww, 9 * C), want)

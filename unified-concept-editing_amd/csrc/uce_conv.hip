@@ -6,18 +6,49 @@
 //
 //   k_im2col3x3 : x [N, H, W, C] (an NCHW tensor in torch.channels_last memory format), 16-bit elements ->
 //                 cols [N*H*W, 9*C], column = (ky*3 + kx)*C + c  (the order of a channels_last Conv2d weight
-//                 viewed as [Cout, 9*C]), zero outside the image.  One 16-byte element per thread-iteration;
-//                 writes are fully contiguous, each input pixel is read nine times out of L2.
+//                 viewed as [Cout, 9*C]), zero outside the image.  Writes are fully contiguous 16-byte stores, each
+//                 input pixel is read nine times out of L2.
 #include "uce_common.h"
 
 namespace {
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x, uint4_t* __restrict__ cols, int N, int H,
-                                                   int W, int C8) {
+// One workgroup per image row (n, y): thread j owns patch-row unit(s) j, j + 256, ... (unit = 16 bytes; tap t = j / C8,
+// channel octet c = j % C8, computed once) and walks the row's pixels - no per-element index divisions, stores
+// contiguous over j, loads contiguous within a tap.
+__global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x, uint4_t* __restrict__ cols, int H, int W,
+                                                   int C8, int units /* = ceil(9*C8 / 256) */) {
+  const int row16 = 9 * C8;
+  const int ny = blockIdx.x;                       // n * H + y
+  const int y = ny % H;
+  const long n = ny / H;
+  const uint4_t* xn = x + n * H * W * C8;
+  uint4_t* out = cols + (long)ny * W * row16;
+  for (int k = 0; k < units; ++k) {
+    const int j = threadIdx.x + 256 * k;
+    if (j >= row16) break;
+    const int t = j / C8, c = j - t * C8;
+    const int yy = y + t / 3 - 1, dx = t % 3 - 1;
+    const bool row_ok = yy >= 0 && yy < H;
+    const uint4_t* src = xn + ((long)(row_ok ? yy : 0) * W) * C8 + c;
+    for (int xw = 0; xw < W; ++xw) {
+      const int xx = xw + dx;
+      uint4_t v = {0u, 0u, 0u, 0u};
+      if (row_ok && xx >= 0 && xx < W) v = src[(long)xx * C8];
+      __builtin_nontemporal_store(v, out + (long)xw * row16 + j);     // streamed: the GEMM reads it back once
+    }
+  }
+}
+
+
+// Flat variant: one 16-byte unit per thread-iteration over the whole patch matrix (grid-stride).  Its per-unit index
+// arithmetic costs more than k_im2col3x3's, but for wide inputs (C > 1280, where one thread of the row kernel would
+// own many units) it keeps more stores in flight: 4.3-4.9 TB/s there against 3.6-4.1 (tools/probe_im2col.py).
+__global__ __launch_bounds__(256) void k_im2col3x3_flat(const uint4_t* __restrict__ x, uint4_t* __restrict__ cols, int N,
+                                                        int H, int W, int C8) {
   const long total = (long)N * H * W * 9 * C8;
-  const int row16 = 9 * C8;                       // 16-byte units per output row
+  const int row16 = 9 * C8;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long p = e / row16;
     const int r = (int)(e - p * row16);
@@ -29,7 +60,7 @@ __global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x
     const int yy = y + t / 3 - 1, xx = xw + t % 3 - 1;
     uint4_t v = {0u, 0u, 0u, 0u};
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((n * H + yy) * W + xx) * C8 + c];
-    __builtin_nontemporal_store(v, cols + e);     // streamed: the GEMM reads it back once
+    __builtin_nontemporal_store(v, cols + e);
   }
 }
 
@@ -38,11 +69,18 @@ __global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x
 extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C,
                                   uce_stream_t stream) {
   if (!h || !x || !cols || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
-  const long total = (long)N * H * W * 9 * (C / 8);
-  long blocks = (total + 255) / 256;
-  if (blocks > 256 * 64) blocks = 256 * 64;
-  hipLaunchKernelGGL(k_im2col3x3, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4_t*)x,
-                     (uint4_t*)cols, N, H, W, C / 8);
+  const int C8 = C / 8;
+  const uint4_t* xs = (const uint4_t*)x;
+  uint4_t* cs = (uint4_t*)cols;
+  if (C <= 1280) {
+    hipLaunchKernelGGL(k_im2col3x3, dim3((unsigned)(N * H)), dim3(256), 0, (hipStream_t)stream, xs, cs, H, W, C8,
+                       (9 * C8 + 255) / 256);
+  } else {
+    const long total = (long)N * H * W * 9 * C8;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_im2col3x3_flat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xs, cs, N, H, W, C8);
+  }
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
