@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x
 
 // Flat variant: one 16-byte unit per thread-iteration over the whole patch matrix (grid-stride).  Its per-unit index
 // arithmetic costs more than k_im2col3x3's, but for wide inputs (C > 1280, where one thread of the row kernel would
-// own many units) it keeps more stores in flight: 4.3-4.9 TB/s there against 3.6-4.1 (tools/probe_im2col.py).
+// own many units) it keeps more stores in flight: 4.3-4.9 TB/s there against 3.6-4.1 (tools/probe_im2col.py); it
+// also takes the few-rows / long-rows cases (VAE decoder, tiny batches) where the row kernel cannot fill the chip.
 __global__ __launch_bounds__(256) void k_im2col3x3_flat(const uint4_t* __restrict__ x, uint4_t* __restrict__ cols, int N,
                                                         int H, int W, int C8) {
   const long total = (long)N * H * W * 9 * C8;
@@ -72,7 +73,9 @@ extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int
   const int C8 = C / 8;
   const uint4_t* xs = (const uint4_t*)x;
   uint4_t* cs = (uint4_t*)cols;
-  if (C <= 1280) {
+  // row kernel: needs enough rows to fill the chip and rows short enough that a thread's serial walk stays short
+  // (VAE decoder convolutions at 128^2 .. 512^2 with one image per chunk go to the flat kernel)
+  if (C <= 1280 && W <= 64 && (long)N * H >= 256) {
     hipLaunchKernelGGL(k_im2col3x3, dim3((unsigned)(N * H)), dim3(256), 0, (hipStream_t)stream, xs, cs, H, W, C8,
                        (9 * C8 + 255) / 256);
   } else {

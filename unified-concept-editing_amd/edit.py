@@ -42,7 +42,7 @@ def _f32c(t: torch.Tensor, device: torch.device) -> torch.Tensor:
 
 
 # patch-matrix chunk of the im2col + GEMM convolutions (bytes); UCE_CONV_COLS_MB overrides for measurements
-CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "1024")) << 20
+CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "4096")) << 20
 
 
 class UceHandle:
@@ -245,6 +245,7 @@ class UceHandle:
         y_rows = y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout)     # NHWC view of the same storage
         per_image = Hh * Ww * 9 * Cc * x.element_size()
         step = max(1, min(N, max_cols_bytes // per_image))
+        step = -(-N // -(-N // step))                                 # same number of chunks, evenly sized (no small tail)
         cols = torch.empty((step * Hh * Ww, 9 * Cc), dtype=x.dtype, device=x.device)
         xs = x.permute(0, 2, 3, 1)                                    # [N, H, W, C] view, contiguous
         for n0 in range(0, N, step):
