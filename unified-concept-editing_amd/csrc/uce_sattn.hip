@@ -47,8 +47,10 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 constexpr int KT = 64;            // keys per tile
 
 // V [B, Lk, C] -> Vt [B, H, DVP, LkP]; 64 keys x 64 dims per workgroup through LDS
+// ones_row >= 0: that (padding) row of V^T is set to 1.0 (`one`, in the element type) for the real keys, so the P V
+// product accumulates the softmax denominator in that output row for free (k_sattn's sum_mfma path).
 __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V, unsigned short* __restrict__ Vt, int H,
-                                            int Lk, int dh, int DVP, int LkP) {
+                                            int Lk, int dh, int DVP, int LkP, int ones_row, unsigned short one) {
   __shared__ unsigned short tile[64][66];
   const int b = blockIdx.z / H, h = blockIdx.z % H;
   const int k0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V
       const int key = k0 + kk + 4 * p;
       unsigned short v = 0;
       if (key < Lk && d0 + dv < dh) v = V[((size_t)b * Lk + key) * C + (size_t)h * dh + d0 + dv];
+      if (key < Lk && d0 + dv == ones_row) v = one;
       tile[kk + 4 * p][dv] = v;
     }
   }
@@ -151,6 +154,9 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
     }
   };
 
+  // dh < DVP: row DVP - 1 of V^T is all ones (k_vt), so O^T's last row IS the running softmax denominator - summed
+  // by the matrix core, rescaled with the other rows - and the 32 VALU adds per tile go away.
+  const bool sum_mfma = dh < DVP;
   float m = -INFINITY, lsum = 0.f;          // running max (shared by lane and lane^32), this lane's partial sum
   float16_t oacc[NDV];
 #pragma unroll
@@ -201,16 +207,19 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
     const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first tile
     const float mc = m_new * scale_log2e;
     m = m_new;
-    float ps = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale_log2e, -mc));
-        sacc[j][r] = p;
-        ps += p;
-      }
-    lsum = fmaf(lsum, alpha, ps);
+      for (int r = 0; r < 16; ++r)
+        sacc[j][r] = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale_log2e, -mc));
+    if (!sum_mfma) {
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps += sacc[j][r];
+      lsum = fmaf(lsum, alpha, ps);
+    }
     if (__any(alpha != 1.0f)) {               // the max rarely moves after the first tiles: skip the rescale
 #pragma unroll
       for (int nt = 0; nt < NDV; ++nt)
@@ -244,7 +253,13 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   }
 
   // ---- 1/sum, convert, store: register r of tile nt = output dim nt*32 + (r&3) + 8*(r>>2) + 4*lh
-  const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
+  float denom = lsum + __shfl_xor(lsum, 32);
+  if (sum_mfma) {                           // row DVP - 1 = tile NDV - 1, register 15 of the lh = 1 lanes
+    const float l1 = oacc[NDV - 1][15];
+    const float l0 = __shfl_xor(l1, 32);
+    denom = lh ? l1 : l0;
+  }
+  const float inv = 1.0f / denom;
   unsigned short* orow = O + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
 #pragma unroll
   for (int nt = 0; nt < NDV; ++nt)
@@ -297,8 +312,10 @@ int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o,
                  float scale, int dtype, hipStream_t st) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   const int DVP = sattn_dvp(dh);
+  const int ones_row = dh < DVP ? DVP - 1 : -1;
+  const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   hipLaunchKernelGGL(k_vt, dim3(LkP / 64, (DVP + 63) / 64, B * H), dim3(256), 0, st, (const unsigned short*)v,
-                     (unsigned short*)vt, H, Lk, dh, DVP, LkP);
+                     (unsigned short*)vt, H, Lk, dh, DVP, LkP, ones_row, one);
   UCE_LAUNCH_CHECK();
   if (dh <= 48) return launch_cfg<48>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
   if (dh <= 64) return launch_cfg<64>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
