@@ -158,6 +158,13 @@ int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const vo
  * x[:, :inner] * gelu(x[:, inner:]), bf16 or f16, inner % 8 == 0. */
 int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, int inner, int dtype, uce_stream_t stream);
 
+/* LayerNorm over the last dim of [rows, C] (bf16 or f16, C % 8 == 0, C <= 2560; gamma / beta [C] in the same dtype;
+ * f32 statistics) - the norm1/2/3 of diffusers' BasicTransformerBlock - optionally fused with the residual join in
+ * front of it: when `residual` is given, s = x + residual is rounded to the element type, written to `sum_out`
+ * ([rows, C]) and y = LN(s).  residual and sum_out are both NULL or both set.  UCE_ENOSYS for wider rows. */
+int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const void* gamma, const void* beta, void* y,
+                      void* sum_out, long rows, int C, float eps, int dtype, uce_stream_t stream);
+
 /* Patch matrix of a 3x3 / stride 1 / pad 1 convolution: x [N, H, W, C] (channels-last, 16-bit elements, C % 8 == 0)
  * -> cols [N*H*W, 9*C], column (ky*3 + kx)*C + c, zero outside the image; the convolution is then ONE library GEMM
  * with the channels-last weight viewed as [Cout, 9*C] (1.0-1.3 PF/s in hipBLASLt vs MIOpen's 0.3-0.55 PF/s). */

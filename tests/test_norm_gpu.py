@@ -161,3 +161,57 @@ def test_im2col_patch_matrix_is_bit_exact(H, N, C, Hh, Ww):
     xp = F.pad(x, (0, 0, 1, 1, 1, 1))
     want = torch.cat([xp[:, ky:ky + Hh, kx:kx + Ww, :] for ky in range(3) for kx in range(3)], dim=-1)
     assert torch.equal(cols.view(N, Hh, Ww, 9 * C), want)
+
+
+@pytest.mark.parametrize("rows_shape,C,dtype", [((2, 4096), 320, torch.bfloat16), ((2, 1024), 640, torch.bfloat16),
+                                                ((3, 256), 1280, torch.bfloat16), ((5, 7), 768, torch.float16),
+                                                ((1, 1), 8, torch.bfloat16), ((2, 33), 2560, torch.bfloat16),
+                                                ((4, 9), 200, torch.float16), ((70000,), 64, torch.bfloat16)])
+def test_layernorm_matches_torch_fp64(H, rows_shape, C, dtype):
+    """uce_layernorm_fwd against F.layer_norm in fp64, with and without the fused residual join (whose sum must be
+    the bit-exact rounding torch's own 16-bit add produces)."""
+    g = torch.Generator().manual_seed(C + len(rows_shape))
+    x = (torch.randn(*rows_shape, C, generator=g) * 1.5 + 0.3).to(dtype).cuda()
+    r = torch.randn(*rows_shape, C, generator=g).to(dtype).cuda()
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    b = (0.1 * torch.randn(C, generator=g)).to(dtype).cuda()
+    tol = 4e-3 if dtype == torch.bfloat16 else 6e-4
+    y = H.layernorm(x, w, b, 1e-5)
+    ref = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-5)
+    assert y.shape == x.shape and y.dtype == dtype
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < tol
+    s, y2 = H.layernorm(x, w, b, 1e-5, residual=r)
+    assert torch.equal(s, x + r)
+    ref2 = F.layer_norm((x + r).double(), (C,), w.double(), b.double(), 1e-5)
+    assert O.rel_fro(y2.double().cpu(), ref2.cpu()) < tol
+    # no worse than torch's own 16-bit LayerNorm kernel
+    err_torch = O.rel_fro(F.layer_norm(x, (C,), w, b, 1e-5).double().cpu(), ref.cpu())
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < max(1.5 * err_torch, 1e-4)
+
+
+def test_layernorm_rejects_bad_arguments(H):
+    from uce_amd import lib as L
+    x = torch.zeros(4, 4096, dtype=torch.bfloat16, device="cuda:0")          # C > 2560
+    w = torch.ones(4096, dtype=torch.bfloat16, device="cuda:0")
+    with pytest.raises(L.UceError):
+        H.layernorm(x, w, w, 1e-5)
+    x = torch.zeros(4, 12, dtype=torch.bfloat16, device="cuda:0")            # C % 8 != 0
+    with pytest.raises(L.UceError):
+        H.layernorm(x, w[:12], w[:12], 1e-5)
+
+
+def test_transformer_block_with_hip_layernorm_matches_torch_ops():
+    """BasicTransformerBlock through uce_layernorm_fwd (fused joins) against the same block through nn.LayerNorm."""
+    from uce_amd.sd import unet as U
+    torch.manual_seed(0)
+    blk = U.BasicTransformerBlock(320, 8, 40, 768).to("cuda", torch.bfloat16)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 256, 320, generator=g).bfloat16().cuda()
+    ctx = torch.randn(2, 77, 768, generator=g).bfloat16().cuda()
+    a = blk(x, ctx).float()
+    U.USE_HIP_LAYERNORM = False
+    try:
+        b = blk(x, ctx).float()
+    finally:
+        U.USE_HIP_LAYERNORM = True
+    assert O.rel_fro(a.cpu(), b.cpu()) < 1e-2

@@ -329,3 +329,134 @@ extern "C" int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* 
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
+
+// -------------------------------------------------------------------------------------------------------------
+// LayerNorm forward over the last dim of [rows, C] 16-bit activations (the three norms of a BasicTransformerBlock;
+// diffusers' attention.py, reached from evalscripts/generate-images-sd.py:37-42), optionally fused with the residual
+// join in front of it:  s = x + residual (rounded to the element type, written to sum_out),  y = LN(s) * gamma + beta.
+// torch's vectorized_layer_norm kernel runs these at ~1.2 TB/s on an MI355X and the join is a separate pass.
+//   TPR (8..64, power of two) consecutive lanes share a row, each holding NU 16-byte units (unit index sub + k*TPR),
+//   so a wave streams 64/TPR rows per iteration; mean, then the centred sum of squares, reduced with lane shuffles;
+//   f32 statistics; gamma / beta stay packed in registers for the thread's fixed units.
+// -------------------------------------------------------------------------------------------------------------
+namespace {
+template <int NU, bool F16, bool RES>
+__global__ __launch_bounds__(256) void k_layernorm(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+                                                   const unsigned short* __restrict__ gamma,
+                                                   const unsigned short* __restrict__ beta, unsigned short* __restrict__ y,
+                                                   unsigned short* __restrict__ sum_out, long rows, int C, int tpr, float eps) {
+  const int units = C / 8;
+  const int sub = threadIdx.x & (tpr - 1);
+  const long rpb = 256 / tpr;                                  // rows per workgroup per iteration
+  uint4_t gq[NU], bq[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int u = sub + k * tpr;
+    gq[k] = bq[k] = uint4_t{0u, 0u, 0u, 0u};
+    if (u < units) {
+      gq[k] = *(const uint4_t*)(gamma + u * 8);
+      bq[k] = *(const uint4_t*)(beta + u * 8);
+    }
+  }
+  const float inv_c = 1.0f / (float)C;
+  for (long row = (long)blockIdx.x * rpb + threadIdx.x / tpr; row < rows; row += (long)gridDim.x * rpb) {
+    uint4_t raw[NU], rr[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int u = sub + k * tpr;
+      raw[k] = rr[k] = uint4_t{0u, 0u, 0u, 0u};
+      if (u < units) {
+        raw[k] = *(const uint4_t*)(x + row * C + u * 8);
+        if (RES) rr[k] = *(const uint4_t*)(res + row * C + u * 8);
+      }
+    }
+    float v[NU][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      unpack8<F16>(raw[k], v[k]);
+      if (RES) {
+        float r8[8];
+        unpack8<F16>(rr[k], r8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[k][i] += r8[i];
+        const uint4_t sq = {pack2<F16>(v[k][0], v[k][1]), pack2<F16>(v[k][2], v[k][3]), pack2<F16>(v[k][4], v[k][5]),
+                            pack2<F16>(v[k][6], v[k][7])};
+        if (sub + k * tpr < units) *(uint4_t*)(sum_out + row * C + (sub + k * tpr) * 8) = sq;
+        unpack8<F16>(sq, v[k]);                                // normalise what the next layer will see
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[k][i];                // padding units hold zeros
+    }
+    for (int o = tpr >> 1; o; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+      if (sub + k * tpr < units) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float dlt = v[k][i] - mean;
+          q = fmaf(dlt, dlt, q);
+        }
+      }
+    for (int o = tpr >> 1; o; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * inv_c + eps);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int u = sub + k * tpr;
+      if (u < units) {
+        float g8[8], b8[8], o8[8];
+        unpack8<F16>(gq[k], g8);
+        unpack8<F16>(bq[k], b8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = fmaf((v[k][i] - mean) * rstd, g8[i], b8[i]);
+        const uint4_t oq = {pack2<F16>(o8[0], o8[1]), pack2<F16>(o8[2], o8[3]), pack2<F16>(o8[4], o8[5]), pack2<F16>(o8[6], o8[7])};
+        *(uint4_t*)(y + row * C + u * 8) = oq;
+      }
+    }
+  }
+}
+
+template <int NU>
+void launch_layernorm(const void* x, const void* res, const void* gamma, const void* beta, void* y, void* sum_out, long rows,
+                      int C, int tpr, float eps, int dtype, hipStream_t st) {
+  const long rpb = 256 / tpr;
+  long blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const dim3 grid((unsigned)blocks), block(256);
+  const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res, *gs = (const unsigned short*)gamma,
+                       *bs = (const unsigned short*)beta;
+  unsigned short *ys = (unsigned short*)y, *ss = (unsigned short*)sum_out;
+  const bool f16 = dtype == UCE_DTYPE_F16;
+  if (res) {
+    if (f16) hipLaunchKernelGGL((k_layernorm<NU, true, true>), grid, block, 0, st, xs, rs, gs, bs, ys, ss, rows, C, tpr, eps);
+    else hipLaunchKernelGGL((k_layernorm<NU, false, true>), grid, block, 0, st, xs, rs, gs, bs, ys, ss, rows, C, tpr, eps);
+  } else {
+    if (f16) hipLaunchKernelGGL((k_layernorm<NU, true, false>), grid, block, 0, st, xs, rs, gs, bs, ys, ss, rows, C, tpr, eps);
+    else hipLaunchKernelGGL((k_layernorm<NU, false, false>), grid, block, 0, st, xs, rs, gs, bs, ys, ss, rows, C, tpr, eps);
+  }
+}
+}  // namespace
+
+extern "C" int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const void* gamma, const void* beta,
+                                 void* y, void* sum_out, long rows, int C, float eps, int dtype, uce_stream_t stream) {
+  if (!h || !x || !gamma || !beta || !y || rows <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
+  if ((residual != nullptr) != (sum_out != nullptr)) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  const int units = C / 8;
+  if (units > 64 * 5) return UCE_ENOSYS;                        // C <= 2560
+  int tpr = 8;
+  while ((units + tpr - 1) / tpr > 5) tpr *= 2;
+  const int nu = (units + tpr - 1) / tpr;
+  hipStream_t st = (hipStream_t)stream;
+  switch (nu) {
+    case 1: launch_layernorm<1>(x, residual, gamma, beta, y, sum_out, rows, C, tpr, eps, dtype, st); break;
+    case 2: launch_layernorm<2>(x, residual, gamma, beta, y, sum_out, rows, C, tpr, eps, dtype, st); break;
+    case 3: launch_layernorm<3>(x, residual, gamma, beta, y, sum_out, rows, C, tpr, eps, dtype, st); break;
+    case 4: launch_layernorm<4>(x, residual, gamma, beta, y, sum_out, rows, C, tpr, eps, dtype, st); break;
+    default: launch_layernorm<5>(x, residual, gamma, beta, y, sum_out, rows, C, tpr, eps, dtype, st); break;
+  }
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}

@@ -257,6 +257,19 @@ class UceHandle:
                 else torch.mm(cols[:rows], wmat.t(), out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows])
         return y
 
+    def layernorm(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+                  residual: Optional[torch.Tensor] = None):
+        """LayerNorm over the last dim of a contiguous 16-bit tensor through uce_layernorm_fwd.  With `residual`,
+        returns (x + residual, LN(x + residual)) from one pass; without, LN(x)."""
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        y = torch.empty_like(x)
+        s = torch.empty_like(x) if residual is not None else None
+        _lib.check(self.lib.uce_layernorm_fwd(self._h, _ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(y), _ptr(s),
+                                              rows, Cc, float(eps), dt, _stream_ptr(self.device)), "uce_layernorm_fwd")
+        return y if residual is None else (s, y)
+
     def geglu(self, x: torch.Tensor) -> torch.Tensor:
         """x [..., 2*inner] -> x[..., :inner] * gelu(x[..., inner:]) through uce_geglu_fwd."""
         inner = x.shape[-1] // 2

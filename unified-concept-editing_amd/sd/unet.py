@@ -92,6 +92,33 @@ def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Opti
     return F.silu(y) if silu else y
 
 
+USE_HIP_LAYERNORM = True          # LayerNorm (+ the residual join in front of it) of the transformer blocks
+
+
+def _hip_ln_ok(norm: nn.LayerNorm, x: torch.Tensor) -> bool:
+    return (USE_HIP_LAYERNORM and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+            and norm.elementwise_affine and norm.bias is not None and norm.weight.dtype == x.dtype
+            and len(norm.normalized_shape) == 1 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2560)
+
+
+def layer_norm(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    """`norm(x)`; one HIP launch (uce_layernorm_fwd) for 16-bit activations on a GPU."""
+    if _hip_ln_ok(norm, x):
+        from .. import edit as _edit
+        return _edit.UceHandle.get(x.device).layernorm(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
+def add_layer_norm(norm: nn.LayerNorm, a: torch.Tensor, x: torch.Tensor):
+    """`s = x + a; return s, norm(s)` - the residual join of a transformer block and the norm of the next
+    sub-layer in one pass over the activation."""
+    if _hip_ln_ok(norm, x) and a.shape == x.shape and a.dtype == x.dtype and a.is_contiguous():
+        from .. import edit as _edit
+        return _edit.UceHandle.get(x.device).layernorm(a, norm.weight, norm.bias, norm.eps, residual=x)
+    s = x + a
+    return s, norm(s)
+
+
 USE_HIP_CONV3X3 = True            # 3x3 / stride 1 / pad 1 convolutions as im2col (HIP) + one hipBLASLt GEMM
 
 
@@ -244,9 +271,10 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        x = x + self.attn1(self.norm1(x))
-        x = x + self.attn2(self.norm2(x), context)
-        return x + self.ff(self.norm3(x))
+        y = layer_norm(self.norm1, x)
+        x, y = add_layer_norm(self.norm2, self.attn1(y), x)          # x <- x + attn1(...), y = norm2(x)
+        x, y = add_layer_norm(self.norm3, self.attn2(y, context), x)
+        return x + self.ff(y)
 
 
 class Transformer2DModel(nn.Module):
