@@ -167,8 +167,11 @@ int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const
 
 /* Patch matrix of a 3x3 / stride 1 / pad 1 convolution: x [N, H, W, C] (channels-last, 16-bit elements, C % 8 == 0)
  * -> cols [N*H*W, 9*C], column (ky*3 + kx)*C + c, zero outside the image; the convolution is then ONE library GEMM
- * with the channels-last weight viewed as [Cout, 9*C] (1.0-1.3 PF/s in hipBLASLt vs MIOpen's 0.3-0.55 PF/s). */
-int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, uce_stream_t stream);
+ * with the channels-last weight viewed as [Cout, 9*C] (1.0-1.3 PF/s in hipBLASLt vs MIOpen's 0.3-0.55 PF/s).
+ * upsample = 1: x is [N, H/2, W/2, C] and the patches are those of its 2x nearest-neighbour upsampling (H, W even;
+ * diffusers' Upsample2D = F.interpolate(scale 2, "nearest") + conv) - the upsampled tensor is never written. */
+int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
+                       uce_stream_t stream);
 
 /* e - broadcast of the edited blob over RCCL/xGMI.  `comm` is an ncclComm_t.  librccl is
  * dlopen()ed on first use; returns UCE_ENOSYS when it cannot be loaded. */

@@ -156,7 +156,7 @@ def test_im2col_patch_matrix_is_bit_exact(H, N, C, Hh, Ww):
     g = torch.Generator().manual_seed(C + Ww)
     x = torch.randn(N, Hh, Ww, C, generator=g).to(torch.bfloat16).cuda()
     cols = torch.full((N * Hh * Ww, 9 * C), 7.0, dtype=torch.bfloat16, device="cuda:0")
-    L.check(H.lib.uce_im2col3x3_nhwc(H._h, x.data_ptr(), cols.data_ptr(), N, Hh, Ww, C,
+    L.check(H.lib.uce_im2col3x3_nhwc(H._h, x.data_ptr(), cols.data_ptr(), N, Hh, Ww, C, 0,
                                      torch.cuda.current_stream().cuda_stream), "uce_im2col3x3_nhwc")
     xp = F.pad(x, (0, 0, 1, 1, 1, 1))
     want = torch.cat([xp[:, ky:ky + Hh, kx:kx + Ww, :] for ky in range(3) for kx in range(3)], dim=-1)
@@ -215,3 +215,33 @@ def test_transformer_block_with_hip_layernorm_matches_torch_ops():
     finally:
         U.USE_HIP_LAYERNORM = True
     assert O.rel_fro(a.cpu(), b.cpu()) < 1e-2
+
+
+@pytest.mark.parametrize("N,C,Hs,Ws", [(2, 64, 4, 6), (2, 640, 16, 16), (1, 1920, 3, 2), (1, 128, 40, 72)])
+def test_im2col_with_fused_upsample_is_bit_exact(H, N, C, Hs, Ws):
+    """upsample = 1 gathers the patches of the 2x nearest-neighbour upsampling straight from the half-resolution
+    tensor: must equal the patch matrix of the materialised F.interpolate output, in both kernels."""
+    from uce_amd import lib as L
+    g = torch.Generator().manual_seed(C + Ws)
+    x = torch.randn(N, Hs, Ws, C, generator=g).to(torch.bfloat16).cuda()
+    Hh, Ww = 2 * Hs, 2 * Ws
+    cols = torch.full((N * Hh * Ww, 9 * C), 7.0, dtype=torch.bfloat16, device="cuda:0")
+    L.check(H.lib.uce_im2col3x3_nhwc(H._h, x.data_ptr(), cols.data_ptr(), N, Hh, Ww, C, 1,
+                                     torch.cuda.current_stream().cuda_stream), "uce_im2col3x3_nhwc")
+    xu = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1)
+    xp = F.pad(xu, (0, 0, 1, 1, 1, 1))
+    want = torch.cat([xp[:, ky:ky + Hh, kx:kx + Ww, :] for ky in range(3) for kx in range(3)], dim=-1)
+    assert torch.equal(cols.view(N, Hh, Ww, 9 * C), want)
+    assert H.lib.uce_im2col3x3_nhwc(H._h, x.data_ptr(), cols.data_ptr(), N, 5, 6, C, 1,
+                                    torch.cuda.current_stream().cuda_stream) == L.EINVAL     # odd output height
+
+
+def test_upsample_conv_matches_interpolate_then_conv(H):
+    from uce_amd.sd import unet as U
+    torch.manual_seed(1)
+    up = U.Upsample2D(64).to("cuda", torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(3, 64, 8, 8).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    y = up(x)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), up.conv.weight.float(), up.conv.bias.float(), padding=1)
+    assert y.shape == (3, 64, 16, 16) and y.is_contiguous(memory_format=torch.channels_last)
+    assert O.rel_fro(y.float().cpu(), ref.cpu()) < 6e-3

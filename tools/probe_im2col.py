@@ -35,7 +35,7 @@ for cin, cout, hw in SHAPES:
     ref = None
     for v in variants:
         os.environ["UCE_IM2COL_VARIANT"] = str(v)
-        f = lambda: L.check(H.lib.uce_im2col3x3_nhwc(H._h, xs.data_ptr(), cols.data_ptr(), N, hw, hw, cin,
+        f = lambda: L.check(H.lib.uce_im2col3x3_nhwc(H._h, xs.data_ptr(), cols.data_ptr(), N, hw, hw, cin, 0,
                                                      torch.cuda.current_stream().cuda_stream), "im2col")
         t = timeit(f)
         if ref is None:

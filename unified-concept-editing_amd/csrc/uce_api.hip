@@ -100,7 +100,7 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
 
 extern "C" {
 
-int uce_version(void) { return 103; }
+int uce_version(void) { return 104; }
 
 const char* uce_strerror(int code) {
   switch (code) {

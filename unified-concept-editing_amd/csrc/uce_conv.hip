@@ -17,13 +17,16 @@ typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 // One workgroup per image row (n, y): thread j owns patch-row unit(s) j, j + 256, ... (unit = 16 bytes; tap t = j / C8,
 // channel octet c = j % C8, computed once) and walks the row's pixels - no per-element index divisions, stores
 // contiguous over j, loads contiguous within a tap.
+// up = 1: x is the HALF-resolution tensor [N, H/2, W/2, C] and the patches are those of its 2x nearest-neighbour
+// upsampling (diffusers' Upsample2D = interpolate + conv): the upsampled activation is never materialised.
 __global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x, uint4_t* __restrict__ cols, int H, int W,
-                                                   int C8, int units /* = ceil(9*C8 / 256) */) {
+                                                   int C8, int units /* = ceil(9*C8 / 256) */, int up) {
   const int row16 = 9 * C8;
   const int ny = blockIdx.x;                       // n * H + y
   const int y = ny % H;
   const long n = ny / H;
-  const uint4_t* xn = x + n * H * W * C8;
+  const int Ws = W >> up;
+  const uint4_t* xn = x + n * (H >> up) * Ws * C8;
   uint4_t* out = cols + (long)ny * W * row16;
   for (int k = 0; k < units; ++k) {
     const int j = threadIdx.x + 256 * k;
@@ -31,11 +34,11 @@ __global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x
     const int t = j / C8, c = j - t * C8;
     const int yy = y + t / 3 - 1, dx = t % 3 - 1;
     const bool row_ok = yy >= 0 && yy < H;
-    const uint4_t* src = xn + ((long)(row_ok ? yy : 0) * W) * C8 + c;
+    const uint4_t* src = xn + ((long)((row_ok ? yy : 0) >> up) * Ws) * C8 + c;
     for (int xw = 0; xw < W; ++xw) {
       const int xx = xw + dx;
       uint4_t v = {0u, 0u, 0u, 0u};
-      if (row_ok && xx >= 0 && xx < W) v = src[(long)xx * C8];
+      if (row_ok && xx >= 0 && xx < W) v = src[(long)(xx >> up) * C8];
       __builtin_nontemporal_store(v, out + (long)xw * row16 + j);     // streamed: the GEMM reads it back once
     }
   }
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void k_im2col3x3(const uint4_t* __restrict__ x
 // own many units) it keeps more stores in flight: 4.3-4.9 TB/s there against 3.6-4.1 (tools/probe_im2col.py); it
 // also takes the few-rows / long-rows cases (VAE decoder, tiny batches) where the row kernel cannot fill the chip.
 __global__ __launch_bounds__(256) void k_im2col3x3_flat(const uint4_t* __restrict__ x, uint4_t* __restrict__ cols, int N,
-                                                        int H, int W, int C8) {
+                                                        int H, int W, int C8, int up) {
   const long total = (long)N * H * W * 9 * C8;
   const int row16 = 9 * C8;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -60,16 +63,19 @@ __global__ __launch_bounds__(256) void k_im2col3x3_flat(const uint4_t* __restric
     const long n = q / H;
     const int yy = y + t / 3 - 1, xx = xw + t % 3 - 1;
     uint4_t v = {0u, 0u, 0u, 0u};
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((n * H + yy) * W + xx) * C8 + c];
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((n * (H >> up) + (yy >> up)) * (W >> up) + (xx >> up)) * C8 + c];
     __builtin_nontemporal_store(v, cols + e);
   }
 }
 
 }  // namespace
 
-extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C,
+extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
                                   uce_stream_t stream) {
   if (!h || !x || !cols || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
+  if (upsample != 0 && upsample != 1) return UCE_EINVAL;
+  if (upsample && ((H | W) & 1)) return UCE_EINVAL;
+  const int up = upsample;
   const int C8 = C / 8;
   const uint4_t* xs = (const uint4_t*)x;
   uint4_t* cs = (uint4_t*)cols;
@@ -77,12 +83,12 @@ extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int
   // (VAE decoder convolutions at 128^2 .. 512^2 with one image per chunk go to the flat kernel)
   if (C <= 1280 && W <= 64 && (long)N * H >= 256) {
     hipLaunchKernelGGL(k_im2col3x3, dim3((unsigned)(N * H)), dim3(256), 0, (hipStream_t)stream, xs, cs, H, W, C8,
-                       (9 * C8 + 255) / 256);
+                       (9 * C8 + 255) / 256, up);
   } else {
     const long total = (long)N * H * W * 9 * C8;
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(k_im2col3x3_flat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xs, cs, N, H, W, C8);
+    hipLaunchKernelGGL(k_im2col3x3_flat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xs, cs, N, H, W, C8, up);
   }
   UCE_LAUNCH_CHECK();
   return UCE_OK;

@@ -234,11 +234,13 @@ class UceHandle:
         return y
 
     def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                     max_cols_bytes: int = CONV_COLS_BYTES) -> torch.Tensor:
+                     max_cols_bytes: int = CONV_COLS_BYTES, upsample: bool = False) -> torch.Tensor:
         """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor: patch matrix through
         uce_im2col3x3_nhwc, then ONE library GEMM (F.linear -> hipBLASLt) against the channels-last weight viewed as
-        [Cout, 9*C].  The batch is walked in chunks whose patch matrix stays under `max_cols_bytes`."""
-        N, Cc, Hh, Ww = x.shape
+        [Cout, 9*C].  The batch is walked in evenly sized chunks whose patch matrix stays under `max_cols_bytes`.
+        upsample: convolve the 2x nearest-neighbour upsampling of x (output [N, Cout, 2H, 2W]) without materialising it."""
+        N, Cc, Hs, Ws = x.shape
+        Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         Cout = weight.shape[0]
         wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -250,7 +252,7 @@ class UceHandle:
         xs = x.permute(0, 2, 3, 1)                                    # [N, H, W, C] view, contiguous
         for n0 in range(0, N, step):
             nb = min(step, N - n0)
-            _lib.check(self.lib.uce_im2col3x3_nhwc(self._h, xs[n0].data_ptr(), _ptr(cols), nb, Hh, Ww, Cc,
+            _lib.check(self.lib.uce_im2col3x3_nhwc(self._h, xs[n0].data_ptr(), _ptr(cols), nb, Hh, Ww, Cc, int(upsample),
                                                    _stream_ptr(self.device)), "uce_im2col3x3_nhwc")
             rows = nb * Hh * Ww
             torch.addmm(bias, cols[:rows], wmat.t(), out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows]) if bias is not None \

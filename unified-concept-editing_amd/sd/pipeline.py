@@ -29,7 +29,7 @@ from .scheduler import PNDMScheduler
 # ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
 # batch 2 (48 ms average over 384 calls in profiles/r01), far more at larger batches.  It never wins.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
-from .unet import UNet2DConditionModel, UNetConfig, conv2d, group_norm_act
+from .unet import UNet2DConditionModel, UNetConfig, conv2d, group_norm_act, upsample2x_conv
 
 MAX_LEN = 77
 BOS, EOS = 49406, 49407
@@ -134,7 +134,7 @@ class _UpConv(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
-        return conv2d(self.conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return upsample2x_conv(self.conv, x)
 
 
 class _VaeMid(nn.Module):

@@ -144,6 +144,15 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Te
     return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+def upsample2x_conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """`conv(F.interpolate(x, scale_factor=2, mode="nearest"))` (diffusers' Upsample2D); on the HIP path the patch
+    matrix is gathered straight from the half-resolution tensor, the upsampled activation is never written."""
+    if _conv3x3_fast_ok(conv, x):
+        from .. import edit as _edit
+        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, conv.bias, upsample=True)
+    return conv2d(conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
 def conv_nobias(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """The convolution WITHOUT its bias (the callers fold it into the next fused kernel)."""
     return conv2d(conv, x, with_bias=False)
@@ -311,7 +320,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
-        return conv2d(self.conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return upsample2x_conv(self.conv, x)
 
 
 class DownBlock(nn.Module):
