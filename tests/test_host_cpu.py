@@ -194,3 +194,15 @@ def test_hidream_module_predicate_embeddings_and_cli():
         assert np.allclose(v.numpy(), text.family_embedding("Van Gogh", name))
     a = cli.parse_hidream_args(["--edit_concepts", "Van Gogh", "--concept_type", "art"])
     assert a.model_id == "HiDream-ai/HiDream-I1-Full" and cli.HIDREAM_MAX_SEQUENCE_LENGTH == 128
+
+
+def test_even_chunk_respects_cap_and_balances():
+    from uce_amd.edit import even_chunk
+    for n in range(1, 70):
+        for cap in (0, 1, 2, 3, 7, 15, 22, 32, 100):
+            step = even_chunk(n, cap)
+            sizes = [min(step, n - i) for i in range(0, n, step)]
+            assert sum(sizes) == n and max(sizes) <= max(1, min(n, cap))
+            assert len(sizes) == -(-n // max(1, min(n, cap)))          # no more chunks than the cap forces
+            assert max(sizes) - min(sizes) <= len(sizes)                 # evenly sized: no small tail
+    assert even_chunk(32, 15) == 11 and even_chunk(32, 22) == 16 and even_chunk(32, 64) == 32

@@ -45,6 +45,14 @@ def _f32c(t: torch.Tensor, device: torch.device) -> torch.Tensor:
 CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "4096")) << 20
 
 
+def even_chunk(n: int, cap: int) -> int:
+    """Chunk length for walking `n` items at most `cap` at a time: the fewest chunks that respect the cap, evenly
+    sized (32 items, cap 15 -> 11 + 11 + 10 rather than 15 + 15 + 2; a small tail launch cannot fill the chip)."""
+    cap = max(1, min(n, cap))
+    chunks = -(-n // cap)
+    return -(-n // chunks)
+
+
 class UceHandle:
     """One per GPU.  Owns the library workspace (uce_create / uce_destroy)."""
 
@@ -246,8 +254,7 @@ class UceHandle:
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         y_rows = y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout)     # NHWC view of the same storage
         per_image = Hh * Ww * 9 * Cc * x.element_size()
-        step = max(1, min(N, max_cols_bytes // per_image))
-        step = -(-N // -(-N // step))                                 # same number of chunks, evenly sized (no small tail)
+        step = even_chunk(N, max_cols_bytes // per_image)
         cols = torch.empty((step * Hh * Ww, 9 * Cc), dtype=x.dtype, device=x.device)
         xs = x.permute(0, 2, 3, 1)                                    # [N, H, W, C] view, contiguous
         for n0 in range(0, N, step):
