@@ -272,7 +272,9 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   if (rc) return rc;
   static const int no_split = getenv("UCE_NO_SPLIT") ? atoi(getenv("UCE_NO_SPLIT")) : 0;
   if (!no_split && N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
-    // N <= 128: THREE launches on the caller's stream, no events:
+    // N <= 128: THREE launches on the caller's stream, no events (forking the Gram -> Cholesky -> solve chain onto a
+    // side stream beside a rider-less projection was measured at 105 us against 70: the two cross-stream event
+    // waits cost more than the overlap buys):
     //   1 projection T = W_old (G - C_e)^T   ||   rider blocks of the same launch: K = lambda S^-1 + C C^T and
     //     its (blocked) Cholesky + block inverses (hidden under the GEMM)
     //   2 triangular solves -> R     3 update W_new = W_old + T R
@@ -288,7 +290,8 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
       size_t slab_stride = 0;
       rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, nullptr, nullptr, 0, &nsplit, &slab_stride, st);
       if (rc) return rc;
-      rc = launch_potrf(h, h->M, n_pad, st);
+      rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
+                        : launch_potrf(h, h->M, n_pad, st);
       if (rc) return rc;
       rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st);
       if (rc) return rc;
