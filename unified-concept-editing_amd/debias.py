@@ -15,7 +15,7 @@ all-reduced; the closed-form solve is replicated (it is < 1 ms; "replicas only")
 from __future__ import annotations
 
 import time
-from typing import Callable, List, Sequence
+from typing import Callable, Sequence
 
 import numpy as np
 import torch

@@ -11,14 +11,12 @@ the reference itself) and the cross-attention kernel (torch SDPA goldens).
 """
 from __future__ import annotations
 
-import json
 import math
 import os
 import zlib
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn

@@ -15,8 +15,8 @@ the C ABI when the module lives on a GPU in bf16/f16; everything else is stock t
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
