@@ -4,17 +4,32 @@ projections (BASELINE.json configs[1]: erase 50 concepts, d = 768, 32 modules = 
 fp32 slab), inputs resident in HBM.  One "step" = one full pass of the hot path
 (Gram -> SPD solve -> weight update for every module) = one `uce_edit` call.
 
-  python bench.py --gpus 1 --steps 50 --warmup 5
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W
 
-The edit does not shard ("replicas only"): with N > 1 every rank edits its own
-replica and `value` is the aggregate over ranks.  Prints ONE JSON line on rank 0.
+With N > 1 and no WORLD_SIZE in the environment the script launches itself under
+`torch.distributed.run` (one rank per GPU, RCCL); launched by torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE as usual.  The edit does not shard ("replicas only"):
+every rank edits its own replica and `value` is the aggregate over ranks; the secondary
+`generate` leg (images/s) does shard - rank r generates its own prompts after ONE RCCL broadcast of
+the edited weights.  Prints ONE JSON line on rank 0.
+
+The line carries, beside the driver's keys:
+  roofline       the kernel of the step with the LARGEST time share (per-kernel durations measured live with HIP
+                 events on the launch stream, uce_profile_begin/_end), every other kernel of the step under
+                 `kernels`, and the step-level figures `step_frac` (roofline floor / measured step) and
+                 `step_traffic_ratio` (PMC HBM bytes of all kernels / algorithmic bytes of the step)
+  configs        the other single-GPU BASELINE configs (0: 2 erase + 3 preserve, 2: 1000 + 500, 3: the SDXL slab)
+  generate       images/s of the edited pipeline (BASELINE's second metric), xattn / sattn: the attention kernels alone
+  cpu_baseline   the reference's op order on the host cores (oracle, torch CPU)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,21 +41,28 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak
-BF16_MFMA_PEAK_TF = 2500.0    # dense bf16 MFMA peak (no sparsity)
+F64_MFMA_PEAK_TF = 78.6      # dense f64 MFMA peak
+BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak (no sparsity)
+CPU_BASELINE_THREADS = 4     # fixed (measured fastest for the reference's many small ops on the GPU box's EPYC host)
 
 WORKLOADS = {
-    # name: (N_edit, N_preserve, d, module table)
-    "sd14_erase50": (50, 0, 768, "sd14"),
-    "sd14_erase2p3": (2, 3, 768, "sd14"),
-    "sd14_erase100": (100, 0, 768, "sd14"),
-    "sd14_erase1000p500": (1000, 500, 768, "sd14"),
-    "sdxl_debias36x2": (36, 0, 2048, "sdxl"),
+    # name: (N_edit, N_preserve, d, module table, BASELINE.json config index)
+    "sd14_erase50": (50, 0, 768, "sd14", 1),
+    "sd14_erase2p3": (2, 3, 768, "sd14", 0),
+    "sd14_erase100": (100, 0, 768, "sd14", None),
+    "sd14_erase1000p500": (1000, 500, 768, "sd14", 2),
+    "sdxl_debias36x2": (36, 0, 2048, "sdxl", 3),
 }
+CONFIG_LEGS = ("sd14_erase2p3", "sd14_erase1000p500", "sdxl_debias36x2")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
 
 
 def make_inputs(name: str, device):
     from uce_amd import synth as O
-    n_e, n_p, d, table = WORKLOADS[name]
+    n_e, n_p, d, table, _ = WORKLOADS[name]
     mods = O.sd14_module_table() if table == "sd14" else O.sdxl_module_table()
     rows = sum(o for _, o in mods)
     N = n_e + n_p
@@ -51,18 +73,35 @@ def make_inputs(name: str, device):
     C = torch.from_numpy(emb[:N]).to(device)
     G = torch.from_numpy(np.repeat(emb[N:N + 1], n_e, axis=0)).to(device)
     s = torch.ones(N, dtype=torch.float32, device=device)
-    return dict(C=C, G=G, s=s, W=W, mods=mods, rows=rows, d=d, n_e=n_e, n_p=n_p, emb=emb)
+    return dict(C=C, G=G, s=s, W=W, mods=mods, rows=rows, d=d, n_e=n_e, n_p=n_p, emb=emb, name=name)
 
 
 def _log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(inp, budget_s: float = 12.0):
-    """The oracle (the reference's own op order on torch CPU: sequential rank-1 fp32 updates,
-    torch.inverse and a GEMM per module) timed on the host cores.  Bounded sample: modules are
-    timed one at a time (round-robin over the three width classes) until ~budget_s seconds are
-    spent; the whole-edit time is the sum over all modules of their class's mean time."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores() -> int:
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or 0)
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def cpu_baseline(inp, repeats: int = 5):
+    """The oracle (the reference's own op order on torch CPU: sequential rank-1 fp32 updates, torch.inverse and a
+    GEMM per module, uce_sd_erase.py:56-82) timed on the host cores: WHOLE edits of all modules, a fixed thread
+    count, the median of `repeats` runs after one untimed run (bounded sample: ~1.5 s per whole 50-concept edit)."""
     from oracle import uce_oracle as O
     Wc = inp["W"].cpu()
     ws, off = [], 0
@@ -74,48 +113,215 @@ def cpu_baseline(inp, budget_s: float = 12.0):
     edit = [C[i:i + 1] for i in range(n_e)]
     guide = [G[i:i + 1] for i in range(n_e)]
     pres = [C[n_e + i:n_e + i + 1] for i in range(n_p)]
+    ncpu = os.cpu_count() or 1
+    threads = min(CPU_BASELINE_THREADS, ncpu)
+    torch.set_num_threads(threads)
 
-    def one(w):
+    def whole():
         t = time.perf_counter()
-        O.uce_edit_ref([w], edit, guide, pres, 1.0, 1.0, 0.5)
+        O.uce_edit_ref(ws, edit, guide, pres, 1.0, 1.0, 0.5)
         return time.perf_counter() - t
 
-    # thread count: the reference would run with torch's default; many tiny ops do not scale
-    # to a 100+ core host, so calibrate on one module and keep the fastest setting
-    ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (4, 8, 16, 32) if c <= ncpu})
-    best, best_t = cands[0], float("inf")
-    for c in cands:
-        torch.set_num_threads(c)
-        one(ws[0])
-        t = one(ws[0])
-        _log(f"cpu baseline calibration: {c} threads -> {t * 1e3:.1f} ms / module")
-        if t < best_t:
-            best, best_t = c, t
-    torch.set_num_threads(best)
-    classes = {}
-    for i, w in enumerate(ws):
-        classes.setdefault(w.shape[0], []).append(i)
-    times = {k: [] for k in classes}
-    t0, rr = time.perf_counter(), 0
-    keys = sorted(classes)
-    while time.perf_counter() - t0 < budget_s or min(len(v) for v in times.values()) < 1:
-        k = keys[rr % len(keys)]
-        idx = classes[k][(rr // len(keys)) % len(classes[k])]
-        times[k].append(one(ws[idx]))
-        rr += 1
-        if rr >= 30 * len(ws):
+    whole()
+    times = []
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        times.append(whole())
+        if time.perf_counter() - t0 > 30.0 and len(times) >= 3:
             break
-    el = time.perf_counter() - t0
-    whole = sum(len(classes[k]) * (sum(times[k]) / len(times[k])) for k in keys)
+    med = statistics.median(times)
     n = n_e + n_p
-    return dict(value=round(n / whole, 2), unit="concepts/s", cores=best, kind="port",
-                sample=f"{rr} single-module edits ({', '.join(f'{len(times[k])}x o={k}' for k in keys)}) of the "
-                       f"{n}-concept workload in {el:.1f} s on {best} of {ncpu} host threads; whole edit "
-                       f"({len(ws)} modules) = {whole:.3f} s extrapolated per width class")
+    return dict(value=round(n / med, 2), unit="concepts/s", cores=threads, kind="port",
+                cpu=cpu_model(), physical_cores=physical_cores(), logical_cpus=ncpu,
+                seconds_per_edit=dict(median=round(med, 4), min=round(min(times), 4), max=round(max(times), 4)),
+                sample=f"{len(times)} whole edits (all {len(ws)} modules, {n} concepts) after one untimed run, median "
+                       f"{med:.3f} s, on {threads} torch threads of {ncpu} logical CPUs")
 
 
-def generation_leg(device, world, n_images, steps, edited_slab, inp, batch=8):
+# ------------------------------------------------------------------------------------------------------------
+# the edit: timed region, per-kernel breakdown, roofline
+# ------------------------------------------------------------------------------------------------------------
+
+def edit_path(N: int, n_e: int, d: int, rows: int, algo: int) -> str:
+    """Which kernel chain uce_edit takes (mirrors csrc/uce_api.hip:uce_edit)."""
+    dual = (algo == 2) or (algo == 0 and round_up(N, 64) < d)
+    if not dual:
+        return "primal"
+    if 1 <= n_e <= 256 and d in (768, 1024, 2048) and rows >= 1024:
+        return "dual_lowrank"
+    return "dual_other"
+
+
+def step_floor(path: str, N: int, n_e: int, d: int, rows: int):
+    """Algorithmic work of one step in its minimal formulation -> (bytes, f32 flop, f64 flop, floor ms)."""
+    q = 4.0 * (N + n_e) * d + 8.0 * rows * d
+    if path == "primal":
+        f32 = 2.0 * rows * d * d
+        f64 = (N + 2.0 * n_e) * d * d + (7.0 / 3.0) * d ** 3
+    else:
+        n = round_up(N, 64)
+        f32 = 4.0 * rows * d * n_e
+        f64 = 1.0 * N * N * d + n ** 3 / 3.0 + 2.0 * n * n * d
+    floor_s = max(q / (HBM_PEAK_GBS * 1e9), f32 / (F32_MFMA_PEAK_TF * 1e12) + f64 / (F64_MFMA_PEAK_TF * 1e12))
+    return q, f32, f64, floor_s * 1e3
+
+
+def kernel_model(name: str, path: str, N: int, n_e: int, d: int, rows: int):
+    """(bound, algorithmic work per launch, peak, unit, note) of one kernel of the step."""
+    nep, n_sys = round_up(max(n_e, 1), 64), (d if path == "primal" else round_up(N, 64))
+    if name == "k_lr_project":
+        return "mfma", 2.0 * rows * d * n_e, F32_MFMA_PEAK_TF, "TFLOP/s", f"f32 MFMA; issues 2*rows*d*{nep} flop on the 64-padded concept tile"
+    if name in ("k_lr_update_s", "k_lr_update"):
+        return "hbm", 8.0 * rows * d + 4.0 * rows * nep + 4.0 * n_e * d, HBM_PEAK_GBS, "GB/s", "W in + W out, T in, R once"
+    if name == "k_lr_fused":
+        return "hbm", 8.0 * rows * d + 8.0 * n_e * d, HBM_PEAK_GBS, "GB/s", "W in + W out; 4*rows*d*N_e f32 flop ride along"
+    if name == "k_trisolve":
+        return "mfma", 2.0 * n_sys * n_sys * d, F64_MFMA_PEAK_TF, "TFLOP/s", "f64 MFMA, forward + backward substitution"
+    if name == "potrf":
+        return "mfma", n_sys ** 3 / 3.0, F64_MFMA_PEAK_TF, "TFLOP/s", "f64 blocked Cholesky launch chain (latency chain of n pivots)"
+    if name == "k_gram_primal":
+        return "mfma", (N + 2.0 * n_e) * d * d, F64_MFMA_PEAK_TF, "TFLOP/s", "f64 MFMA, lower tiles of A + all of Bt"
+    if name == "k_gram_dual":
+        return "mfma", 1.0 * N * N * d, F64_MFMA_PEAK_TF, "TFLOP/s", "f64 MFMA, lower tiles"
+    if name == "k_apply_b3":
+        return "mfma", 6.0 * 2.0 * rows * d * d, BF16_MFMA_PEAK_TF, "TFLOP/s", "bf16 MFMA, six partial products per fp32-equivalent product (2*rows*d^2 fp32-equivalent flop)"
+    if name == "k_apply":
+        return "mfma", 2.0 * rows * d * d, F32_MFMA_PEAK_TF, "TFLOP/s", "f32 MFMA"
+    if name == "k_split3":
+        return "hbm", 10.0 * d * d, HBM_PEAK_GBS, "GB/s", "Delta^T f32 in, three bf16 planes out"
+    if name == "k_delta_factors":
+        return "mfma", 2.0 * n_e * d * d, F32_MFMA_PEAK_TF, "TFLOP/s", "f32 MFMA"
+    if name == "k_apply_lowrank_generic":
+        return "hbm", 8.0 * rows * d + 8.0 * n_e * d, HBM_PEAK_GBS, "GB/s", "W in + W out"
+    return "hbm", 0.0, HBM_PEAK_GBS, "GB/s", "unmodelled"
+
+
+def load_traffic():
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+def kernel_breakdown(H, inp, algo: int, step, iters: int = 30):
+    """Per-kernel average duration of the launches of one step (HIP events on the launch stream around every launch,
+    recorded by the library itself: uce_profile_begin/_end), each priced against its own roofline."""
+    N, d, rows, n_e = inp["C"].shape[0], inp["d"], inp["rows"], inp["n_e"]
+    path = edit_path(N, n_e, d, rows, algo)
+    prof = H.profile(step, iters)
+    traffic = load_traffic().get(inp["name"], {})
+    total = sum(ms * cnt for ms, cnt in prof.values()) or 1.0
+    rows_out = []
+    for name, (ms, cnt) in prof.items():
+        kname = "k_lr_update_s" if (name == "k_lr_update" and n_e <= 128) else name
+        bound, work, peak, unit, note = kernel_model(kname, path, N, n_e, d, rows)
+        ach = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12) if ms > 0 else 0.0
+        ent = dict(kernel=kname, launches_per_step=cnt, avg_ms=round(ms, 5), share=round(ms * cnt / total, 4), bound=bound,
+                   achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                   **({"algorithmic_bytes": work} if bound == "hbm" else {"algorithmic_flops": work}), note=note)
+        t = traffic.get(kname)
+        ent["traffic"] = t.get("total_bytes") if isinstance(t, dict) else None
+        if isinstance(t, dict) and t.get("mfma_util") is not None:
+            ent["mfma_util"] = t["mfma_util"]
+        rows_out.append(ent)
+    rows_out.sort(key=lambda e: -e["share"])
+    return path, rows_out, total
+
+
+def time_steps(step, steps: int, world: int, device):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides (wall clock, max over ranks) and, inside the
+    same region, HIP events on the launch stream (sub-100-us steps: the events exclude the host-side sync latency)."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev = e0.elapsed_time(e1) * 1e-3
+    if world > 1:
+        t = torch.tensor([elapsed, ev], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed, ev = float(t[0].item()), float(t[1].item())
+    return elapsed, ev
+
+
+def run_edit(H, name: str, device, steps: int, warmup: int, algo: int, world: int = 1, breakdown: bool = True):
+    inp = make_inputs(name, device)
+    C, G, s, W = inp["C"], inp["G"], inp["s"], inp["W"]
+    N, d, rows, n_e = C.shape[0], inp["d"], inp["rows"], inp["n_e"]
+    out = torch.empty_like(W)
+    H.reserve(d, max(N, d))
+    H.reserve_rows(rows, max(n_e, 1))
+
+    def step():
+        H.edit(C, G, s, 0.5, W, out=out, algo=algo)
+
+    _log(f"{name}: inputs ready (N={N} d={d} rows={rows}); warm-up")
+    for _ in range(warmup):
+        step()
+    H.status()
+    elapsed, ev = time_steps(step, steps, world, device)
+    H.status()
+    ms = 1e3 * elapsed / steps
+    _log(f"{name}: {ms:.4f} ms/step (wall), {1e3 * ev / steps:.4f} ms/step (events)")
+    res = dict(inp=inp, out=out, elapsed=elapsed, ms_per_step=ms, ms_per_step_events=1e3 * ev / steps, N=N)
+    if breakdown:
+        path, kernels, _ = kernel_breakdown(H, inp, algo, step)
+        q, f32, f64, floor_ms = step_floor(path, N, n_e, d, rows)
+        tr = [k["traffic"] for k in kernels]
+        res.update(path=path, kernels=kernels, floor_ms=floor_ms, alg_bytes=q, alg_f32=f32, alg_f64=f64,
+                   traffic=sum(tr) if tr and all(t is not None for t in tr) else None)
+    return res
+
+
+def roofline_block(r):
+    """`roofline` of the JSON line: the kernel with the largest time share on top, the rest under `kernels`."""
+    top = dict(r["kernels"][0])
+    step_ms = r["ms_per_step_events"]
+    top.update(kernels=r["kernels"][1:], path=r["path"],
+               step_floor_ms=round(r["floor_ms"], 5), step_frac=round(r["floor_ms"] / step_ms, 4),
+               step_algorithmic_bytes=r["alg_bytes"], step_algorithmic_flops={"f32": r["alg_f32"], "f64": r["alg_f64"]},
+               step_traffic=r["traffic"],
+               step_traffic_ratio=round(r["traffic"] / r["alg_bytes"], 3) if r["traffic"] else None,
+               traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950), bytes per "
+                              "launch (profiles/traffic.json <- tools/pmc_fold.py); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / "
+                              "(32 * SQ_BUSY_CYCLES)")
+    return top
+
+
+def config_leg(H, name: str, device, algo: int):
+    n_e, n_p, d, _, idx = WORKLOADS[name]
+    steps = 20 if name != "sd14_erase2p3" else 50
+    r = run_edit(H, name, device, steps, 3, algo)
+    k0 = r["kernels"][0]
+    out = dict(baseline_config=idx, workload=name, concepts=n_e + n_p, d=d, rows=r["inp"]["rows"],
+               ms_per_step=round(r["ms_per_step"], 5), ms_per_step_events=round(r["ms_per_step_events"], 5),
+               concepts_per_s=round((n_e + n_p) / (r["ms_per_step_events"] * 1e-3), 1), path=r["path"],
+               step_floor_ms=round(r["floor_ms"], 5), step_frac=round(r["floor_ms"] / r["ms_per_step_events"], 4),
+               dominant=dict(kernel=k0["kernel"], avg_ms=k0["avg_ms"], share=k0["share"], bound=k0["bound"],
+                             achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"]),
+               kernels=[dict(kernel=k["kernel"], avg_ms=k["avg_ms"], launches_per_step=k["launches_per_step"], share=k["share"],
+                             frac=k["frac"], bound=k["bound"], traffic=k["traffic"], **({"mfma_util": k["mfma_util"]} if "mfma_util" in k else {}))
+                        for k in r["kernels"]])
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# generation and attention legs
+# ------------------------------------------------------------------------------------------------------------
+
+def generation_leg(device, world, n_images, steps, edited_slab, batch=8):
     """Secondary figure (BASELINE.json's second metric): images/s of the edited SD-1.4 pipeline,
     512x512, `steps` PNDM steps (+1 U-Net call), guidance 7.5, bf16, CPU-seeded latents, synthetic
     (seeded-random) weights, cross-attention through uce_xattn_fwd.  Every rank generates its own
@@ -125,10 +331,15 @@ def generation_leg(device, world, n_images, steps, edited_slab, inp, batch=8):
     from uce_amd import edit as E
     _log("generation leg: building the synthetic SD-1.4 pipeline")
     pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.bfloat16, device, synthetic=True, vae=True)
+    bcast_ms = None
     if edited_slab is not None:
         blob = edited_slab.clone()
         if world > 1:
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
             torch.distributed.broadcast(blob, src=0)          # RCCL over xGMI: the one exchange step
+            torch.cuda.synchronize()
+            bcast_ms = 1e3 * (time.perf_counter() - tb)
         mods = E.collect_uce_modules(pipe.unet)
         off = 0
         state = {}
@@ -178,55 +389,76 @@ def generation_leg(device, world, n_images, steps, edited_slab, inp, batch=8):
     if failure is not None:
         _log("generation leg failed: " + failure)
         return {"metric": "images/sec 512x512 50-step", "value": None, "error": failure, "n_gpus": world}
-    return {"metric": "images/sec 512x512 50-step", "value": round(world * n_images / el, 4), "unit": "images/s",
-            "n_gpus": world, "images_per_rank": n_images, "prompts_per_unet_call": batch, "steps": steps, "dtype": "bf16",
-            "scaling": "weak",
-            "data": "synthetic weights, synthetic prompts, CPU-seeded latents", "seconds": round(el, 3)}
+    out = {"metric": "images/sec 512x512 50-step", "value": round(world * n_images / el, 4), "unit": "images/s",
+           "n_gpus": world, "images_per_rank": n_images, "prompts_per_unet_call": batch, "steps": steps, "dtype": "bf16",
+           "scaling": "weak",
+           "data": "synthetic weights, synthetic prompts, CPU-seeded latents", "seconds": round(el, 3)}
+    if bcast_ms is not None:
+        out["weight_broadcast_ms"] = round(bcast_ms, 3)
+    return out
 
 
-def xattn_leg(device, batches=(2, 16)):
+XATTN_SHAPES = ((4096, 40), (1024, 80), (256, 160), (64, 160))
+
+
+def xattn_leg(device, batches=(2, 16), iters: int = 100):
     """Cross-attention kernel alone at SD-1.4's four attn2 shapes (H = 8, Lk = 77, bf16) at B = 2 (the CFG pair
     of one prompt) and at the batch the generation leg runs (2 x prompts per U-Net call): algorithmic bytes =
     Q + O + K + V once, per launch, vs the HBM peak."""
     from uce_amd import edit as E
     H = E.UceHandle.get(device)
+    traffic = load_traffic().get("xattn", {})
     out = []
     for B in batches:
-        for Lq, dh in ((4096, 40), (1024, 80), (256, 160), (64, 160)):
+        for Lq, dh in XATTN_SHAPES:
             C = 8 * dh
             q = torch.randn(B, Lq, C, device=device).bfloat16()
             k = torch.randn(B, 77, C, device=device).bfloat16()
             v = torch.randn_like(k)
             o = torch.empty_like(q)
-            ms = time_kernel(lambda: H.xattn(q, k, v, 8, out=o), 100)
+            ms = time_kernel(lambda: H.xattn(q, k, v, 8, out=o), iters)
             byts = 2.0 * (B * Lq * C * 2) + 2.0 * (B * 77 * C * 2)
-            out.append({"B": B, "Lq": Lq, "dh": dh, "avg_us": round(ms * 1e3, 2), "bytes": byts,
-                        "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1),
-                        "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            ent = {"B": B, "Lq": Lq, "dh": dh, "avg_us": round(ms * 1e3, 2), "bytes": byts,
+                   "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1),
+                   "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            t = traffic.get(f"B{B}_Lq{Lq}_dh{dh}")
+            if isinstance(t, dict):
+                ent["traffic"] = t.get("total_bytes")
+                if t.get("mfma_util") is not None:
+                    ent["mfma_util"] = t["mfma_util"]
+            out.append(ent)
     return {"kernel": "k_xattn", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shapes": out,
             "note": "B = 2 launches move 1.4-10.7 MB each (launch/latency-bound); the batched rows are the ones "
                     "the generation leg issues"}
 
 
-def sattn_leg(device, B):
+def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
     """Self-attention kernel (attn1 of the U-Net, uce_sattn_fwd) at SD-1.4's four shapes and the generation batch,
     beside torch's scaled_dot_product_attention on the same tensors; 4*B*H*L^2*dh flop per call vs the dense bf16
     MFMA peak (the loop is VALU-bound on the online softmax, not MFMA-bound)."""
     import torch.nn.functional as F
     from uce_amd import edit as E
     H = E.UceHandle.get(device)
+    traffic = load_traffic().get("sattn", {})
     out = []
-    for L, dh in ((4096, 40), (1024, 80), (256, 160), (64, 160)):
+    for L, dh in XATTN_SHAPES:
         C = 8 * dh
         q = torch.randn(B, L, C, device=device).bfloat16()
         k, v = torch.randn_like(q), torch.randn_like(q)
         o = torch.empty_like(q)
-        ms = time_kernel(lambda: H.sattn(q, k, v, 8, out=o), 10)
-        sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)
-        ms_t = time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), 10)
+        ms = time_kernel(lambda: H.sattn(q, k, v, 8, out=o), iters)
         fl = 4.0 * B * 8 * L * L * dh
-        out.append({"B": B, "L": L, "dh": dh, "avg_us": round(ms * 1e3, 1), "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
-                    "frac": round(fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4), "torch_sdpa_us": round(ms_t * 1e3, 1)})
+        ent = {"B": B, "L": L, "dh": dh, "avg_us": round(ms * 1e3, 1), "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
+               "frac": round(fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4)}
+        if with_torch:
+            sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)  # noqa: E731
+            ent["torch_sdpa_us"] = round(time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), iters) * 1e3, 1)
+        t = traffic.get(f"B{B}_L{L}_dh{dh}")
+        if isinstance(t, dict):
+            ent["traffic"] = t.get("total_bytes")
+            if t.get("mfma_util") is not None:
+                ent["mfma_util"] = t["mfma_util"]
+        out.append(ent)
     return {"kernel": "k_sattn (+ k_vt)", "bound": "mfma", "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "shapes": out}
 
 
@@ -244,6 +476,25 @@ def time_kernel(fn, iters: int):
     return e0.elapsed_time(e1) / iters
 
 
+# ------------------------------------------------------------------------------------------------------------
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run
+    (one per GPU, rendezvous on 127.0.0.1) and pass their output through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    _log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,15 +507,16 @@ def main() -> None:
                     help="images per rank for the secondary images/s figure (0 = skip)")
     ap.add_argument("--gen-batch", type=int, default=16, help="prompts denoised per U-Net call")
     ap.add_argument("--gen-steps", type=int, default=50)
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs")
+    ap.add_argument("--only", default="", choices=["", "edit", "xattn", "sattn"],
+                    help="profiling runs (tools/prof_round.sh): only the edit timed region / only one attention leg, few launches")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -276,120 +528,64 @@ def main() -> None:
     from uce_amd import edit as E
     from uce_amd import cli
     H = E.UceHandle.get(device)
-    inp = make_inputs(args.workload, device)
-    C, G, s, W = inp["C"], inp["G"], inp["s"], inp["W"]
-    N, d, rows, n_e = C.shape[0], inp["d"], inp["rows"], inp["n_e"]
     algo = cli.ALGO_IDS[args.algo]
-    out = torch.empty_like(W)
-    H.reserve(d, max(N, d))
-    H.reserve_rows(rows, max(n_e, 1))
+    gb = 2 * max(1, min(args.gen_batch, max(args.gen_images, 1)))
+    if args.only == "xattn":            # fixed launch counts for the PMC passes (tools/pmc_fold.py splits by order)
+        print(json.dumps(xattn_leg(device, (2, gb), iters=4)), flush=True)
+        return
+    if args.only == "sattn":
+        print(json.dumps(sattn_leg(device, gb, iters=4, with_torch=False)), flush=True)
+        return
 
-    def step():
-        H.edit(C, G, s, 0.5, W, out=out, algo=algo)
-
-    _log(f"inputs ready: N={N} d={d} rows={rows}; warm-up")
-    for _ in range(args.warmup):
-        step()
-    H.status()
-    _log("timed region")
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    H.status()
-
-    _log(f"timed region done: {1e3 * elapsed / args.steps:.4f} ms/step")
-    # ---- per-kernel timing of the dominant kernel, HIP events on the launch stream
-    use_dual = (algo == 2) or (algo == 0 and ((N + 63) // 64) * 64 < d)
-    iters = max(20, min(200, args.steps))
-    if use_dual and 1 <= n_e <= 256 and d in (768, 1024, 2048) and rows >= 1024:
-        # uce_edit's path here: projection (+ riders) -> triangular solves -> update; the update is the
-        # HBM-bound pass over the weights and the longest kernel
-        Dm, R = H.dual_factors(C, G, s, 0.5)
-        T = H.lowrank_project(W, Dm)
-        ms = time_kernel(lambda: H.lowrank_update(W, T, R, out=out), iters)
-        nep = T.shape[1]
-        alg_bytes = 8.0 * rows * d + 4.0 * rows * nep + 4.0 * n_e * d      # W in + W out, T in, R once
-        roof = dict(kernel="k_lr_update_s" if n_e <= 128 else "k_lr_update", bound="hbm",
-                    achieved=round(alg_bytes / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    avg_ms=round(ms, 5), algorithmic_bytes=alg_bytes)
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        ms_p = time_kernel(lambda: H.lowrank_project(W, Dm), iters)
-        flops_p = 2.0 * rows * d * nep
-        roof["second_kernel"] = dict(kernel="k_lr_project", bound="mfma", achieved=round(flops_p / (ms_p * 1e-3) / 1e12, 2),
-                                     peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", avg_ms=round(ms_p, 5),
-                                     frac=round(flops_p / (ms_p * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4),
-                                     note="timed alone, without the Gram+Cholesky rider blocks it carries inside uce_edit")
-    elif use_dual and n_e <= 256:
-        Dm, R = H.dual_factors(C, G, s, 0.5)
-        ms = time_kernel(lambda: H.apply_lowrank(W, Dm, R, out=out), iters)
-        alg_bytes = 8.0 * rows * d + 8.0 * n_e * d          # W in + W out (+ the two factors once)
-        roof = dict(kernel="k_apply_lowrank", bound="hbm", achieved=round(alg_bytes / (ms * 1e-3) / 1e9, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", avg_ms=round(ms, 5), algorithmic_bytes=alg_bytes)
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    else:
-        A, Bt = H.gram(C, G, s, 0.5)
-        DT = H.solve_delta(A, Bt)
-        ms = time_kernel(lambda: H.apply(W, DT, out=out), iters)
-        flops = 2.0 * rows * d * d
-        roof = dict(kernel="k_apply", bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2),
-                    peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", avg_ms=round(ms, 5), algorithmic_flops=flops)
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    roof["traffic"] = None
-    if os.path.exists(traffic_file):
-        try:
-            t = json.load(open(traffic_file)).get(args.workload, {}).get(roof["kernel"])
-            roof["traffic"] = t["total_bytes"] if isinstance(t, dict) else t
-            roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/traffic.json), bytes per launch"
-        except Exception:
-            pass
-
-    gen = None
-    if args.gen_images > 0:
-        gen = generation_leg(device, world, args.gen_images, args.gen_steps, out if out.shape[1] == 768 else None, inp,
-                             args.gen_batch)
+    r = run_edit(H, args.workload, device, args.steps, args.warmup, algo, world, breakdown=(rank == 0))
+    inp, out, N = r["inp"], r["out"], r["N"]
+    n_e, n_p, d, _, cfg_idx = WORKLOADS[args.workload]
     result = {
         "metric": "concepts/sec closed-form edit (SD-1.4, 768-d)",
-        "value": round(world * N * args.steps / elapsed, 1),
+        "value": round(world * N * args.steps / r["elapsed"], 1),
         "unit": "concepts/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+        "ms_per_step": round(r["ms_per_step"], 5),
+        "ms_per_step_events": round(r["ms_per_step_events"], 5),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32 (f64 Gram/solve)",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {n_e} erase + {inp['n_p']} preserve concepts, d={d}, "
-                               f"{len(inp['mods'])} attn2 to_k/to_v modules = one {rows}x{d} fp32 slab, "
+        "config": {"workload": f"{args.workload}: {n_e} erase + {n_p} preserve concepts, d={d}, "
+                               f"{len(inp['mods'])} attn2 to_k/to_v modules = one {inp['rows']}x{d} fp32 slab, "
                                f"lambda 0.5, algo {args.algo}",
+                   "baseline_config": cfg_idx,
                    "parallelism": "replicas only" if world > 1 else "single GPU"},
-        "roofline": roof,
     }
-    if gen is not None:
-        result["generate"] = gen
+    if rank == 0:
+        result["roofline"] = roofline_block(r)
+    if args.only == "edit":
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return
+    if rank == 0 and world == 1 and not args.no_configs:
+        del r
+        result["configs"] = []
+        for name in CONFIG_LEGS:
+            if name == args.workload:
+                continue
+            try:
+                result["configs"].append(config_leg(H, name, device, algo))
+            except Exception as err:  # noqa: BLE001
+                result["configs"].append({"workload": name, "error": repr(err)})
+    if args.gen_images > 0:
+        result["generate"] = generation_leg(device, world, args.gen_images, args.gen_steps,
+                                            out if out.shape[1] == 768 else None, args.gen_batch)
     if rank == 0 and args.gen_images > 0:
-        gb = 2 * max(1, min(args.gen_batch, args.gen_images))
         result["xattn"] = xattn_leg(device, (2, gb))
         result["sattn"] = sattn_leg(device, gb)
     if rank == 0:
         _log("gpu part: " + json.dumps(result))
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(inp, args.cpu_budget)
+            result["cpu_baseline"] = cpu_baseline(inp)
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -116,6 +116,14 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
  * *info = 0 OK, k > 0: leading minor k not positive definite (function then returns UCE_EDOM). */
 int uce_status(uce_handle_t h, int* info, uce_stream_t stream);
 
+/* Measurement aid for bench.py (per-kernel time measured live with HIP events on the launch
+ * stream): between uce_profile_begin and uce_profile_end every kernel launch (or launch chain) that uce_edit and
+ * the calls it is composed of issue on this handle is bracketed by two HIP events.  uce_profile_end synchronises
+ * `stream` and writes one line per kernel, "<name> <total ms> <launches>\n", into `report` (UCE_EINVAL when `cap`
+ * is too small).  The brackets serialise nothing but add two event records per launch: never inside a timed region. */
+int uce_profile_begin(uce_handle_t h);
+int uce_profile_end(uce_handle_t h, uce_stream_t stream, char* report, size_t cap);
+
 /* a6 - debias drift (uce_sd_debias.py:122-127, cumulative over iterations):
  *   G [N_edit,d] f32 = C_edit + Dsum [N_edit,N_debias] (f64, = sum_t direction_scale_t) @ C_debias */
 int uce_debias_targets(uce_handle_t h, const float* C_edit, const float* C_debias, const double* Dsum,

@@ -1,21 +1,37 @@
 """Builds libuce_hip.so (hand-written HIP kernels for gfx950) in-tree with hipcc.
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the
-gpurun snapshot.  `python -m uce_amd.build` rebuilds unconditionally.
+gpurun snapshot.  Every csrc/*.hip is compiled to its own object (in parallel, only when it or a
+header is newer than the object) and the objects are linked into lib/libuce_hip.so.
+`python -m uce_amd.build` rebuilds unconditionally.
 """
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
-import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libuce_hip.so")
-SOURCES = ["uce_gram.hip", "uce_solve.hip", "uce_apply.hip", "uce_apply_b3.hip", "uce_lowrank2.hip", "uce_xattn.hip", "uce_sattn.hip", "uce_norm.hip", "uce_conv.hip", "uce_api.hip"]
-HEADERS = ["uce_common.h", os.path.join("..", "..", "include", "uce_hip.h")]
+PUBLIC_HEADER = os.path.normpath(os.path.join(PKG, "..", "include", "uce_hip.h"))
+
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950 reads/writes them there directly).  Left to
+# its heuristics the compiler parks them in AGPRs and pays a v_accvgpr_read/write pair around every VALU
+# touch of an accumulator - 128 extra moves per key tile in the attention kernels' softmax.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
+def sources() -> list[str]:
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers() -> list[str]:
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [PUBLIC_HEADER]
 
 
 def _hipcc() -> str:
@@ -25,23 +41,42 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(p) > t for p in deps)
+
+
+def needs_build() -> bool:
+    """True when the library is missing or older than ANY csrc/*.hip, csrc/*.h or the public header."""
+    return _stale(LIB_PATH, sources() + headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950 reads/writes them there directly).  Left to
-    # its heuristics the compiler parks them in AGPRs and pays a v_accvgpr_read/write pair around every VALU
-    # touch of an accumulator - 128 extra moves per key tile in the attention kernels' softmax.
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc, hdrs = _hipcc(), headers()
+    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
+
+    def compile_one(src: str) -> None:
+        cmd = [cc] + FLAGS + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print("[uce_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as pool:
+        list(pool.map(compile_one, todo))
+    objs = [_obj(s) for s in sources()]
+    stale_objs = set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - set(objs)
+    for o in stale_objs:                      # a removed source must not stay linked in
+        os.remove(o)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print("[uce_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -49,5 +84,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv or True)
+    build(force=True)
     print(LIB_PATH)

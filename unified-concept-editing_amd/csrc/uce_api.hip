@@ -2,8 +2,36 @@
 // orchestration of the edit pipeline (gram -> potrf chain -> trisolve -> apply) on one stream.
 #include "uce_common.h"
 #include <dlfcn.h>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <new>
+#include <vector>
+
+// ---- per-launch HIP-event brackets (uce_profile_begin / uce_profile_end) ----------------------
+struct uce_prof {
+  struct Rec { const char* name; hipEvent_t e0, e1; };
+  std::vector<Rec> recs;
+};
+
+void uce_prof_mark(uce_ctx* h, const char* name, hipStream_t st, bool begin) {
+  if (!h || !h->prof) return;
+  if (begin) {
+    uce_prof::Rec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, st);
+    h->prof->recs.push_back(r);
+  } else if (!h->prof->recs.empty() && h->prof->recs.back().name == name) {
+    (void)hipEventRecord(h->prof->recs.back().e1, st);
+  }
+}
+
+static void prof_clear(uce_ctx* h) {
+  if (!h->prof) return;
+  for (auto& r : h->prof->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  delete h->prof;
+  h->prof = nullptr;
+}
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -100,7 +128,7 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
 
 extern "C" {
 
-int uce_version(void) { return 104; }
+int uce_version(void) { return 105; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -144,6 +172,7 @@ int uce_destroy(uce_handle_t h) {
   if (h->Vt) (void)hipFree(h->Vt);
   for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
   if (h->ticket) (void)hipFree(h->ticket);
+  prof_clear(h);
   delete h;
   return UCE_OK;
 }
@@ -180,6 +209,7 @@ int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int
   if (N_edit > 0 && !G) return UCE_EINVAL;
   int rc = uce_ensure(h, d, d);
   if (rc) return rc;
+  UceProfScope ps(h, "k_gram_primal", (hipStream_t)stream);
   return launch_gram_primal(h, C, G ? G : C, s, N, N_edit, d, lamb, A, Bt, (hipStream_t)stream);
 }
 
@@ -188,8 +218,12 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
   int rc = uce_ensure(h, d, d);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = launch_potrf(h, A, d, st);                    // k_potrf_first resets the status word
+  {
+    UceProfScope ps(h, "potrf", st);
+    rc = launch_potrf(h, A, d, st);                  // k_potrf_first resets the status word
+  }
   if (rc) return rc;
+  UceProfScope ps(h, "k_trisolve", st);
   return launch_trisolve(h, d, d, Bt, nullptr, d, DeltaT, d, st);
 }
 
@@ -200,10 +234,13 @@ int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_
   // default: bf16 matrix cores with a three-way split of both operands (fp32-equivalent products, 2.7x the
   // f32-MFMA rate); UCE_APPLY_VARIANT=0 selects the exact-f32 MFMA kernel
   static const int variant = getenv("UCE_APPLY_VARIANT") ? atoi(getenv("UCE_APPLY_VARIANT")) : 1;
-  if (variant == 0) return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
+  if (variant == 0) {
+    UceProfScope ps(h, "k_apply", (hipStream_t)stream);
+    return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
+  }
   const int rc = uce_ensure(h, d, 64);
   if (rc) return rc;
-  return launch_apply_b3(W_old, DeltaT, h->DeltaP, W_new, rows, d, (hipStream_t)stream);
+  return launch_apply_b3(W_old, DeltaT, h->DeltaP, W_new, rows, d, (hipStream_t)stream, h);
 }
 
 int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,
@@ -216,12 +253,19 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
   hipStream_t st = (hipStream_t)stream;
   int nsplit = 1;
   size_t slab_stride = 0;
-  rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, G, Dm, N_edit, &nsplit, &slab_stride, st);
+  {
+    UceProfScope ps(h, "k_gram_dual", st);
+    rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, G, Dm, N_edit, &nsplit, &slab_stride, st);
+  }
   if (rc) return rc;
-  rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
-                    : launch_potrf(h, h->M, n_pad, st);
+  {
+    UceProfScope ps(h, "potrf", st);
+    rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
+                      : launch_potrf(h, h->M, n_pad, st);
+  }
   if (rc) return rc;
   if (N_edit == 0) return UCE_OK;
+  UceProfScope ps(h, "k_trisolve", st);
   return launch_trisolve(h, n_pad, d, nullptr, C, N, R, N_edit, st);
 }
 
@@ -229,6 +273,7 @@ int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int 
                            float* DeltaT, uce_stream_t stream) {
   if (!h || !DeltaT || N_edit < 0 || d <= 0 || d % 64) return UCE_EINVAL;
   if (N_edit > 0 && (!Dm || !R)) return UCE_EINVAL;
+  UceProfScope ps(h, "k_delta_factors", (hipStream_t)stream);
   return launch_delta_from_factors(Dm, R, N_edit, d, DeltaT, (hipStream_t)stream);
 }
 
@@ -242,10 +287,15 @@ int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const
     // the two-kernel form (projection into the handle's T, then the update pass)
     int rc = uce_ensure_T(h, rows, N_edit);
     if (rc) return rc;
-    rc = launch_lr_project(W_old, Dm, nullptr, h->T, rows, d, N_edit, (hipStream_t)stream);
+    {
+      UceProfScope ps(h, "k_lr_project", (hipStream_t)stream);
+      rc = launch_lr_project(W_old, Dm, nullptr, h->T, rows, d, N_edit, (hipStream_t)stream);
+    }
     if (rc) return rc;
+    UceProfScope ps(h, "k_lr_update", (hipStream_t)stream);
     return launch_lr_update(W_old, h->T, R, W_new, rows, d, N_edit, (hipStream_t)stream);
   }
+  UceProfScope ps(h, "k_apply_lowrank_generic", (hipStream_t)stream);
   return launch_apply_lowrank(W_old, Dm, R, W_new, rows, d, N_edit, (hipStream_t)stream);
 }
 
@@ -283,21 +333,33 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (n_pad <= lr_rider_max_n()) {
+      UceProfScope ps(h, "k_lr_project", st);          // with the Gram + Cholesky rider blocks
       rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st, h, C, s, N, lamb);
       if (rc) return rc;
     } else {
       int nsplit = 1;
       size_t slab_stride = 0;
-      rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, nullptr, nullptr, 0, &nsplit, &slab_stride, st);
+      {
+        UceProfScope ps(h, "k_gram_dual", st);
+        rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, nullptr, nullptr, 0, &nsplit, &slab_stride, st);
+      }
       if (rc) return rc;
-      rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
-                        : launch_potrf(h, h->M, n_pad, st);
+      {
+        UceProfScope ps(h, "potrf", st);
+        rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
+                          : launch_potrf(h, h->M, n_pad, st);
+      }
       if (rc) return rc;
+      UceProfScope ps(h, "k_lr_project", st);
       rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st);
       if (rc) return rc;
     }
-    rc = launch_trisolve(h, n_pad, d, nullptr, C, N, h->R, N_edit, st);
+    {
+      UceProfScope ps(h, "k_trisolve", st);
+      rc = launch_trisolve(h, n_pad, d, nullptr, C, N, h->R, N_edit, st);
+    }
     if (rc) return rc;
+    UceProfScope ps(h, "k_lr_update", st);
     return launch_lr_update(W_old, h->T, h->R, W_new, rows, d, N_edit, st);
   }
   rc = uce_dual_factors(h, C, G, s, N, N_edit, d, lamb, h->Dm, h->R, stream);
@@ -307,6 +369,39 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   rc = uce_delta_from_factors(h, h->Dm, h->R, N_edit, d, h->DeltaT, stream);
   if (rc) return rc;
   return uce_apply(h, W_old, h->DeltaT, W_new, rows, d, stream);
+}
+
+int uce_profile_begin(uce_handle_t h) {
+  if (!h) return UCE_EINVAL;
+  prof_clear(h);
+  h->prof = new (std::nothrow) uce_prof();
+  return h->prof ? UCE_OK : UCE_ENOMEM;
+}
+
+int uce_profile_end(uce_handle_t h, uce_stream_t stream, char* report, size_t cap) {
+  if (!h || !h->prof || !report || cap == 0) return UCE_EINVAL;
+  UCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  struct Agg { const char* name; double ms; int n; };
+  std::vector<Agg> agg;
+  for (auto& r : h->prof->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    size_t i = 0;
+    for (; i < agg.size(); ++i)
+      if (!strcmp(agg[i].name, r.name)) break;
+    if (i == agg.size()) agg.push_back(Agg{r.name, 0.0, 0});
+    agg[i].ms += ms;
+    agg[i].n += 1;
+  }
+  prof_clear(h);
+  size_t off = 0;
+  report[0] = 0;
+  for (auto& a : agg) {
+    const int w = snprintf(report + off, cap - off, "%s %.6f %d\n", a.name, a.ms, a.n);
+    if (w < 0 || (size_t)w >= cap - off) return UCE_EINVAL;
+    off += (size_t)w;
+  }
+  return UCE_OK;
 }
 
 int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {

@@ -192,9 +192,12 @@ __global__ __launch_bounds__(256, 2) void k_apply_b3(const float* __restrict__ W
 
 // planes: h->DeltaP, 3 * d * d bf16
 int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* planes, float* W_new, long rows, int d,
-                    hipStream_t st) {
+                    hipStream_t st, uce_ctx* h) {
   const long n = (long)d * d;
-  hipLaunchKernelGGL(k_split3, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, DeltaT, planes, n);
+  {
+    UceProfScope ps(h, "k_split3", st);
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, DeltaT, planes, n);
+  }
   UCE_LAUNCH_CHECK();
   const size_t smem = (size_t)2 * 6 * PLANE * sizeof(unsigned short);
   static bool attr_set = false;
@@ -206,7 +209,10 @@ int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* pla
   const int col_tiles = (d + BN - 1) / BN;
   const long nwg = row_tiles * col_tiles;
   if (nwg > 0x7fffffffL) return UCE_EINVAL;
-  hipLaunchKernelGGL(k_apply_b3, dim3((unsigned)nwg), dim3(256), smem, st, W_old, planes, W_new, rows, d);
+  {
+    UceProfScope ps(h, "k_apply_b3", st);
+    hipLaunchKernelGGL(k_apply_b3, dim3((unsigned)nwg), dim3(256), smem, st, W_old, planes, W_new, rows, d);
+  }
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

@@ -49,6 +49,16 @@ struct uce_ctx {
   size_t Vt_elems;
   void* retired[32];   // outgrown Vt buffers: kept alive until uce_destroy (captured hipGraphs may still name them)
   int n_retired;
+  struct uce_prof* prof;   // per-launch HIP-event brackets of uce_edit (uce_profile_begin / _end); null = off
+};
+
+// Measurement aid (uce_profile_begin / uce_profile_end): when h->prof is set, every kernel launch (or launch
+// chain) uce_edit issues is bracketed by two HIP events on the caller's stream.
+void uce_prof_mark(uce_ctx* h, const char* name, hipStream_t st, bool begin);
+struct UceProfScope {
+  uce_ctx* h; const char* name; hipStream_t st;
+  UceProfScope(uce_ctx* h_, const char* n, hipStream_t s) : h(h_), name(n), st(s) { if (h && h->prof) uce_prof_mark(h, name, st, true); }
+  ~UceProfScope() { if (h && h->prof) uce_prof_mark(h, name, st, false); }
 };
 
 // ---- internal launchers (defined across the .hip files) -------------------------------------
@@ -70,7 +80,7 @@ int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* 
                     float* out, int out_rows, hipStream_t st);
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
 int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* planes, float* W_new, long rows, int d,
-                    hipStream_t st);
+                    hipStream_t st, uce_ctx* h = nullptr);
 int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, float* W_new, long rows,
                          int d, int N_edit, hipStream_t st);
 bool apply_lowrank_fits(int d, int N_edit);

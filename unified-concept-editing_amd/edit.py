@@ -179,6 +179,22 @@ class UceHandle:
             raise _lib.UceError(rc, f"solve (leading minor {info.value} is not positive definite)")
         _lib.check(rc, "uce_status")
 
+    def profile(self, fn, iters: int = 20) -> Dict[str, Tuple[float, int]]:
+        """Per-kernel average duration of the launches `fn` makes through this handle: {kernel: (avg ms, launches per
+        call)} from HIP events the library records around every launch on the launch stream (uce_profile_begin/_end)."""
+        fn()
+        torch.cuda.synchronize(self.device)
+        _lib.check(self.lib.uce_profile_begin(self._h), "uce_profile_begin")
+        for _ in range(iters):
+            fn()
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(self.lib.uce_profile_end(self._h, _stream_ptr(self.device), buf, len(buf)), "uce_profile_end")
+        out: Dict[str, Tuple[float, int]] = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.split()
+            out[name] = (float(ms) / int(n), int(n) // iters)
+        return out
+
     def debias_targets(self, C_edit: torch.Tensor, C_debias: torch.Tensor, Dsum: torch.Tensor) -> torch.Tensor:
         Ne, d = C_edit.shape
         Nd = C_debias.shape[0]

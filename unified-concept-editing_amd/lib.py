@@ -32,6 +32,8 @@ SIGNATURES = {
     "uce_delta_from_factors": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "uce_edit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _l, _i, _vp]),
     "uce_status": (_i, [_vp, C.POINTER(_i), _vp]),
+    "uce_profile_begin": (_i, [_vp]),
+    "uce_profile_end": (_i, [_vp, _vp, C.c_char_p, _sz]),
     "uce_debias_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "uce_cast_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
     "uce_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
