@@ -104,10 +104,37 @@ def test_pipeline_generator_list_forms():
         pipe(["a", "b"], num_inference_steps=2, num_images_per_prompt=2, generator=[g(1), g(2), g(3)], output_type="latent")
 
 
-def test_patch_unet_rejects_unknown_keys(tmp_path):
+def test_patch_unet_ignores_unknown_keys_like_strict_false(tmp_path):
+    """generate-images-sd.py:19 loads with strict=False: unknown keys are ignored, shape mismatches still raise."""
     pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
-    with pytest.raises(KeyError):
-        sdp.patch_unet(pipe, {"nope.weight": torch.zeros(1)})
+    name = next(n for n, _ in pipe.unet.named_parameters() if "attn2.to_k" in n)
+    w = dict(pipe.unet.named_parameters())[name]
+    loaded = sdp.patch_unet(pipe, {"nope.weight": torch.zeros(1), name: torch.ones_like(w)})
+    assert loaded == [name] and bool((dict(pipe.unet.named_parameters())[name] == 1).all())
+    with pytest.raises(ValueError):
+        sdp.patch_unet(pipe, {name: torch.zeros(3, 3)})
+
+
+def test_vae_deprecated_attention_keys_are_renamed():
+    """SD-1.x VAE checkpoints: query/key/value/proj_attn -> to_q/to_k/to_v/to_out.0 (diffusers renames at load)."""
+    f = sdp.convert_deprecated_vae_key
+    assert f("decoder.mid_block.attentions.0.query.weight") == "decoder.mid_block.attentions.0.to_q.weight"
+    assert f("decoder.mid_block.attentions.0.key.bias") == "decoder.mid_block.attentions.0.to_k.bias"
+    assert f("decoder.mid_block.attentions.0.value.weight") == "decoder.mid_block.attentions.0.to_v.weight"
+    assert f("decoder.mid_block.attentions.0.proj_attn.bias") == "decoder.mid_block.attentions.0.to_out.0.bias"
+    assert f("decoder.mid_block.attentions.0.group_norm.weight") == "decoder.mid_block.attentions.0.group_norm.weight"
+    assert f("decoder.mid_block.resnets.0.conv1.weight") == "decoder.mid_block.resnets.0.conv1.weight"
+    vae = sdp.VaeDecoder((32, 32, 64, 64))
+    sd = {}
+    for k, v in vae.state_dict().items():            # a checkpoint in the deprecated naming, conv-shaped projections
+        for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".{new}.", f".{old}.")
+                v = v[:, :, None, None] if v.dim() == 2 else v
+        sd[k] = v
+    assert any(".query." in k for k in sd)
+    conv = {f(k): (v[:, :, 0, 0] if (".attentions." in k and v.dim() == 4) else v) for k, v in sd.items()}
+    vae.load_state_dict(conv, strict=True)
 
 
 def test_two_rank_gloo_generation_with_broadcast(tmp_path):

@@ -206,3 +206,15 @@ def test_even_chunk_respects_cap_and_balances():
             assert len(sizes) == -(-n // max(1, min(n, cap)))          # no more chunks than the cap forces
             assert max(sizes) - min(sizes) <= len(sizes)                 # evenly sized: no small tail
     assert even_chunk(32, 15) == 11 and even_chunk(32, 22) == 16 and even_chunk(32, 64) == 32
+
+
+def test_edit_slab_rejects_negative_scales_and_nonpositive_lambda():
+    """The solver is Cholesky-only: a negative scale / lamb <= 0 is refused with a clear error before any launch
+    (the reference's LU inverse would accept it)."""
+    from uce_amd import edit as E
+    slab = E.WeightSlab(["m"], [0], [4], torch.zeros(4, 64))
+    C, G = torch.randn(3, 64), torch.randn(2, 64)
+    with pytest.raises(ValueError, match="scales"):
+        E.edit_slab(None, slab, C, G, torch.tensor([1.0, -0.5, 1.0]), 0.5)
+    with pytest.raises(ValueError, match="lamb"):
+        E.edit_slab(None, slab, C, G, torch.ones(3), 0.0)

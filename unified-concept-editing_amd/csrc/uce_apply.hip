@@ -208,10 +208,9 @@ __global__ void k_cast_bf16(const float* __restrict__ src, unsigned short* __res
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st) {
   static const int one_per_cu = getenv("UCE_APPLY_1WG") ? atoi(getenv("UCE_APPLY_1WG")) : 0;
   const size_t smem = one_per_cu ? (size_t)100 * 1024 : (size_t)2 * (BM + BN) * TLD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   const long row_tiles = (rows + BM - 1) / BM;
   const int col_tiles = (d + BN - 1) / BN;
@@ -437,11 +436,10 @@ int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, fl
   if (NEP == 0) NEP = 16;
   const size_t smem = ((size_t)LR_BM * (d + 8) + (size_t)5 * LR_BM * (NEP + 2)) * sizeof(float);
   if (smem > 160 * 1024) return UCE_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-    attr_set = true;
   }
   const long nwg = (rows + LR_BM - 1) / LR_BM;
   if (nwg > 0x7fffffffL) return UCE_EINVAL;

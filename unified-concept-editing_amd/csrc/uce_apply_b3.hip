@@ -200,10 +200,9 @@ int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* pla
   }
   UCE_LAUNCH_CHECK();
   const size_t smem = (size_t)2 * 6 * PLANE * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_b3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   const long row_tiles = (rows + BM - 1) / BM;
   const int col_tiles = (d + BN - 1) / BN;

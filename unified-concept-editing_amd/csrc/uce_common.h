@@ -22,6 +22,20 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef short short8_t __attribute__((ext_vector_type(8)));
 
+// Function attributes (the > 64 KB dynamic-LDS opt-in) are per DEVICE: a launcher sets them the first time it runs
+// on each device of the process, not once per process.
+struct PerDeviceOnce {
+  unsigned long long seen[4] = {0, 0, 0, 0};      // up to 256 device ordinals
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (seen[dev >> 6] & bit) return false;
+    seen[dev >> 6] |= bit;
+    return true;
+  }
+};
+
 constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solves
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding

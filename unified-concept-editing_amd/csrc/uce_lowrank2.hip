@@ -586,11 +586,10 @@ int launch_project(const float* W_old, const float* Dm, const float* Csub, float
                    int NEP64, const GramPotrfJob& job, hipStream_t st) {
   size_t smem = (size_t)2 * (MT * 16 + 64) * PJ_LD * sizeof(float);
   if (job.C && smem < gp_smem(job.nb)) smem = gp_smem(job.nb);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-    attr_set = true;
   }
   const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) : 0);
   hipLaunchKernelGGL((k_lr_project<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
@@ -614,11 +613,10 @@ template <int D, int UP_MT, int WPE>
 int launch_update_v(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
                     int NEP64, hipStream_t st) {
   const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_update<D, UP_MT, WPE>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   const long nwg = (rows + UP_MT * 16 - 1) / (UP_MT * 16);
   hipLaunchKernelGGL((k_lr_update<D, UP_MT, WPE>), dim3((unsigned)nwg), dim3(256), smem, st, W_old, T, R, W_new, rows,

@@ -281,11 +281,10 @@ int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_sattn<DHP, true>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,

@@ -217,13 +217,12 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
   const size_t smem = 3 * 64 * LD * sizeof(double);
   const size_t smem_first = sizeof(Potrf64Scratch);
   static_assert(sizeof(Potrf64Scratch) <= POTRF_STEP_SMEM, "scratch must fit the three tile regions");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_first, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem_first));
-    attr_set = true;
   }
   hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(512), smem_first, st, (const double*)M, n, nsplit,
                      slab_stride, h->Lmat, h->Linv, h->status);
@@ -247,14 +246,13 @@ int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* 
   const bool use_lds = n <= 1024;
   const size_t smem = 64 * 16 * 8 + (use_lds ? (size_t)n * 16 * 8 : 0);
   double* Yg = use_lds ? nullptr : h->Yg;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (attr_once.first()) {
     const int cap = 64 * 16 * 8 + 1024 * 16 * 8;
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trisolve<true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trisolve<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    attr_set = true;
   }
   const dim3 grid(m / 16);
   if (rhs32)

@@ -75,27 +75,41 @@ def clip_zero_shot_classifier(device):
     return classify
 
 
+def rank_device(device) -> str:
+    """The device this process works on: `device` as given for a single process; under torch.distributed.run (one
+    process per GPU) a CUDA device becomes cuda:LOCAL_RANK.  Call it BEFORE loading the pipeline / classifier."""
+    from .generate import dist_env
+    _, world, local = dist_env()
+    if world > 1 and torch.device(device).type == "cuda":
+        torch.cuda.set_device(local)
+        return f"cuda:{local}"
+    return str(device)
+
+
 def UCE(pipe, classify, edit_concepts, debias_concepts, preserve_concepts, edit_scale, preserve_scale, lamb, save_dir,
         exp_name, max_diff, step_size, num_images_per_prompt, num_inference_steps, guidance_scale,
-        desired_ratios=(0.5, 0.5), max_iterations=30, device="cuda:0", ratios_fn=None):
+        desired_ratios=(0.5, 0.5), max_iterations=30, device="cuda:0", ratios_fn=None, algo: int = 0,
+        embed_batch: int = 0):
     """Same positional signature as the reference's debias UCE() (:37); `desired_ratios`,
     `max_iterations`, `device` replace the module globals it reads; `ratios_fn` lets a test script
-    the (unseeded, irreproducible) sampling step."""
+    the (unseeded, irreproducible) sampling step; `algo` / `embed_batch` as in edit.UCE."""
     from .generate import dist_env, init_distributed
     rank, world, local = dist_env()
-    if world > 1 and torch.device(device).type == "cuda":      # one process per GPU
-        device = f"cuda:{local}"
-        torch.cuda.set_device(local)
+    device = rank_device(device)
     handle = E.UceHandle.get(device)
+    pdev = getattr(pipe, "device", None)
+    if pdev is not None and torch.device(pdev).type == "cuda" and torch.device(pdev) != handle.device:
+        raise RuntimeError(f"the pipeline lives on {pdev} but this rank edits on {handle.device}: load it on "
+                           "debias.rank_device(device) (one process per GPU)")
     init_distributed(handle.device)
     modules = E.collect_uce_modules(pipe.unet)
     slab = E.WeightSlab.from_modules(modules, handle.device)
     embeds = E.last_token_embeddings(pipe, list(edit_concepts) + list(debias_concepts) + list(preserve_concepts),
-                                     handle.device)
+                                     handle.device, batch_size=embed_batch)
     C_edit = torch.stack([embeds[e] for e in edit_concepts]).contiguous()
     C_deb = torch.stack([embeds[c] for c in debias_concepts]).contiguous()
     C_pres = torch.stack([embeds[p] for p in preserve_concepts]).contiguous() if preserve_concepts else None
-    state = E.DebiasState(handle, slab, C_edit, C_deb, C_pres, edit_scale, preserve_scale, lamb)
+    state = E.DebiasState(handle, slab, C_edit, C_deb, C_pres, edit_scale, preserve_scale, lamb, algo=algo)
     if hasattr(pipe, "to"):
         pipe = pipe.to(torch.bfloat16)                         # :90
     start_time = time.time()

@@ -435,6 +435,10 @@ def drop_zero_scale_rows(C, G, s, n_edit: int):
 def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor,
               lamb: float, algo: int = _lib.ALGO_AUTO) -> WeightSlab:
     n_edit = 0 if G is None else G.shape[0]
+    if bool((s < 0).any()) or not (lamb > 0):
+        # the solver is Cholesky-only (SPD system); the reference's general LU inverse would accept these
+        raise ValueError("erase/edit/preserve scales must be >= 0 and lamb > 0: the closed-form system "
+                         "lamb*I + sum_i s_i c_i c_i^T is solved by a Cholesky factorisation (SPD only)")
     C, G, s, n_edit = drop_zero_scale_rows(C, G, s, n_edit)
     if C.shape[0] == 0 or n_edit == 0:
         # nothing pulls the weights anywhere: W_new = W_old exactly (Delta = 0)
@@ -472,8 +476,9 @@ class DebiasState:
     re-solves from W_old, so the weights after iteration t depend only on sum_{t'<=t} D_t'."""
 
     def __init__(self, handle: UceHandle, slab: WeightSlab, C_edit: torch.Tensor, C_debias: torch.Tensor,
-                 C_pres: Optional[torch.Tensor], edit_scale: float, preserve_scale: float, lamb: float):
-        self.handle, self.slab, self.lamb = handle, slab, lamb
+                 C_pres: Optional[torch.Tensor], edit_scale: float, preserve_scale: float, lamb: float,
+                 algo: int = _lib.ALGO_AUTO):
+        self.handle, self.slab, self.lamb, self.algo = handle, slab, lamb, algo
         self.C_edit, self.C_debias = C_edit, C_debias
         n_e = C_edit.shape[0]
         n_p = 0 if C_pres is None else C_pres.shape[0]
@@ -486,5 +491,5 @@ class DebiasState:
     def step(self, direction_scale: np.ndarray) -> WeightSlab:
         self.Dsum += torch.as_tensor(np.asarray(direction_scale, dtype=np.float64), device=self.handle.device)
         G = self.handle.debias_targets(self.C_edit, self.C_debias, self.Dsum)
-        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb)
+        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb, self.algo)
         return self.current

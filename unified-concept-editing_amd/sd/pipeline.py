@@ -394,8 +394,7 @@ def _seeded_init(module: nn.Module, seed: int) -> None:
             if p.dim() >= 2:
                 fan_in = p[0].numel()
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / math.sqrt(fan_in))
-            elif "norm" in "":  # never true: norm weights keep their default (1 / 0)
-                pass
+            # 1-D parameters (norm weights 1 / biases 0) keep their defaults
 
 
 def load_pipeline(model_id: str, torch_dtype=torch.float32, device="cpu", model_dir: Optional[str] = None,
@@ -426,8 +425,12 @@ def load_pipeline(model_id: str, torch_dtype=torch.float32, device="cpu", model_
         unet.load_state_dict(load_file(up), strict=True)
         vp = os.path.join(model_dir, "vae", "diffusion_pytorch_model.safetensors")
         if vae_m is not None and os.path.exists(vp):
-            sd = {k: v for k, v in load_file(vp).items() if k.startswith(("decoder.", "post_quant_conv."))}
-            vae_m.load_state_dict(sd, strict=False)
+            sd = {convert_deprecated_vae_key(k): v for k, v in load_file(vp).items()
+                  if k.startswith(("decoder.", "post_quant_conv."))}
+            for k, v in sd.items():       # SD-1.x checkpoints store the attention projections as 1x1 convolutions
+                if ".attentions." in k and k.endswith(".weight") and v.dim() == 4:
+                    sd[k] = v[:, :, 0, 0]
+            vae_m.load_state_dict(sd, strict=True)
     for m in (unet, text, vae_m):
         if m is not None:
             m.eval().requires_grad_(False)
@@ -435,16 +438,31 @@ def load_pipeline(model_id: str, torch_dtype=torch.float32, device="cpu", model_
     return pipe.to(device, torch_dtype)
 
 
+_DEPRECATED_VAE_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def convert_deprecated_vae_key(key: str) -> str:
+    """SD-1.x VAE checkpoints name the mid-block attention `query/key/value/proj_attn`; diffusers renames them to
+    `to_q/to_k/to_v/to_out.0` at load time (`_convert_deprecated_attention_blocks`).  Same mapping here, so that a
+    real checkpoint never leaves the attention randomly initialised."""
+    if ".attentions." not in key:
+        return key
+    head, _, leaf = key.rpartition(".")
+    stem, _, name = head.rpartition(".")
+    return f"{stem}.{_DEPRECATED_VAE_ATTN[name]}.{leaf}" if name in _DEPRECATED_VAE_ATTN else key
+
+
 def patch_unet(pipe, state: Dict[str, torch.Tensor]) -> List[str]:
     """`pipe.unet.load_state_dict(uce_weights, strict=False)` (generate-images-sd.py:17-19), with the
     fp32 -> bf16 cast done by the HIP kernel when the parameters live on a GPU in bf16."""
     params = dict(pipe.unet.named_parameters())
-    unknown = [k for k in state if k not in params]
-    if unknown:
-        raise KeyError(f"keys not in the U-Net: {unknown[:3]}...")
     handle = None
+    loaded = []
     for k, v in state.items():
-        p = params[k]
+        p = params.get(k)
+        if p is None:                     # strict=False: keys the U-Net does not have are ignored
+            continue
+        loaded.append(k)
         if tuple(p.shape) != tuple(v.shape):
             raise ValueError(f"{k}: shape {tuple(v.shape)} vs parameter {tuple(p.shape)}")
         if p.is_cuda and p.dtype == torch.bfloat16 and v.dtype == torch.float32:
@@ -453,4 +471,4 @@ def patch_unet(pipe, state: Dict[str, torch.Tensor]) -> List[str]:
             handle.cast_bf16(v.to(p.device).contiguous(), p.data)
         else:
             p.data.copy_(v.to(device=p.device, dtype=p.dtype))
-    return list(state)
+    return loaded
