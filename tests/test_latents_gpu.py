@@ -1,0 +1,112 @@
+"""GPU: latent parity of the generation path at SD-1.4 size (north star: "generated latents within
+a stated fp16 tolerance at fixed seed"; reference call site evalscripts/generate-images-sd.py:37-42).
+
+diffusers, checkpoints and tokenizer vocabularies do not exist on these machines, so the pin is the one that can be
+built here: the SAME seeded weights and the SAME CPU-seeded initial latents run through
+  (a) the fp32 torch path   - the bf16-representable weights held in fp32 (the reference runs its pipeline in bf16,
+                              generate-images-sd.py:13, so the MODEL is the bf16-rounded one; with fp32-only weights a
+                              50-step trajectory on random weights decorrelates completely - measured relF 1.35 for
+                              torch's bf16 ops and for ours alike), fp32 arithmetic, every hand-written kernel off
+                              (16-bit-only kernels fall back to torch ops), eager launches: the comparison standard;
+  (b) the product path      - bf16, hipGraph-replayed step, uce_xattn_fwd / uce_sattn_fwd / GroupNorm / LayerNorm /
+                              GEGLU / im2col kernels, hoisted K/V;
+  (c) the torch bf16 path   - bf16 weights, every hand-written kernel off: what the reference's own bf16 pipeline
+                              does to the same network (its torch ops in bf16).
+Stated tolerances (measured values in profiles/r02/latent_parity.json):
+  per U-Net call (same input latents):  relF(eps_product, eps_fp32) <= PER_CALL_TOL
+  after the full 50-step PNDM loop:     relF(lat_product, lat_fp32) <= FINAL_TOL
+  and the product path is no further from fp32 than torch's own bf16 ops: <= 1.25 x relF(torch bf16, fp32) + 0.01.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+from uce_amd import REPO_ROOT
+
+pytestmark = pytest.mark.gpu
+
+PER_CALL_TOL = 6e-2          # measured 4.1e-2 .. 4.7e-2 (torch bf16 ops on the same model: 4.9e-2 .. 6.0e-2)
+FINAL_TOL = 5e-2             # measured 2.9e-2 after 51 U-Net calls (torch bf16 ops: 2.9e-2)
+PROMPT = "a photo of an astronaut riding a horse"
+SEED = 1234
+STEPS = 50
+PROBE_STEPS = (0, 1, 12, 25, 38, 50)          # U-Net calls whose input / output the fp32 run records
+
+
+def _set_hip(on: bool):
+    from uce_amd.sd import unet as U
+    for name in ("USE_HIP_GROUPNORM", "USE_HIP_LAYERNORM", "USE_HIP_CONV3X3", "USE_HIP_SELF_ATTENTION",
+                 "USE_HIP_CROSS_ATTENTION"):
+        setattr(U, name, on)
+
+
+def _guided_eps(pipe, latents, t, ctx, scale=7.5):
+    x = torch.cat([latents] * 2)
+    eu, ec = pipe.unet(x, torch.tensor([t], device=pipe.device), ctx).chunk(2)
+    return eu + scale * (ec - eu)
+
+
+def test_latents_at_sd14_size_match_fp32_within_stated_tolerance():
+    from uce_amd.sd import pipeline as sdp
+    dev = "cuda:0"
+    pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.float32, dev, synthetic=True, vae=False, seed=0)
+    for m in (pipe.unet, pipe.text_encoder):                       # the model under test = the bf16-rounded weights
+        for p in m.parameters():
+            p.data.copy_(p.data.to(torch.bfloat16).float())
+    # initial noise as the reference's bf16 pipeline draws it (generate-images-sd.py:41: a CPU generator; diffusers'
+    # randn_tensor draws in the pipeline dtype), the SAME tensor for all three runs
+    lat0 = torch.randn((1, 4, 64, 64), generator=torch.Generator().manual_seed(SEED), dtype=torch.bfloat16)
+    probes = {}
+
+    def record(i, t, lat, eps):
+        if i in PROBE_STEPS:
+            probes[i] = (t, lat.detach().float().clone(), eps.detach().float().clone())
+
+    try:
+        # ---- (a) fp32 torch path
+        _set_hip(False)
+        pipe.use_graph = False
+        ref = pipe(PROMPT, num_inference_steps=STEPS, latents=lat0, output_type="latent", callback=record).latents.float()
+        assert ref.shape == (1, 4, 64, 64) and bool(torch.isfinite(ref).all())
+        assert sorted(probes) == list(PROBE_STEPS)
+        # ---- (b) product path: bf16, all kernels, hipGraph replay
+        pipe.to(dev, torch.bfloat16)
+        _set_hip(True)
+        pipe.use_graph = True
+        prod = pipe(PROMPT, num_inference_steps=STEPS, latents=lat0, output_type="latent").latents.float()
+        assert len(pipe._graphs) == 1                               # the step really was replayed from a hipGraph
+        pe, ne = pipe.encode_prompt(PROMPT, dev, 1, True)
+        ctx = torch.cat([ne, pe])
+        per_call = {}
+        pipe.unet.cache_context(ctx)
+        for i, (t, lat, eps) in probes.items():
+            got = _guided_eps(pipe, lat.to(torch.bfloat16), t, ctx).float()
+            per_call[i] = O.rel_fro(got, eps)
+        pipe.unet.cache_context(None)
+        # ---- (c) torch bf16 path (no hand-written kernels)
+        _set_hip(False)
+        pipe.use_graph = False
+        tb = pipe(PROMPT, num_inference_steps=STEPS, latents=lat0, output_type="latent").latents.float()
+        per_call_torch = {i: O.rel_fro(_guided_eps(pipe, lat.to(torch.bfloat16), t, ctx).float(), eps)
+                          for i, (t, lat, eps) in probes.items()}
+    finally:
+        _set_hip(True)
+    final_prod, final_torch = O.rel_fro(prod, ref), O.rel_fro(tb, ref)
+    report = dict(prompt=PROMPT, seed=SEED, steps=STEPS, size="SD-1.4, 512x512 (latents 1x4x64x64), guidance 7.5, PNDM",
+                  weights="seeded-random (no checkpoint on this machine)",
+                  final_relF=dict(product_bf16_vs_fp32=final_prod, torch_bf16_vs_fp32=final_torch,
+                                  product_vs_torch_bf16=O.rel_fro(prod, tb)),
+                  per_call_relF=dict(product_bf16_vs_fp32={str(k): v for k, v in per_call.items()},
+                                     torch_bf16_vs_fp32={str(k): v for k, v in per_call_torch.items()}),
+                  tolerances=dict(per_call=PER_CALL_TOL, final=FINAL_TOL))
+    out = os.path.join(REPO_ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(report, open(os.path.join(out, "latent_parity.json"), "w"), indent=1)
+    print(json.dumps(report))
+    assert max(per_call.values()) <= PER_CALL_TOL, per_call
+    assert final_prod <= FINAL_TOL, (final_prod, final_torch)
+    assert max(per_call.values()) <= 1.25 * max(per_call_torch.values()) + 0.01, (per_call, per_call_torch)
+    assert final_prod <= 1.25 * final_torch + 0.01, (final_prod, final_torch)

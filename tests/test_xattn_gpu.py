@@ -60,6 +60,41 @@ def test_xattn_shapes(H, B, H_, Lq, Lk, dh, dtype):
         assert torch.equal(o, v.expand(B, Lq, C).contiguous())
 
 
+@pytest.mark.parametrize("variant", ["2", "3"])
+@pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
+    (2, 8, 4096, 77, 40, torch.bfloat16),     # one tile per workgroup
+    (8, 8, 1000, 77, 40, torch.bfloat16),     # XCD remap (B % 8 == 0), ragged last tile
+    (3, 16, 333, 77, 40, torch.bfloat16),     # two column groups, ragged, no remap
+    (5, 8, 130, 80, 80, torch.bfloat16),      # 80 keys: the last key row of the LDS image
+    (8, 8, 1024, 77, 80, torch.bfloat16),
+    (2, 8, 256, 77, 160, torch.bfloat16),
+    (16, 4, 70, 33, 160, torch.float16),      # f16, two key tiles only
+    (3, 8, 64, 1, 40, torch.bfloat16),        # a single key: O == V
+])
+def test_xattn_group_kernel_forced(H, variant, B, H_, Lq, Lk, dh, dtype):
+    """The 640-byte column-group kernel (default only at generation-batch sizes) forced at every size: its 16-wave
+    (variant 2) and 8-wave (variant 3) dh = 40 forms, dh = 80 / 160, ragged tiles, the XCD remap, both dtypes."""
+    import os
+    g = torch.Generator().manual_seed(Lq * 11 + dh + B)
+    C = H_ * dh
+    q = torch.randn(B, Lq, C, generator=g).to(dtype)
+    k = torch.randn(B, Lk, C, generator=g).to(dtype)
+    v = torch.randn(B, Lk, C, generator=g).to(dtype)
+    old = os.environ.get("UCE_XATTN_VARIANT")
+    os.environ["UCE_XATTN_VARIANT"] = variant
+    try:
+        o = H.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
+    finally:
+        if old is None:
+            del os.environ["UCE_XATTN_VARIANT"]
+        else:
+            os.environ["UCE_XATTN_VARIANT"] = old
+    ref = O.xattn_ref(q, k, v, H_)
+    assert O.rel_fro(o.double(), ref) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
+    if Lk == 1:
+        assert torch.equal(o, v.expand(B, Lq, C).contiguous())
+
+
 def test_xattn_peaked_and_scaled(H):
     """Large logits (one key dominating) and a custom scale: exercises max-subtraction."""
     g = torch.Generator().manual_seed(3)

@@ -86,6 +86,9 @@ def by_kernel(path, wanted):
     return g
 
 
+ALIASES = {"k_xattn_g": "k_xattn"}       # the column-group form and the per-head form serve the same call
+
+
 def by_order(path, kernel_names, keys):
     """Launch-order split: the i-th group of LAUNCHES_PER_SHAPE launches of each named kernel belongs to keys[i]."""
     g = defaultdict(list)
@@ -93,9 +96,10 @@ def by_order(path, kernel_names, keys):
         return g
     seen = defaultdict(int)
     for _, name, c in dispatches(path):
-        k = short(name, kernel_names)
+        k = short(name, list(kernel_names) + list(ALIASES))
         if not k:
             continue
+        k = ALIASES.get(k, k)
         idx = seen[k] // LAUNCHES_PER_SHAPE
         seen[k] += 1
         if idx < len(keys):

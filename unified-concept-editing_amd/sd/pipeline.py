@@ -322,7 +322,8 @@ class StableDiffusionPipeline:
     @torch.no_grad()
     def __call__(self, prompt, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                  num_images_per_prompt: int = 1, generator=None,
-                 output_type: str = "pil", height: int = None, width: int = None, **kw) -> PipeOutput:
+                 output_type: str = "pil", height: int = None, width: int = None, callback=None,
+                 latents: Optional[torch.Tensor] = None, **kw) -> PipeOutput:
         """`prompt` may be a list: the prompts are denoised as ONE batch (images are independent units, so
         this is the same result per image as calling prompt by prompt, at a multiple of the throughput)."""
         n = num_images_per_prompt
@@ -332,7 +333,10 @@ class StableDiffusionPipeline:
         ctx = torch.cat([ne, pe]) if cfg else pe
         s = self.unet.cfg.sample_size
         hh, ww = (height // 8 if height else s), (width // 8 if width else s)
-        latents = self._draw_latents(n_prompts, n, hh, ww, generator)
+        if latents is None:
+            latents = self._draw_latents(n_prompts, n, hh, ww, generator)
+        else:                                              # diffusers' `latents=`: pre-drawn initial noise
+            latents = latents.to(device=self.device, dtype=self.dtype)
         n = n_prompts * n                                  # batch of the denoising loop from here on
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, device="cpu")
@@ -354,7 +358,7 @@ class StableDiffusionPipeline:
         if graphed is None and self.hoist_context:
             self.unet.cache_context(ctx)
         try:
-            for t in sch.timesteps.tolist():
+            for step_index, t in enumerate(sch.timesteps.tolist()):
                 if graphed is not None:
                     eps = graphed(latents, t)
                 else:
@@ -363,6 +367,8 @@ class StableDiffusionPipeline:
                     if cfg:
                         eu, ec = eps.chunk(2)
                         eps = eu + guidance_scale * (ec - eu)
+                if callback is not None:                   # (step index, timestep, latents fed to the U-Net, guided eps)
+                    callback(step_index, t, latents, eps)
                 latents = sch.step(eps, t, latents)
         finally:
             self.unet.cache_context(None)

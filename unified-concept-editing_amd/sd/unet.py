@@ -221,6 +221,7 @@ class Attention(nn.Module):
 
 
 USE_HIP_SELF_ATTENTION = True     # attn1 through uce_sattn_fwd on a GPU in bf16/f16 (False: torch SDPA)
+USE_HIP_CROSS_ATTENTION = True    # attn2 through uce_xattn_fwd (False: torch SDPA; comparison runs only)
 
 
 def _attention_core(q, k, v, heads: int, is_cross: bool):
@@ -231,9 +232,9 @@ def _attention_core(q, k, v, heads: int, is_cross: bool):
             and q.shape[0] * heads <= 65535:
         from .. import edit as _edit
         handle = _edit.UceHandle.get(q.device)
-        if is_cross and k.shape[1] <= 128:
+        if is_cross and k.shape[1] <= 128 and USE_HIP_CROSS_ATTENTION:
             return handle.xattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
-        if USE_HIP_SELF_ATTENTION:
+        if USE_HIP_SELF_ATTENTION and (USE_HIP_CROSS_ATTENTION or not is_cross):
             return handle.sattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
     B, Lq, C = q.shape
     dh = C // heads
