@@ -351,9 +351,14 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8):
     rank = int(os.environ.get("RANK", "0"))
     batch = max(1, min(batch, n_images))
 
+    # the rows this rank would take of a coco_30k-schema prompt table (tools/make_prompts_csv.py): case r of every `world`
+    from uce_amd import synth
+    table = synth.coco_like_rows(world * n_images, seed=0)
+    mine = table[rank::world]
+
     def run(first, count, nsteps):
-        prompts = [f"synthetic prompt {rank * n_images + first + j}" for j in range(count)]
-        gens = [torch.Generator().manual_seed(1000 + rank * n_images + first + j) for j in range(count)]
+        prompts = [mine[first + j][2] for j in range(count)]
+        gens = [torch.Generator().manual_seed(mine[first + j][3]) for j in range(count)]   # evaluation_seed, CPU generator
         return pipe(prompts if count > 1 else prompts[0], num_inference_steps=nsteps, guidance_scale=7.5,
                     generator=gens if count > 1 else gens[0])
 
@@ -392,7 +397,8 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8):
     out = {"metric": "images/sec 512x512 50-step", "value": round(world * n_images / el, 4), "unit": "images/s",
            "n_gpus": world, "images_per_rank": n_images, "prompts_per_unet_call": batch, "steps": steps, "dtype": "bf16",
            "scaling": "weak",
-           "data": "synthetic weights, synthetic prompts, CPU-seeded latents", "seconds": round(el, 3)}
+           "data": "synthetic weights, coco_30k-schema prompt table (synthetic captions), CPU-seeded latents",
+           "seconds": round(el, 3)}
     if bcast_ms is not None:
         out["weight_broadcast_ms"] = round(bcast_ms, 3)
     return out

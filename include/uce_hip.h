@@ -129,6 +129,13 @@ int uce_profile_end(uce_handle_t h, uce_stream_t stream, char* report, size_t ca
 int uce_debias_targets(uce_handle_t h, const float* C_edit, const float* C_debias, const double* Dsum,
                        int N_edit, int N_debias, int d, float* G, uce_stream_t stream);
 
+/* a2 / SURVEY 8f row 1 - last-token gather of the BATCHED concept-embedding extraction (the reference runs one
+ * text-encoder call per string and slices t_emb[0][0, attention_mask.sum() - 2, :], uce_sd_erase.py:25-42):
+ *   out [B, d] f32 = hidden[i, idx[i], :]  for hidden [B, L, d] in bf16 / f16 / f32 (dtype), idx [B] int32 on the device
+ *   (clamped to [0, L)), d % 8 == 0.  Reads only the B rows that are needed and widens them to fp32 (C / G rows). */
+int uce_gather_last_token(uce_handle_t h, const void* hidden, const int* idx, float* out, int B, int L, int d, int dtype,
+                          uce_stream_t stream);
+
 /* a8 - weight patch (generate-images-sd.py:17-19, uce_sd_debias.py:15-19): f32 -> bf16
  * round-to-nearest-even cast of the edited slab into the U-Net's parameter storage. */
 int uce_cast_bf16(uce_handle_t h, const float* src, void* dst_bf16, long n, uce_stream_t stream);
@@ -181,9 +188,9 @@ int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const
 int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
                        uce_stream_t stream);
 
-/* e - broadcast of the edited blob over RCCL/xGMI.  `comm` is an ncclComm_t.  librccl is
- * dlopen()ed on first use; returns UCE_ENOSYS when it cannot be loaded. */
-int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream);
+/* e - the one exchange step of the multi-GPU generation path (broadcast of the edited weights from rank 0) is issued by
+ * the host through torch.distributed (backend "nccl" = RCCL over xGMI): see uce_amd/generate.py.  The library holds
+ * no communicator and exports no collective. */
 
 #ifdef __cplusplus
 }

@@ -413,3 +413,42 @@ def test_hidream_variant_matches_reference_golden(H, tmp_path):
         got = saved[n + ".weight"]
         assert O.rel_fro(got, ex) < EPS_BUILD
         assert O.rel_fro(got, ref) < max(1e-4, 1.5 * O.rel_fro(ref, ex))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_gather_last_token_matches_indexing(H, dtype):
+    """uce_gather_last_token == hidden[i, idx[i], :].float() bit for bit (uce_sd_erase.py:41 per string)."""
+    g = torch.Generator().manual_seed(5)
+    hidden = torch.randn(9, 77, 768, generator=g).to(dtype).cuda()
+    idx = torch.tensor([0, 1, 2, 5, 20, 40, 74, 75, 76])
+    got = H.gather_last_token(hidden, idx)
+    want = hidden[torch.arange(9, device="cuda"), idx.cuda(), :].float()
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+
+
+def test_batched_embeddings_on_gpu_match_the_reference_call_pattern():
+    """--embed_batch (one text-encoder forward per batch + the gather kernel) gives the rows the
+    reference's one-string-per-call loop gives (uce_sd_erase.py:25-42), on the synthetic CLIP text encoder; includes
+    '' (BOS index), a > 75-token string and duplicates."""
+    from uce_amd import edit as E
+    from uce_amd.sd import pipeline as sdp
+    pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.float32, "cuda:0", synthetic=True, vae=False)
+    prompts = ["Van Gogh", "art", "", "Van Gogh", "a photo of a dog", " ".join(f"w{i}" for i in range(90)), "Monet"]
+    one = E.last_token_embeddings(pipe, prompts, "cuda:0")
+    calls = {"n": 0}
+    orig = E.UceHandle.gather_last_token
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+
+    E.UceHandle.gather_last_token = counted
+    try:
+        bat = E.last_token_embeddings(pipe, prompts, "cuda:0", batch_size=4)
+    finally:
+        E.UceHandle.gather_last_token = orig
+    assert calls["n"] == 2                                   # 6 unique strings in batches of 4
+    assert list(one) == list(bat) and len(one) == 6
+    for k in one:
+        assert one[k].dtype == torch.float32 and one[k].shape == (768,)
+        assert float((one[k] - bat[k]).norm() / one[k].norm()) < 1e-5, k

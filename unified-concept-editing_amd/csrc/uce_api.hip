@@ -1,7 +1,6 @@
 // C ABI of libuce_hip.so (include/uce_hip.h): handle lifetime, argument checks, and the
 // orchestration of the edit pipeline (gram -> potrf chain -> trisolve -> apply) on one stream.
 #include "uce_common.h"
-#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -128,7 +127,7 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
 
 extern "C" {
 
-int uce_version(void) { return 105; }
+int uce_version(void) { return 106; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -411,26 +410,6 @@ int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {
   UCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   *info = v;
   return v ? UCE_EDOM : UCE_OK;
-}
-
-// -------------------------------------------------------------------------------------------
-// RCCL broadcast: librccl is loaded lazily so that the library itself has no link dependency
-// -------------------------------------------------------------------------------------------
-typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void*, hipStream_t);
-
-int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream) {
-  if (!h || !buf || !comm) return UCE_EINVAL;
-  static nccl_bcast_fn fn = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (lib) fn = (nccl_bcast_fn)dlsym(lib, "ncclBroadcast");
-  }
-  if (!fn) return UCE_ENOSYS;
-  const int rc = fn(buf, buf, bytes, /*ncclUint8*/ 1, root, comm, (hipStream_t)stream);
-  return rc == 0 ? UCE_OK : UCE_EHIP - 999;
 }
 
 }  // extern "C"

@@ -203,6 +203,17 @@ class UceHandle:
                                                _ptr(G), _stream_ptr(self.device)), "uce_debias_targets")
         return G
 
+    def gather_last_token(self, hidden: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """[B, L, d] text-encoder output (bf16 / f16 / f32, on this GPU) + [B] token indices -> [B, d] fp32 rows."""
+        B, L, d = hidden.shape
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16, torch.float32: _lib.DTYPE_F32}[hidden.dtype]
+        hidden = hidden.contiguous()
+        idx = idx.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty(B, d, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_gather_last_token(self._h, _ptr(hidden), _ptr(idx), _ptr(out), B, L, d, dt,
+                                                  _stream_ptr(self.device)), "uce_gather_last_token")
+        return out
+
     def cast_bf16(self, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
         assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
         _lib.check(self.lib.uce_cast_bf16(self._h, _ptr(src), _ptr(dst), src.numel(), _stream_ptr(self.device)),
@@ -388,8 +399,12 @@ def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[
                                        do_classifier_free_guidance=False)[0]            # [B, 77, d]
             mask = pipe.tokenizer(chunk, padding="max_length", max_length=pipe.tokenizer.model_max_length,
                                   truncation=True, return_tensors="pt")["attention_mask"]
-            idx = (mask.sum(dim=1) - 2).to(t_emb.device)
-            rows = t_emb[torch.arange(len(chunk), device=t_emb.device), idx, :]
+            idx = mask.sum(dim=1) - 2
+            idx = torch.where(idx < 0, idx + t_emb.shape[1], idx)      # python indexing of the reference: -1 wraps
+            if t_emb.is_cuda and t_emb.shape[-1] % 8 == 0:
+                rows = UceHandle.get(t_emb.device).gather_last_token(t_emb, idx)     # fused gather + fp32 widening (HIP)
+            else:
+                rows = t_emb[torch.arange(len(chunk), device=t_emb.device), idx.to(t_emb.device), :]
             for e, r in zip(chunk, rows):
                 out[e] = r.to(device=device, dtype=torch.float32)
         return out

@@ -40,15 +40,16 @@ def init_distributed(device: torch.device) -> Tuple[int, int]:
     return rank, world
 
 
-def broadcast_uce_weights(path: Optional[str], keys_like, device: torch.device, rank: int, world: int
-                          ) -> Optional[Dict[str, torch.Tensor]]:
+def broadcast_uce_weights(path: Optional[str], keys_like, device: torch.device, rank: int, world: int,
+                          force_collective: bool = False) -> Optional[Dict[str, torch.Tensor]]:
     """Rank 0 loads the safetensors artifact; everyone ends up with the same {name: fp32 tensor}.
-    The tensors travel as ONE flat fp32 buffer (a single broadcast)."""
+    The tensors travel as ONE flat fp32 buffer (a single broadcast).  `force_collective` issues the broadcast even
+    in a one-rank group (single-GPU smoke test of the RCCL path)."""
     if path is None:
         return None
     import torch.distributed as dist
     from safetensors.torch import load_file
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return load_file(path)
     meta: List = [None]
     state = None

@@ -35,6 +35,7 @@ SIGNATURES = {
     "uce_profile_begin": (_i, [_vp]),
     "uce_profile_end": (_i, [_vp, _vp, C.c_char_p, _sz]),
     "uce_debias_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "uce_gather_last_token": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "uce_cast_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
     "uce_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "uce_sattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
@@ -44,7 +45,6 @@ SIGNATURES = {
     "uce_geglu_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "uce_im2col3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "uce_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
-    "uce_bcast": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
 }
 
 _LIB: Optional[C.CDLL] = None

@@ -50,3 +50,40 @@ def linear_default_weight(o: int, d: int, rng: np.random.Generator) -> np.ndarra
     """nn.Linear's default init range U(-1/sqrt(d), 1/sqrt(d))."""
     bound = 1.0 / math.sqrt(d)
     return rng.uniform(-bound, bound, size=(o, d)).astype(np.float32)
+
+
+# ---- prompt tables in the schema of the reference's data/coco_30k.csv (no dataset on these machines) --------------
+_SUBJECTS = ["a man", "a woman", "a child", "two people", "a dog", "a cat", "a horse", "a bird", "a giraffe", "an elephant",
+             "a bicycle", "a motorcycle", "a bus", "a train", "an airplane", "a boat", "a pizza", "a sandwich", "a cake",
+             "a laptop", "a clock", "a vase", "a bench", "a kite", "a skateboard", "a surfboard", "a tennis racket",
+             "a teddy bear", "a fire hydrant", "a stop sign"]
+_VERBS = ["sitting on", "standing next to", "riding", "holding", "looking at", "parked in front of", "lying on",
+          "walking past", "flying over", "placed on"]
+_PLACES = ["a wooden table", "a city street", "a grassy field", "the beach", "a kitchen counter", "a snowy hill",
+           "a parking lot", "a living room couch", "a river bank", "a brick wall", "a train station platform",
+           "a park bench"]
+_TAILS = ["", " at sunset", " on a cloudy day", " in black and white", " with mountains in the background",
+          " next to a window", " under a blue sky", " at night"]
+
+
+def coco_like_rows(n: int, seed: int = 0, first_case: int = 0):
+    """`n` rows (case_number, source, prompt, evaluation_seed, coco_id) in the schema of the reference's
+    data/coco_30k.csv (read by evalscripts/generate-images-sd.py:21-36): caption-like prompts from a small grammar,
+    5-digit evaluation seeds, deterministic in `seed`.  Stands in for the real table, which is not on these machines."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = []
+    for i in range(n):
+        s, v, p, t = (int(rng.integers(len(x))) for x in (_SUBJECTS, _VERBS, _PLACES, _TAILS))
+        prompt = f"{_SUBJECTS[s]} {_VERBS[v]} {_PLACES[p]}{_TAILS[t]}."
+        rows.append((first_case + i, "coco-30k-synthetic", prompt[0].upper() + prompt[1:], int(rng.integers(10000, 100000)),
+                     int(rng.integers(1, 600000))))
+    return rows
+
+
+def write_prompts_csv(path: str, n: int, seed: int = 0) -> str:
+    import csv
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["case_number", "source", "prompt", "evaluation_seed", "coco_id"])
+        w.writerows(coco_like_rows(n, seed))
+    return path
