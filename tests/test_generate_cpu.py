@@ -173,3 +173,42 @@ def test_debias_sampling_is_sharded_over_ranks(tmp_path):
     c0 = open(tmp_path / "calls_w2_r0.txt").read().split(";")
     c1 = open(tmp_path / "calls_w2_r1.txt").read().split(";")
     assert c0 == ["doctor", "teacher", "chef"] and c1 == ["nurse", "pilot"]   # disjoint, round-robin
+
+
+def test_sdxl_topology_tokenless_pipeline_on_cpu():
+    """The SDXL runtime at test widths: module discovery (2x(1+... ) transformer depths), dual-encoder context, pooled
+    conditioning, Euler loop; unknown model ids are an error, not a silent SD-1.x build."""
+    from uce_amd import edit as E
+    pipe = sdp.load_pipeline("tiny-sdxl-test", torch.float32, "cpu", synthetic=True, vae=True)
+    names = [n for n, _ in E.collect_uce_modules(pipe.unet)]
+    # down_blocks.1 (2 attn x 1 block), down_blocks.2 (2 x 2), up_blocks.0 (3 x 2), up_blocks.1 (3 x 1), mid (1 x 2)
+    assert len(names) == 2 * (2 * 1 + 2 * 2 + 3 * 2 + 3 * 1 + 1 * 2)
+    assert names[0].startswith("down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k")
+    assert any(n.startswith("up_blocks.0.attentions.2.transformer_blocks.1.attn2") for n in names)
+    pe, ne, pp, npool = pipe.encode_prompt("a doctor", "cpu", 2, True)
+    assert pe.shape == (2, 77, 64) and pp.shape == (2, 32) and float(ne.abs().max()) == 0.0 and float(npool.abs().max()) == 0.0
+    g = lambda: torch.Generator().manual_seed(1)
+    a = pipe("a doctor", num_inference_steps=3, num_images_per_prompt=2, guidance_scale=7.5, generator=g())
+    b = pipe("a doctor", num_inference_steps=3, num_images_per_prompt=2, guidance_scale=7.5, generator=g())
+    assert a.latents.shape == (2, 4, 8, 8) and torch.equal(a.latents, b.latents) and len(a.images) == 2
+    c = pipe("a nurse", num_inference_steps=3, num_images_per_prompt=2, guidance_scale=7.5, generator=g())
+    assert not torch.equal(a.latents, c.latents)
+    with pytest.raises(ValueError, match="unknown architecture"):
+        sdp.load_pipeline("stabilityai/some-other-model", torch.float32, "cpu", synthetic=True)
+
+
+def test_euler_scheduler_matches_its_closed_form():
+    """EulerDiscreteScheduler ("leading" spacing, offset 1): sigma table, init sigma, input scaling, one step."""
+    from uce_amd.sd.scheduler import EulerDiscreteScheduler
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(20)
+    assert s.timesteps.tolist()[:3] == [951.0, 901.0, 851.0] and s.timesteps.tolist()[-1] == 1.0
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2
+    ac = torch.cumprod(1 - betas, 0).double()
+    sig = ((1 - ac) / ac) ** 0.5
+    assert abs(float(s.sigmas[0]) - float(sig[951])) < 1e-4 and float(s.sigmas[-1]) == 0.0
+    assert abs(s.init_noise_sigma - float((sig[951] ** 2 + 1) ** 0.5)) < 1e-4
+    x, eps = torch.ones(1, 4, 2, 2), torch.full((1, 4, 2, 2), 0.5)
+    assert torch.allclose(s.scale_model_input(x), x / (float(s.sigmas[0]) ** 2 + 1) ** 0.5)
+    y = s.step(eps, 951.0, x)
+    assert torch.allclose(y, x + 0.5 * (float(s.sigmas[1]) - float(s.sigmas[0])))

@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .scheduler import PNDMScheduler
+from .scheduler import EulerDiscreteScheduler, PNDMScheduler
 
 # MIOpen times every applicable solver the first time it meets a convolution; its reference
 # ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
@@ -74,14 +74,19 @@ class TextConfig:
         return cls(hidden, hidden * 2, 2, 2)
 
 
-def build_text_encoder(cfg: TextConfig, model_dir: Optional[str] = None):
-    from transformers import CLIPTextConfig, CLIPTextModel
-    if model_dir and os.path.isdir(os.path.join(model_dir, "text_encoder")):
-        return CLIPTextModel.from_pretrained(os.path.join(model_dir, "text_encoder"))
+def build_text_encoder(cfg: TextConfig, model_dir: Optional[str] = None, sub: str = "text_encoder",
+                       projection_dim: Optional[int] = None, hidden_act: str = "quick_gelu"):
+    """CLIPTextModel (SD-1.x, SDXL's first encoder) or, with `projection_dim`, CLIPTextModelWithProjection (SDXL's
+    second, OpenCLIP-bigG: its pooled `text_embeds` feed the U-Net's micro-conditioning)."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    cls = CLIPTextModel if projection_dim is None else CLIPTextModelWithProjection
+    if model_dir and os.path.isdir(os.path.join(model_dir, sub)):
+        return cls.from_pretrained(os.path.join(model_dir, sub))
+    kw = {} if projection_dim is None else {"projection_dim": projection_dim}
     c = CLIPTextConfig(vocab_size=49408, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
-                       max_position_embeddings=MAX_LEN, hidden_act="quick_gelu")
-    return CLIPTextModel(c)
+                       max_position_embeddings=MAX_LEN, hidden_act=hidden_act, **kw)
+    return cls(c)
 
 
 # ------------------------------------------------------------------------------------ VAE decoder
@@ -170,8 +175,9 @@ class VaeDecoder(nn.Module):
     """AutoencoderKL's decode path (post_quant_conv + decoder), scaling factor 0.18215."""
     scaling_factor = 0.18215
 
-    def __init__(self, ch=(128, 256, 512, 512)):
+    def __init__(self, ch=(128, 256, 512, 512), scaling_factor: float = 0.18215):
         super().__init__()
+        self.scaling_factor = scaling_factor                 # SD-1.x 0.18215, SDXL 0.13025
         self.post_quant_conv = nn.Conv2d(4, 4, 1)
         self.decoder = _Decoder(ch)
 
@@ -384,12 +390,114 @@ class StableDiffusionPipeline:
         return PipeOutput(images=images, latents=latents)
 
 
+class StableDiffusionXLPipeline(StableDiffusionPipeline):
+    """The surface uce_sd_debias.py uses of diffusers' StableDiffusionXLPipeline (`--model_id
+    stabilityai/stable-diffusion-xl-base-1.0`, uce_sd_debias.py:240-242): `.unet` (140 attn2 projections, 2048-d
+    context), `.tokenizer` (CLIP-L's), `.encode_prompt(...)[0]` = the two encoders' penultimate hidden states
+    concatenated ([B, 77, 768 + 1280]), `pipe(prompt, ...).images` with the Euler scheduler, the pooled-text +
+    size/crop micro-conditioning and 1024x1024 default size.  Restated from the published diffusers==0.33.0
+    pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl.py; numerics against diffusers are unpinned."""
+
+    def __init__(self, unet, text_encoder, text_encoder_2, tokenizer, tokenizer_2, vae, scheduler=None):
+        super().__init__(unet, text_encoder, tokenizer, vae, scheduler or EulerDiscreteScheduler())
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.use_graph = False             # the captured step of the base class is the SD-1.x call; SDXL launches eagerly
+        self.force_zeros_for_empty_prompt = True
+
+    def to(self, device=None, dtype=None):
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        super().to(device, dtype)
+        self.text_encoder_2.to(device=device, dtype=dtype)
+        return self
+
+    @torch.no_grad()
+    def encode_prompt(self, prompt, device=None, num_images_per_prompt: int = 1,
+                      do_classifier_free_guidance: bool = False, negative_prompt=None, **kw):
+        """-> (prompt_embeds [B, 77, 2048], negative_prompt_embeds, pooled [B, 1280], negative_pooled)."""
+        device = torch.device(device) if device is not None else self.device
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+
+        def enc(texts):
+            parts, pooled = [], None
+            for tok, te in ((self.tokenizer, self.text_encoder), (self.tokenizer_2, self.text_encoder_2)):
+                ids = tok(texts, padding="max_length", max_length=tok.model_max_length, truncation=True,
+                          return_tensors="pt")["input_ids"].to(device)
+                out = te(input_ids=ids, output_hidden_states=True)
+                pooled = out[0]                                   # kept from the LAST encoder: its projected text_embeds
+                parts.append(out.hidden_states[-2])
+            pe = torch.cat(parts, dim=-1).to(self.dtype)
+            return (pe.repeat_interleave(num_images_per_prompt, dim=0),
+                    pooled.to(self.dtype).repeat_interleave(num_images_per_prompt, dim=0))
+
+        pe, pp = enc(prompts)
+        ne = npool = None
+        if do_classifier_free_guidance:
+            if negative_prompt is None and self.force_zeros_for_empty_prompt:
+                ne, npool = torch.zeros_like(pe), torch.zeros_like(pp)
+            else:
+                neg = [""] * len(prompts) if negative_prompt is None else (
+                    [negative_prompt] * len(prompts) if isinstance(negative_prompt, str) else list(negative_prompt))
+                ne, npool = enc(neg)
+        return pe, ne, pp, npool
+
+    @torch.no_grad()
+    def __call__(self, prompt, num_inference_steps: int = 50, guidance_scale: float = 5.0,
+                 num_images_per_prompt: int = 1, generator=None, output_type: str = "pil", height: int = None,
+                 width: int = None, callback=None, latents: Optional[torch.Tensor] = None, **kw) -> PipeOutput:
+        n = num_images_per_prompt
+        cfg = guidance_scale > 1.0
+        n_prompts = 1 if isinstance(prompt, str) else len(prompt)
+        pe, ne, pp, npool = self.encode_prompt(prompt, self.device, n, cfg)
+        s = self.unet.cfg.sample_size
+        height, width = height or s * 8, width or s * 8
+        hh, ww = height // 8, width // 8
+        if latents is None:
+            latents = self._draw_latents(n_prompts, n, hh, ww, generator)
+        else:
+            latents = latents.to(device=self.device, dtype=self.dtype)
+        n = n_prompts * n
+        ids = torch.tensor([[height, width, 0, 0, height, width]], dtype=self.dtype, device=self.device).repeat(n, 1)
+        ctx = torch.cat([ne, pe]) if cfg else pe
+        added = {"text_embeds": torch.cat([npool, pp]) if cfg else pp, "time_ids": torch.cat([ids, ids]) if cfg else ids}
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps, device="cpu")
+        latents = latents * sch.init_noise_sigma
+        if self.hoist_context:
+            self.unet.cache_context(ctx)
+        try:
+            for step_index, t in enumerate(sch.timesteps.tolist()):
+                x = torch.cat([latents] * 2) if cfg else latents
+                x = sch.scale_model_input(x, t)
+                eps = self.unet(x, torch.tensor([t], device=self.device), ctx, added_cond_kwargs=added)
+                if cfg:
+                    eu, ec = eps.chunk(2)
+                    eps = eu + guidance_scale * (ec - eu)
+                if callback is not None:
+                    callback(step_index, t, latents, eps)
+                latents = sch.step(eps, t, latents)
+        finally:
+            self.unet.cache_context(None)
+        images: list = []
+        if output_type != "latent" and self.vae is not None:
+            img = self.vae.decode(latents).float()
+            img = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()
+            if output_type == "pil":
+                from PIL import Image
+                images = [Image.fromarray((im * 255).round().astype("uint8")) for im in img]
+            else:
+                images = list(img)
+        return PipeOutput(images=images, latents=latents)
+
+
 # ------------------------------------------------------------------------------------ loading
 
 ARCH = {
     "CompVis/stable-diffusion-v1-4": ("sd1", 768),
     "runwayml/stable-diffusion-v1-5": ("sd1", 768),
+    "stabilityai/stable-diffusion-xl-base-1.0": ("sdxl", 2048),
     "tiny-sd-test": ("tiny", 64),
+    "tiny-sdxl-test": ("tiny_xl", 64),
 }
 
 
@@ -418,7 +526,12 @@ def load_pipeline(model_id: str, torch_dtype=torch.float32, device="cpu", model_
             raise RuntimeError(
                 f"cannot load '{model_id}': diffusers is not installed and no --model_dir was given. "
                 "Pass --model_dir <diffusers-format directory> or --synthetic_model (random weights).")
-    kind, _ = ARCH.get(model_id, ("sd1", 768))
+    if model_id not in ARCH:
+        raise ValueError(f"unknown architecture '{model_id}': this runtime builds {sorted(ARCH)} "
+                         "(install diffusers to load any other hub id)")
+    kind, _ = ARCH[model_id]
+    if kind in ("sdxl", "tiny_xl"):
+        return _load_sdxl(kind, torch_dtype, device, model_dir, vae, seed)
     ucfg = UNetConfig.tiny() if kind == "tiny" else UNetConfig.sd14()
     tcfg = TextConfig.tiny(ucfg.cross_attention_dim) if kind == "tiny" else TextConfig()
     torch.manual_seed(seed)
@@ -441,6 +554,39 @@ def load_pipeline(model_id: str, torch_dtype=torch.float32, device="cpu", model_
         if m is not None:
             m.eval().requires_grad_(False)
     pipe = StableDiffusionPipeline(unet, text, load_tokenizer(model_dir), vae_m)
+    return pipe.to(device, torch_dtype)
+
+
+def _load_sdxl(kind: str, torch_dtype, device, model_dir: Optional[str], vae: bool, seed: int) -> StableDiffusionXLPipeline:
+    """SDXL-base (or its small-width test twin): U-Net with 140 attn2 projections, CLIP-L + OpenCLIP-bigG text encoders,
+    the SDXL VAE scaling.  Random weights are drawn directly on the target device (2.6 G parameters)."""
+    tiny = kind == "tiny_xl"
+    ucfg = UNetConfig.tiny_xl() if tiny else UNetConfig.sdxl()
+    t1 = TextConfig.tiny(32) if tiny else TextConfig()
+    t2 = TextConfig.tiny(32) if tiny else TextConfig(1280, 5120, 32, 20)
+    torch.manual_seed(seed)
+    dev = torch.device(device)
+    with torch.device(dev if (dev.type == "cuda" and not model_dir) else "cpu"):
+        unet = UNet2DConditionModel(ucfg)
+        text1 = build_text_encoder(t1, model_dir)
+        text2 = build_text_encoder(t2, model_dir, "text_encoder_2", projection_dim=32 if tiny else 1280, hidden_act="gelu")
+        vae_m = VaeDecoder((32, 32, 64, 64) if tiny else (128, 256, 512, 512), scaling_factor=0.13025) if vae else None
+    if model_dir:
+        from safetensors.torch import load_file
+        unet.load_state_dict(load_file(os.path.join(model_dir, "unet", "diffusion_pytorch_model.safetensors")), strict=True)
+        vp = os.path.join(model_dir, "vae", "diffusion_pytorch_model.safetensors")
+        if vae_m is not None and os.path.exists(vp):
+            sd = {convert_deprecated_vae_key(k): v for k, v in load_file(vp).items()
+                  if k.startswith(("decoder.", "post_quant_conv."))}
+            vae_m.load_state_dict(sd, strict=True)
+    for m in (unet, text1, text2, vae_m):
+        if m is not None:
+            m.eval().requires_grad_(False)
+    tok2 = SyntheticTokenizer()
+    if model_dir and os.path.isdir(os.path.join(model_dir, "tokenizer_2")):
+        from transformers import CLIPTokenizer
+        tok2 = CLIPTokenizer.from_pretrained(os.path.join(model_dir, "tokenizer_2"))
+    pipe = StableDiffusionXLPipeline(unet, text1, text2, load_tokenizer(model_dir), tok2, vae_m)
     return pipe.to(device, torch_dtype)
 
 

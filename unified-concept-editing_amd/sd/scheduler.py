@@ -70,3 +70,43 @@ class PNDMScheduler:
         prev = self._prev_sample(sample, t, t_prev, model_output)
         self.counter += 1
         return prev
+
+
+class EulerDiscreteScheduler:
+    """Euler (ancestral-free) discrete scheduler as SDXL-base ships it (scheduler/scheduler_config.json: scaled_linear betas
+    0.00085 -> 0.012 over 1000 steps, epsilon prediction, timestep_spacing "leading", steps_offset 1, linear sigma
+    interpolation, no Karras sigmas, s_churn 0): what `pipe(...)` runs inside uce_sd_debias.py:22-26 when the model is
+    SDXL.  Restated from the published diffusers==0.33.0 schedulers/scheduling_euler_discrete.py (not installed here)."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 steps_offset: int = 1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0).numpy().astype(np.float64)
+        self.train_sigmas = ((1 - ac) / ac) ** 0.5
+        self.num_train_timesteps = num_train_timesteps
+        self.steps_offset = steps_offset
+        self.timesteps: Optional[torch.Tensor] = None
+        self.sigmas: Optional[np.ndarray] = None
+        self.init_noise_sigma = float((self.train_sigmas.max() ** 2 + 1) ** 0.5)
+        self._index = 0
+
+    def set_timesteps(self, num_inference_steps: int, device=None) -> None:
+        step_ratio = self.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        sig = np.interp(ts, np.arange(0, len(self.train_sigmas)), self.train_sigmas)
+        self.sigmas = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.timesteps = torch.from_numpy(ts).to(device)
+        self.init_noise_sigma = float((self.sigmas.max() ** 2 + 1) ** 0.5)        # "leading" spacing
+        self._index = 0
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        sigma = float(self.sigmas[self._index])
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor) -> torch.Tensor:
+        """x_{i+1} = x_i + eps * (sigma_{i+1} - sigma_i)  (epsilon prediction: the derivative IS the model output);
+        computed in fp32 and cast back, as diffusers does."""
+        sigma, sigma_next = float(self.sigmas[self._index]), float(self.sigmas[self._index + 1])
+        prev = sample.float() + model_output.float() * (sigma_next - sigma)
+        self._index += 1
+        return prev.to(model_output.dtype)

@@ -37,10 +37,40 @@ class UNetConfig:
                                        "CrossAttnUpBlock2D")
     norm_num_groups: int = 32
     sample_size: int = 64
+    # SDXL additions (diffusers UNet2DConditionModel config keys of stabilityai/stable-diffusion-xl-base-1.0)
+    attention_heads: Optional[Tuple[int, ...]] = None          # per-block head counts (SDXL: 5, 10, 20); None: attention_head_dim everywhere
+    transformer_layers_per_block: Tuple[int, ...] = (1, 1, 1, 1)
+    use_linear_projection: bool = False                        # proj_in / proj_out of Transformer2DModel as Linear
+    addition_embed_type: Optional[str] = None                  # "text_time": pooled text embedding + 6 size/crop ids
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
+
+    def heads_of(self, block: int) -> int:
+        return self.attention_heads[block] if self.attention_heads is not None else self.attention_head_dim
 
     @classmethod
     def sd14(cls) -> "UNetConfig":
         return cls()
+
+    @classmethod
+    def sdxl(cls) -> "UNetConfig":
+        """SDXL-base: 70 transformer blocks (2x2 + 2x10 down, 10 mid, 3x10 + 3x2 up) -> 140 attn2 to_k/to_v projections
+        with in_features 2048 (CLIP-L 768 + OpenCLIP-bigG 1280), the edit surface of uce_sd_debias.py:39-46,240-242."""
+        return cls(block_out_channels=(320, 640, 1280), cross_attention_dim=2048, attention_heads=(5, 10, 20),
+                   down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                   up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                   transformer_layers_per_block=(1, 2, 10), use_linear_projection=True, addition_embed_type="text_time",
+                   addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816, sample_size=128)
+
+    @classmethod
+    def tiny_xl(cls) -> "UNetConfig":
+        """SDXL topology, small widths (CPU tests): context 64 = 32 + 32, pooled 32 + 6 x 8 size/crop ids."""
+        return cls(block_out_channels=(32, 64, 64), cross_attention_dim=64, attention_heads=(2, 4, 4),
+                   down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                   up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                   transformer_layers_per_block=(1, 1, 2), use_linear_projection=True, addition_embed_type="text_time",
+                   addition_time_embed_dim=8, projection_class_embeddings_input_dim=32 + 6 * 8, norm_num_groups=8,
+                   sample_size=8)
 
     @classmethod
     def tiny(cls) -> "UNetConfig":
@@ -288,16 +318,25 @@ class BasicTransformerBlock(nn.Module):
 
 
 class Transformer2DModel(nn.Module):
-    def __init__(self, channels: int, heads: int, cross_dim: int, groups: int):
+    def __init__(self, channels: int, heads: int, cross_dim: int, groups: int, depth: int = 1, linear_proj: bool = False):
         super().__init__()
         self.norm = nn.GroupNorm(groups, channels, eps=1e-6)
-        self.proj_in = nn.Conv2d(channels, channels, 1)      # SD-1.x: conv projections
+        self.linear_proj = linear_proj
+        # SD-1.x: 1x1-conv projections; SD-2.x / SDXL (use_linear_projection): Linear on the [B, HW, C] sequence
+        self.proj_in = nn.Linear(channels, channels) if linear_proj else nn.Conv2d(channels, channels, 1)
         self.transformer_blocks = nn.ModuleList(
-            [BasicTransformerBlock(channels, heads, channels // heads, cross_dim)])
-        self.proj_out = nn.Conv2d(channels, channels, 1)
+            [BasicTransformerBlock(channels, heads, channels // heads, cross_dim) for _ in range(depth)])
+        self.proj_out = nn.Linear(channels, channels) if linear_proj else nn.Conv2d(channels, channels, 1)
 
     def forward(self, x, context):
         B, C, H, W = x.shape
+        if self.linear_proj:
+            h = group_norm_act(self.norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = self.proj_in(h)
+            for blk in self.transformer_blocks:
+                h = blk(h, context)
+            h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
+            return add_bias(x, h, None)
         h = conv2d(self.proj_in, group_norm_act(self.norm, x, False))
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
@@ -325,11 +364,13 @@ class Upsample2D(nn.Module):
 
 
 class DownBlock(nn.Module):
-    def __init__(self, cin, cout, temb, groups, layers, cross: bool, heads, cross_dim, add_down: bool):
+    def __init__(self, cin, cout, temb, groups, layers, cross: bool, heads, cross_dim, add_down: bool, depth: int = 1,
+                 linear_proj: bool = False):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(layers)])
         if cross:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(layers)])
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups, depth, linear_proj)
+                                             for _ in range(layers)])
         self.has_cross = cross
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
 
@@ -347,7 +388,8 @@ class DownBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cin, cout, cprev, temb, groups, layers, cross: bool, heads, cross_dim, add_up: bool):
+    def __init__(self, cin, cout, cprev, temb, groups, layers, cross: bool, heads, cross_dim, add_up: bool, depth: int = 1,
+                 linear_proj: bool = False):
         super().__init__()
         res = []
         for i in range(layers):
@@ -356,7 +398,8 @@ class UpBlock(nn.Module):
             res.append(ResnetBlock2D(rin + skip, cout, temb, groups))
         self.resnets = nn.ModuleList(res)
         if cross:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(layers)])
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups, depth, linear_proj)
+                                             for _ in range(layers)])
         self.has_cross = cross
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
 
@@ -372,9 +415,9 @@ class UpBlock(nn.Module):
 
 
 class MidBlock(nn.Module):
-    def __init__(self, c, temb, groups, heads, cross_dim):
+    def __init__(self, c, temb, groups, heads, cross_dim, depth: int = 1, linear_proj: bool = False):
         super().__init__()
-        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, cross_dim, groups)])
+        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, cross_dim, groups, depth, linear_proj)])
         self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups), ResnetBlock2D(c, c, temb, groups)])
 
     def forward(self, x, temb, context):
@@ -393,24 +436,30 @@ class UNet2DConditionModel(nn.Module):
         ch = cfg.block_out_channels
         temb = ch[0] * 4
         g = cfg.norm_num_groups
-        heads = cfg.attention_head_dim
+        nblk = len(ch)
+        depth = list(cfg.transformer_layers_per_block)[:nblk]
+        lin = cfg.use_linear_projection
         self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
         self.time_embedding = TimestepEmbedding(ch[0], temb)
+        if cfg.addition_embed_type == "text_time":               # SDXL micro-conditioning (registered where diffusers does)
+            self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, temb)
         self.down_blocks = nn.ModuleList([])
         self.up_blocks = nn.ModuleList([])
         out = ch[0]
         for i, t in enumerate(cfg.down_block_types):
             cin, out = out, ch[i]
             self.down_blocks.append(DownBlock(cin, out, temb, g, cfg.layers_per_block, t.startswith("CrossAttn"),
-                                              heads, cfg.cross_attention_dim, add_down=i < len(ch) - 1))
-        self.mid_block = MidBlock(ch[-1], temb, g, heads, cfg.cross_attention_dim)
+                                              cfg.heads_of(i), cfg.cross_attention_dim, add_down=i < nblk - 1,
+                                              depth=depth[i], linear_proj=lin))
+        self.mid_block = MidBlock(ch[-1], temb, g, cfg.heads_of(nblk - 1), cfg.cross_attention_dim, depth[-1], lin)
         rev = list(reversed(ch))
         out = rev[0]
         for i, t in enumerate(cfg.up_block_types):
             prev, out = out, rev[i]
-            cin = rev[min(i + 1, len(ch) - 1)]
+            cin = rev[min(i + 1, nblk - 1)]
             self.up_blocks.append(UpBlock(cin, out, prev, temb, g, cfg.layers_per_block + 1, t.startswith("CrossAttn"),
-                                          heads, cfg.cross_attention_dim, add_up=i < len(ch) - 1))
+                                          cfg.heads_of(nblk - 1 - i), cfg.cross_attention_dim, add_up=i < nblk - 1,
+                                          depth=depth[nblk - 1 - i], linear_proj=lin))
         self.conv_norm_out = nn.GroupNorm(g, ch[0], eps=1e-5)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
 
@@ -420,12 +469,17 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, Attention) and m.is_cross:
                 m.kv_cache = None if context is None else (m.to_k(context), m.to_v(context))
 
-    def forward(self, sample, timestep, encoder_hidden_states):
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], device=sample.device)
         t = t.reshape(-1).expand(sample.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.cfg.block_out_channels[0]).to(sample.dtype))
+        if self.cfg.addition_embed_type == "text_time":
+            # diffusers get_aug_embed: sinusoidal embedding of the 6 size / crop ids + the pooled text embedding
+            text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            tid = timestep_embedding(time_ids.flatten(), self.cfg.addition_time_embed_dim).reshape(text_embeds.shape[0], -1)
+            temb = temb + self.add_embedding(torch.cat([text_embeds, tid.to(text_embeds.dtype)], dim=-1).to(sample.dtype))
         x = self.conv_in(sample)
         skips = [x]
         for blk in self.down_blocks:
