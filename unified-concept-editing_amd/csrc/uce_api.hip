@@ -35,10 +35,10 @@ static void prof_clear(uce_ctx* h) {
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 static void free_ws(uce_ctx* h) {
-  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->DeltaT, h->DeltaP, h->Dm, h->R};  // (T is separate)
+  void* ptrs[] = {h->M, h->Lmat, h->Linv, h->slabs, h->Bt, h->Yg, h->Wi, h->DeltaT, h->DeltaP, h->Dm, h->R};  // (T is separate)
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  h->M = h->Lmat = h->Linv = h->slabs = h->Bt = h->Yg = nullptr;
+  h->M = h->Lmat = h->Linv = h->slabs = h->Bt = h->Yg = h->Wi = nullptr;
   h->DeltaT = h->Dm = h->R = nullptr;
   h->DeltaP = nullptr;
   h->slabs_bytes = 0;
@@ -80,7 +80,8 @@ int uce_ensure(uce_ctx* h, int d, int n) {
   alloc((void**)&h->Linv, (size_t)(nc / 64) * 64 * 64 * sizeof(double));
   alloc((void**)&h->slabs, slabs);
   alloc((void**)&h->Bt, dd * sizeof(double));
-  alloc((void**)&h->Yg, nc > 1024 ? (size_t)nc * dc * sizeof(double) : 16);
+  alloc((void**)&h->Yg, (size_t)nc * dc * sizeof(double));
+  alloc((void**)&h->Wi, nn * sizeof(double));
   alloc((void**)&h->DeltaT, dd * sizeof(float));
   alloc((void**)&h->DeltaP, 3 * dd * sizeof(unsigned short));
   alloc((void**)&h->Dm, (size_t)nc * dc * sizeof(float));
@@ -223,7 +224,7 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
   }
   if (rc) return rc;
   UceProfScope ps(h, "k_trisolve", st);
-  return launch_trisolve(h, d, d, Bt, nullptr, d, DeltaT, d, st);
+  return launch_trisolve(h, d, d, Bt, nullptr, d, DeltaT, d, st, A);
 }
 
 int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,
@@ -265,7 +266,7 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
   if (rc) return rc;
   if (N_edit == 0) return UCE_OK;
   UceProfScope ps(h, "k_trisolve", st);
-  return launch_trisolve(h, n_pad, d, nullptr, C, N, R, N_edit, st);
+  return launch_trisolve(h, n_pad, d, nullptr, C, N, R, N_edit, st, h->M);
 }
 
 int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int N_edit, int d,
@@ -355,7 +356,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     }
     {
       UceProfScope ps(h, "k_trisolve", st);
-      rc = launch_trisolve(h, n_pad, d, nullptr, C, N, h->R, N_edit, st);
+      rc = launch_trisolve(h, n_pad, d, nullptr, C, N, h->R, N_edit, st, h->M);
     }
     if (rc) return rc;
     UceProfScope ps(h, "k_lr_update", st);

@@ -50,7 +50,8 @@ struct uce_ctx {
   double* slabs;  // split-K partial sums of the Gram kernels
   size_t slabs_bytes;
   double* Bt;     // [d_cap, d_cap] right-hand side of the primal solve
-  double* Yg;     // [n_cap, d_cap] global scratch for the triangular solves when n > 1024
+  double* Yg;     // [n_cap, d_cap] intermediate of the triangular solves (Y = L^-1 RHS)
+  double* Wi;     // [n_cap, n_cap] explicit L^-1 of the GEMM-shaped triangular solves (uce_trinv.hip)
   float* DeltaT;  // [d_cap, d_cap]
   unsigned short* DeltaP;  // [3][d_cap, d_cap] bf16 planes of Delta^T (uce_apply_b3.hip)
   float* Dm;      // [n_cap, d_cap]
@@ -90,8 +91,12 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
 int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st);
 // X = M^-1 RHS after launch_potrf.  RHS is f64 [n, m] (rhs64) or f32 [rhs_rows, m] (rhs32, rows
 // beyond rhs_rows are zero).  out f32 [out_rows, m] gets rows 0..out_rows-1 of X.
+// `scratch` [n, n] f64 (optional): the factored matrix, dead after launch_potrf - with it, systems of >= 3 diagonal
+// blocks take the GEMM-shaped path (explicit L^-1 by recursive doubling, uce_trinv.hip).
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
-                    float* out, int out_rows, hipStream_t st);
+                    float* out, int out_rows, hipStream_t st, double* scratch = nullptr);
+int launch_trisolve_inv(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows, float* out,
+                        int out_rows, double* scratch, hipStream_t st);
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
 int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* planes, float* W_new, long rows, int d,
                     hipStream_t st, uce_ctx* h = nullptr);

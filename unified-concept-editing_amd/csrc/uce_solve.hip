@@ -13,6 +13,7 @@
 //                   substitution with the inverted diagonal blocks; Y lives in LDS (n <= 1024).
 #include "uce_common.h"
 #include "uce_potrf64.h"
+#include <cstdlib>
 
 namespace {
 
@@ -242,7 +243,11 @@ int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
 }
 
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
-                    float* out, int out_rows, hipStream_t st) {
+                    float* out, int out_rows, hipStream_t st, double* scratch) {
+  // UCE_TRISOLVE_VARIANT=0 keeps the substitution kernel at every size (A/B measurements)
+  static const int variant = getenv("UCE_TRISOLVE_VARIANT") ? atoi(getenv("UCE_TRISOLVE_VARIANT")) : 1;
+  if (variant && scratch && n >= 192 && m % 64 == 0)
+    return launch_trisolve_inv(h, n, m, rhs64, rhs32, rhs_rows, out, out_rows, scratch, st);
   const bool use_lds = n <= 1024;
   const size_t smem = 64 * 16 * 8 + (use_lds ? (size_t)n * 16 * 8 : 0);
   double* Yg = use_lds ? nullptr : h->Yg;
