@@ -24,6 +24,8 @@ PUBLIC_HEADER = os.path.normpath(os.path.join(PKG, "..", "include", "uce_hip.h")
 # its heuristics the compiler parks them in AGPRs and pays a v_accvgpr_read/write pair around every VALU
 # touch of an accumulator - 128 extra moves per key tile in the attention kernels' softmax.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+if os.environ.get("UCE_CHAIN_DEBUG"):          # phase stamps of the rider chain (tools/dbg_chain.py); never in the product build
+    FLAGS.append("-DUCE_CHAIN_DEBUG")
 
 
 def sources() -> list[str]:

@@ -156,8 +156,8 @@ int uce_create(uce_handle_t* out, int device) {
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->status, 0, sizeof(int));
-  if (hipMalloc((void**)&h->ticket, sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
-  (void)hipMemset(h->ticket, 0, sizeof(unsigned));
+  if (hipMalloc((void**)&h->ticket, 2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
+  (void)hipMemset(h->ticket, 0, 2 * sizeof(unsigned));
   *out = h;
   return UCE_OK;
 }
@@ -260,8 +260,8 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
   if (rc) return rc;
   {
     UceProfScope ps(h, "potrf", st);
-    rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
-                      : launch_potrf(h, h->M, n_pad, st);
+    rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st, N)
+                      : launch_potrf(h, h->M, n_pad, st, N);
   }
   if (rc) return rc;
   if (N_edit == 0) return UCE_OK;
@@ -332,9 +332,12 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     rc = uce_ensure_T(h, rows, N_edit);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (n_pad <= lr_rider_max_n()) {
-      UceProfScope ps(h, "k_lr_project", st);          // with the Gram + Cholesky rider blocks
-      rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st, h, C, s, N, lamb);
+    const bool riders = n_pad <= lr_rider_max_n();
+    if (riders) {
+      // TWO launches: projection || (Gram -> Cholesky -> triangular solves, all in rider blocks of the same launch),
+      // then the update
+      UceProfScope ps(h, "k_lr_project", st);
+      rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st, h, C, s, N, lamb, h->R);
       if (rc) return rc;
     } else {
       int nsplit = 1;
@@ -346,19 +349,19 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
       if (rc) return rc;
       {
         UceProfScope ps(h, "potrf", st);
-        rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st)
-                          : launch_potrf(h, h->M, n_pad, st);
+        rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st, N)
+                          : launch_potrf(h, h->M, n_pad, st, N);
       }
       if (rc) return rc;
       UceProfScope ps(h, "k_lr_project", st);
       rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st);
       if (rc) return rc;
     }
-    {
+    if (!riders) {
       UceProfScope ps(h, "k_trisolve", st);
       rc = launch_trisolve(h, n_pad, d, nullptr, C, N, h->R, N_edit, st, h->M);
+      if (rc) return rc;
     }
-    if (rc) return rc;
     UceProfScope ps(h, "k_lr_update", st);
     return launch_lr_update(W_old, h->T, h->R, W_new, rows, d, N_edit, st);
   }

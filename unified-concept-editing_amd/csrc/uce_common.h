@@ -57,7 +57,8 @@ struct uce_ctx {
   float* Dm;      // [n_cap, d_cap]
   float* R;       // [n_cap, d_cap]
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
-  unsigned* ticket;  // arrival counter of the rider blocks (zero between launches)
+  unsigned* ticket;  // [0] arrival counter of the rider blocks (zero between launches), [1] "factorisation done" sequence word
+  unsigned seq;      // launches with riders so far (the value the solve riders wait for)
   float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply
   size_t T_elems;
   void* Vt;       // V^T scratch of uce_sattn_fwd ([B, H, DVP, LkP] 16-bit elements)
@@ -87,8 +88,9 @@ int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* 
 int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, float lamb, double* K,
                      int n_pad, const float* G, float* Dm, int N_edit, int* nsplit_out,
                      size_t* slab_stride_out, hipStream_t st);
-int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st);
-int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st);
+// n_valid (0 = n): rows / columns >= n_valid are the identity padding of the system (their pivots are skipped).
+int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid = 0);
+int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st, int n_valid = 0);
 // X = M^-1 RHS after launch_potrf.  RHS is f64 [n, m] (rhs64) or f32 [rhs_rows, m] (rhs32, rows
 // beyond rhs_rows are zero).  out f32 [out_rows, m] gets rows 0..out_rows-1 of X.
 // `scratch` [n, n] f64 (optional): the factored matrix, dead after launch_potrf - with it, systems of >= 3 diagonal
@@ -108,9 +110,11 @@ int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d
 int launch_sub_rows(const float* G, const float* C, float* Dm, long n, hipStream_t st);
 bool lowrank_split_supported(int d, int N_edit);
 int lr_rider_max_n();   // largest dual system (rows, multiple of 64) the projection launch's riders factor
+// With `h`: the launch also carries the whole small-system chain (Gram + Cholesky riders, then the solve riders
+// that write R [N_edit, d] = rows of K^-1 C) - the caller needs no separate triangular-solve launch.
 int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
                       int N_edit, hipStream_t st, uce_ctx* h = nullptr, const float* C = nullptr,
-                      const float* s = nullptr, int N = 0, float lamb = 0.f);
+                      const float* s = nullptr, int N = 0, float lamb = 0.f, float* R = nullptr);
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
 int uce_ensure_T(uce_ctx* h, long rows, int N_edit);

@@ -15,6 +15,18 @@
 #include "uce_potrf64.h"
 #include <cstdlib>
 
+// -DUCE_CHAIN_DEBUG: wall-clock stamps (100 MHz) of the rider chain's phases, read back with uce_debug_read
+// (tools/dbg_chain.py); compiled out of the product library.
+#ifdef UCE_CHAIN_DEBUG
+__device__ unsigned long long g_dbg[64][16];
+#define DBG(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_dbg[blockIdx.x][slot] = wall_clock64(); } while (0)
+extern "C" int uce_debug_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
+}
+#else
+#define DBG(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int PJ_KC = 64;    // floats per W k-chunk
@@ -135,11 +147,11 @@ __device__ __forceinline__ void project_body(const float* __restrict__ W_old, co
 // the d features, split over GP_NB blocks x 2 wave quads), then the 64x64 Cholesky + inverse by the
 // rider block that finishes its slab LAST.  Riders need nothing from the projection and vice versa,
 // so riding along costs no launch and no event, and - being shorter than the GEMM beside them - no
-// time.  The slab hand-off between rider blocks is the split-K reduction of the CDNA guide (G16):
-// plain slab stores -> per-wave vmcnt(0) -> barrier -> one lane: agent-scope release fence + vmcnt(0)
-// -> relaxed agent-scope ticket; the block drawing the last ticket does one agent-scope acquire,
-// a barrier, then plain loads of all slabs (summed in slab order: bit-repeatable).  Correct for any
-// placement of the rider blocks; the ticket word is zero at creation and reset by its last taker.
+// time.  The slab hand-off between rider blocks is the split-K reduction of the CDNA guide (G16) in its write-through
+// form: sc1 slab stores -> per-wave vmcnt(0) -> barrier -> one lane draws a relaxed agent-scope ticket; the block
+// drawing the last ticket reads all slabs with sc1 loads (summed in slab order: bit-repeatable) - no release / acquire
+// fence on either side (st_sc1 below).  Correct for any placement of the rider blocks; the ticket word is zero at
+// creation and reset by its last taker.
 struct GramPotrfJob {
   const float* C;       // [N, d]; null = no riders
   const float* s;       // [N]
@@ -152,6 +164,9 @@ struct GramPotrfJob {
   int* status;
   double* M;            // [n, n] assembled system (nb > 1 only)
   int nb;               // 64-blocks of the dual system handled by the riders: 1 or 2
+  float* R;             // [N_edit, d] rows of K^-1 C, written by the solve riders (null: no solve riders)
+  int N_edit;
+  unsigned seq;         // value of ticket[1] that announces THIS launch's factorisation
 };
 
 constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of the system (split over the feature axis)
@@ -161,8 +176,187 @@ constexpr int GP_TLD = 66;      // doubles
 
 __host__ __device__ constexpr int gp_riders(int nb) { return GP_NB * nb * (nb + 1) / 2; }
 
+// Write-through (sc1) stores / L1-bypassing (sc1) loads of hand-off payloads: a relaxed agent-scope atomic of 8 bytes
+// lowers to global_store/load_dwordx2 sc1.  Payload published this way needs NO release fence (buffer_wbl2 writes back
+// every dirty line of the XCD's L2 - megabytes of T while the projection streams - and cost several microseconds per
+// hand-off here) and the consumer needs no acquire (no L1 invalidate): drained stores -> barrier -> relaxed flag /
+// ticket on one side, relaxed poll -> barrier -> sc1 loads on the other (CDNA guide, Guideline 16, the sc1 form).
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The factorising block tells the solve riders that L / L^-1 of this launch are in memory: all its stores drained,
+// one agent-scope release, then the sequence word (the hand-off recipe of the CDNA guide, Guideline 16).
+// `fence`: the payload was written with plain stores (the 128 x 128 path shares its tile bodies with the launch chain)
+// and needs the agent-scope release; the single-tile path stores L / L^-1 write-through and skips it.
+__device__ __forceinline__ void announce_factor(const GramPotrfJob& j, bool fence) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (fence) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __hip_atomic_store(j.ticket + 1, j.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Solve riders (blocks after the Gram riders, one per 64 columns of R): wait for the factorisation of THIS launch,
+// then  R[:, cols] = rows 0..N_edit-1 of  L^-T L^-1 C[:, cols]  with the inverted diagonal blocks - the triangular
+// solves that used to be a launch of their own between the projection and the update.  64 x 64 f64 tiles in LDS
+// (stride SV_LD), 8 waves x two 16 x 16 MFMA tiles, full contraction per wave (no partial sums to combine).
+// ---------------------------------------------------------------------------------------------
+constexpr int SV_LD = 66;
+constexpr size_t SV_TILE = (size_t)64 * SV_LD * sizeof(double);
+__host__ __device__ constexpr size_t sv_smem(int nb) { return (nb <= 1 ? 3 : 4) * SV_TILE; }
+
+// dst = base - / + op(A) * B :  A, B, dst (, base) are LDS tiles [64][SV_LD]; TA: op(A)[i][k] = A[k][i].
+// B is read as [k][col].  base == nullptr: dst = op(A) B.  (dst may alias base, never A or B.)
+template <bool TA>
+__device__ __forceinline__ void sv_prod(double* dst, const double* A, const double* B, const double* base, double sign) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int row0 = 16 * (w & 3), col0 = 32 * (w >> 2);
+  double4_t acc[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll 4
+  for (int kb = 0; kb < 16; ++kb) {
+    const int t = 4 * kb + kk;
+    const double a = TA ? A[t * SV_LD + row0 + r] : A[(row0 + r) * SV_LD + t];
+    acc[0] = mfma_f64(a, B[t * SV_LD + col0 + r], acc[0]);
+    acc[1] = mfma_f64(a, B[t * SV_LD + col0 + 16 + r], acc[1]);
+  }
+  // D layout: row = kk + 4q, col = r
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = (row0 + kk + 4 * q) * SV_LD + col0 + 16 * n + r;
+      dst[o] = (base ? base[o] : 0.0) + sign * acc[n][q];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char* smem_raw, int colblk) {
+  double* Ms = (double*)smem_raw;                       // the matrix operand of the current product
+  double* W0 = Ms + 64 * SV_LD;
+  double* W1 = W0 + 64 * SV_LD;
+  double* W2 = W1 + 64 * SV_LD;                         // (nb == 2 only)
+  const int tid = threadIdx.x;
+  const int n = 64 * j.nb;
+  // 64 concepts x this block's 64 columns of C (rows >= N are zero) -> LDS, widened to f64.  Needs nothing from the
+  // factorisation: loaded before the wait.
+  auto load_c = [&](double* Wt, int kblk) {
+    for (int e = tid; e < 64 * 16; e += 512) {
+      const int r = e >> 4, c4 = (e & 15) << 2;
+      const int row = kblk * 64 + r;
+      float4_t v = {0.f, 0.f, 0.f, 0.f};
+      if (row < j.N) v = *(const float4_t*)(j.C + (size_t)row * D + colblk * 64 + c4);
+      Wt[r * SV_LD + c4] = (double)v[0];
+      Wt[r * SV_LD + c4 + 1] = (double)v[1];
+      Wt[r * SV_LD + c4 + 2] = (double)v[2];
+      Wt[r * SV_LD + c4 + 3] = (double)v[3];
+    }
+  };
+  auto load_m = [&](const double* G, int ld) {            // a 64 x 64 block of a row-major f64 matrix -> Ms
+    if (j.nb == 1) {                                      // published write-through: read it past the L1
+      double v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int e = tid + 512 * p;
+        v[p] = ld_sc1(G + (size_t)(e >> 6) * ld + (e & 63));
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int e = tid + 512 * p;
+        Ms[(e >> 6) * SV_LD + (e & 63)] = v[p];
+      }
+      return;
+    }
+    for (int e = tid; e < 64 * 32; e += 512) {
+      const int r = e >> 5, c2 = (e & 31) << 1;
+      typedef double double2_t __attribute__((ext_vector_type(2)));
+      const double2_t v = *(const double2_t*)(G + (size_t)r * ld + c2);
+      Ms[r * SV_LD + c2] = v[0];
+      Ms[r * SV_LD + c2 + 1] = v[1];
+    }
+  };
+  auto store_r = [&](const double* Wt, int kblk) {        // rows of X -> R (fp32), rows < N_edit only
+    for (int e = tid; e < 64 * 16; e += 512) {
+      const int r = e >> 4, c4 = (e & 15) << 2;
+      const int row = kblk * 64 + r;
+      if (row < j.N_edit)
+        *(float4_t*)(j.R + (size_t)row * D + colblk * 64 + c4) =
+            (float4_t){(float)Wt[r * SV_LD + c4], (float)Wt[r * SV_LD + c4 + 1], (float)Wt[r * SV_LD + c4 + 2],
+                       (float)Wt[r * SV_LD + c4 + 3]};
+    }
+  };
+  DBG(0);
+  load_c(W0, 0);
+  DBG(1);
+  // ---- wait for this launch's factorisation: one lane polls (relaxed, with s_sleep), one acquire, then plain loads
+  if (tid == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(j.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != j.seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 24)) {                          // ~ seconds: the factorising block never ran (cannot happen
+        atomicCAS(j.status, 0, -1);                        //   with in-order dispatch); report instead of hanging
+        break;
+      }
+    }
+    if (j.nb != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  DBG(2);
+  const double* Linv0 = j.Linv;
+  if (j.nb == 1) {
+    load_m(Linv0, 64);
+    __syncthreads();
+    DBG(3);
+    sv_prod<false>(W1, Ms, W0, nullptr, 1.0);             // Y = L^-1 C
+    __syncthreads();
+    sv_prod<true>(W0, Ms, W1, nullptr, 1.0);              // X = L^-T Y
+    __syncthreads();
+    DBG(4);
+    store_r(W0, 0);
+    DBG(5);
+    return;
+  }
+  const double* Linv1 = j.Linv + 4096;
+  const double* L10 = j.Lmat + (size_t)64 * n;            // block (1, 0) of L
+  load_m(Linv0, 64);
+  __syncthreads();
+  sv_prod<false>(W1, Ms, W0, nullptr, 1.0);               // Y0 = L00^-1 C0
+  __syncthreads();
+  load_c(W0, 1);
+  load_m(L10, n);
+  __syncthreads();
+  sv_prod<false>(W0, Ms, W1, W0, -1.0);                   // C1 - L10 Y0
+  __syncthreads();
+  load_m(Linv1, 64);
+  __syncthreads();
+  sv_prod<false>(W2, Ms, W0, nullptr, 1.0);               // Y1
+  __syncthreads();
+  sv_prod<true>(W0, Ms, W2, nullptr, 1.0);                // X1 = L11^-T Y1
+  __syncthreads();
+  store_r(W0, 1);
+  load_m(L10, n);
+  __syncthreads();
+  sv_prod<true>(W1, Ms, W0, W1, -1.0);                    // Y0 - L10^T X1
+  __syncthreads();
+  load_m(Linv0, 64);
+  __syncthreads();
+  sv_prod<true>(W2, Ms, W1, nullptr, 1.0);                // X0
+  __syncthreads();
+  store_r(W2, 0);
+}
+
 template <int D>
 __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned char* smem_raw) {
+  DBG(0);
   float* As = (float*)smem_raw;                                   // [2 halves][64][GP_LD]  rows of block ti
   float* Bs = As + 2 * 64 * GP_LD;                                // [2 halves][64][GP_LD]  rows of block tk
   constexpr size_t AB_BYTES = (size_t)4 * 64 * GP_LD * sizeof(float);
@@ -227,6 +421,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     }
     __syncthreads();
   }
+  DBG(1);
   // D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15
   const int c = lane & 15, rq = lane >> 4;
   if (half == 1) {
@@ -247,31 +442,50 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wr + m * 16 + rq + 4 * r, col = wc + n * 16 + c;
-          myslab[row * 64 + col] = acc[m][n][r] + P1[row * GP_TLD + col];
+          st_sc1(&myslab[row * 64 + col], acc[m][n][r] + P1[row * GP_TLD + col]);
         }
   }
   // ---- publish the slab, draw a ticket (CDNA guide, Guideline 16 / split-K reduction recipe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (slabs went out write-through and are read back past the L1: no release / acquire fence - see st_sc1)
     const unsigned t = __hip_atomic_fetch_add(j.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_last_p = (t == (unsigned)nriders - 1) ? 1u : 0u;
     if (t == (unsigned)nriders - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(j.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       *j.status = 0;
     }
   }
   __syncthreads();
+  DBG(2);
   if (!*s_last_p) return;
   auto diag_term = [&](int row) -> double {
     const float sv = (row < j.N) ? j.s[row] : 1.f;
     return (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
   };
   if (j.nb == 1) {
-    // last arriver: all 8 waves factor - waves 0-3 carry the matrix tiles, waves 4-7 the tiles of L^-1
+    // last arriver: all 8 waves factor - waves 0-3 carry the matrix tiles, waves 4-7 the tiles of L^-1.
+    // The GP_NB slabs are summed by ALL 512 threads (8 elements each, every load independent and in flight at
+    // once, fixed slab order: bit-repeatable) into the LDS tile the matrix waves then pick their 4x4 tiles from.
+    double* Ksum = (double*)smem_raw;                             // [64][GP_TLD] (the Gram staging is dead)
+    {
+      double v[GP_NB][8];
+#pragma unroll
+      for (int b = 0; b < GP_NB; ++b)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[b][p] = ld_sc1(&j.slabs[(size_t)b * 4096 + tid + 512 * p]);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int e = tid + 512 * p, row = e >> 6, col = e & 63;
+        double acc = v[0][p];
+#pragma unroll
+        for (int b = 1; b < GP_NB; ++b) acc += v[b][p];
+        if (row == col) acc += diag_term(row);
+        Ksum[row * GP_TLD + col] = acc;
+      }
+    }
+    __syncthreads();
     const int t256 = tid & 255;
     const int tti = t256 >> 4, ttj = t256 & 15;
     double tt[4][4];
@@ -279,26 +493,28 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int row = 4 * tti + r, col = 4 * ttj + cc;
-          double v = j.slabs[row * 64 + col];
-#pragma unroll
-          for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)b * 64 * 64 + row * 64 + col];   // fixed order
-          if (row == col) v += diag_term(row);
-          tt[r][cc] = v;
-        }
-      potrf64_reg8<0>(tt, sc, t256, j.status, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) j.Lmat[(4 * tti + r) * 64 + 4 * ttj + cc] = tt[r][cc];
-    } else {
-      potrf64_reg8<1>(tt, sc, t256, j.status, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) j.Linv[(4 * tti + r) * 64 + 4 * ttj + cc] = tt[r][cc];
+        for (int cc = 0; cc < 4; ++cc) tt[r][cc] = Ksum[(4 * tti + r) * GP_TLD + 4 * ttj + cc];
     }
+    __syncthreads();                                              // Ksum is read before the scratch (same LDS) is used
+    DBG(3);
+    if (half == 0) {
+      potrf64_reg8<0>(tt, sc, t256, j.status, 0, j.N);
+      DBG(4);
+      if (!j.R) {                                                 // (with solve riders nobody reads L: only L^-1 leaves)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) st_sc1(&j.Lmat[(4 * tti + r) * 64 + 4 * ttj + cc], tt[r][cc]);
+      }
+    } else {
+      potrf64_reg8<1>(tt, sc, t256, j.status, 0, j.N);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) st_sc1(&j.Linv[(4 * tti + r) * 64 + 4 * ttj + cc], tt[r][cc]);
+    }
+    announce_factor(j, false);
+    DBG(5);
     return;
   }
   // nb == 2: the last arriver assembles the 128 x 128 system and runs the blocked factorisation that
@@ -309,40 +525,52 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     const int gi = t == 0 ? 0 : 1, gk = t == 2 ? 1 : 0;
     for (int e = tid; e < 64 * 64; e += 512) {
       const int r = e >> 6, cc = e & 63;
-      double v = j.slabs[(size_t)(t * GP_NB) * 4096 + e];
+      double v = ld_sc1(&j.slabs[(size_t)(t * GP_NB) * 4096 + e]);
 #pragma unroll
-      for (int b = 1; b < GP_NB; ++b) v += j.slabs[(size_t)(t * GP_NB + b) * 4096 + e];        // fixed order
+      for (int b = 1; b < GP_NB; ++b) v += ld_sc1(&j.slabs[(size_t)(t * GP_NB + b) * 4096 + e]);        // fixed order
       const int grow = gi * 64 + r, gcol = gk * 64 + cc;
       if (grow == gcol) v += diag_term(grow);
       j.M[(size_t)grow * n + gcol] = v;
     }
   }
   __syncthreads();                                    // the block's own global writes -> visible to the block
-  potrf_first_body8(j.M, n, 1, 0, j.Lmat, j.Linv, j.status, (Potrf64Scratch*)smem_raw);
+  potrf_first_body8(j.M, n, 1, 0, j.Lmat, j.Linv, j.status, (Potrf64Scratch*)smem_raw, j.N);
   __syncthreads();
-  potrf_step_tile(j.M, n, 0, 1, 1, j.Lmat, j.Linv, j.status, smem_raw);
+  potrf_step_tile(j.M, n, 0, 1, 1, j.Lmat, j.Linv, j.status, smem_raw, j.N);
+  announce_factor(j, true);
 }
 
 constexpr size_t GP_SMEM1 = (size_t)4 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + 16;   // one system tile
 constexpr size_t GP_SMEM = GP_SMEM1 > POTRF_STEP_SMEM + 16 ? GP_SMEM1 : POTRF_STEP_SMEM + 16;              // 128 x 128 systems
-__host__ __device__ constexpr size_t gp_smem(int nb) { return nb <= 1 ? GP_SMEM1 : GP_SMEM; }
+__host__ __device__ constexpr size_t gp_smem(int nb) {
+  const size_t g = nb <= 1 ? GP_SMEM1 : GP_SMEM;
+  return g > sv_smem(nb) ? g : sv_smem(nb);
+}
 
 template <int D, int MT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_project(
     const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ Csub,
     float* __restrict__ T, long rows, int Ne, int NEP, GramPotrfJob job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int has_rider = job.C ? gp_riders(job.nb) : 0;
-  if ((int)blockIdx.x < has_rider) {
+  const int n_gram = job.C ? gp_riders(job.nb) : 0;
+  const int n_solve = (job.C && job.R) ? D / 64 : 0;
+  const int has_rider = n_gram + n_solve;
+  if ((int)blockIdx.x < n_gram) {
     gram_potrf_rider<D>(job, smem_raw);
     return;
   }
+  if ((int)blockIdx.x < has_rider) {
+    solve_rider<D>(job, smem_raw, (int)blockIdx.x - n_gram);
+    return;
+  }
+  DBG(0);
   float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD]
   constexpr int M0 = (MT + 1) / 2;
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
     project_body<D, MT, M0>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, has_rider);
   else
     project_body<D, MT, MT - M0>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, has_rider);
+  DBG(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,7 +819,7 @@ int launch_project(const float* W_old, const float* Dm, const float* Csub, float
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
   }
-  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) : 0);
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) + (job.R ? D / 64 : 0) : 0);
   hipLaunchKernelGGL((k_lr_project<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
                      N_edit, NEP64, job);
   UCE_LAUNCH_CHECK();
@@ -677,13 +905,13 @@ bool lowrank_split_supported(int d, int N_edit) {
 // and a dual system that is a single 64-block (N <= 64) the launch also builds and factors that
 // system (block 0): K = lamb S^-1 + C C^T -> h->Lmat (ld 64), h->Linv, h->status.
 int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
-                      int N_edit, hipStream_t st, uce_ctx* h, const float* C, const float* s, int N, float lamb) {
+                      int N_edit, hipStream_t st, uce_ctx* h, const float* C, const float* s, int N, float lamb, float* R) {
   const int NEP64 = (N_edit + 63) / 64 * 64;
   GramPotrfJob job{};
   if (h) {
     const int nb = (N + 63) / 64;
     if (nb < 1 || nb > GP_MAXB) return UCE_EINVAL;
-    job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, h->M, nb};
+    job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, h->M, nb, R, N_edit, ++h->seq};
   }
   if (d == 768) return launch_project_d<768>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
   if (d == 1024) return launch_project_d<1024>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);

@@ -184,10 +184,14 @@ __device__ __forceinline__ void potrf64_pair8(double (&t)[4][4], Potrf64Scratch*
 }
 
 // All 512 threads call this (tid = 0..511).  role 0 threads pass their tile of the SPD block.
+// `npiv`: the leading npiv rows / columns are the real system, the rest of the block is the identity padding of a
+// system whose size is not a multiple of 64 (K_pad = diag(K, I)): its pivots are 1 and touch nothing, so the
+// elimination stops after ceil(npiv / 4) of the 16 iterations (a 5-concept edit: 2 iterations instead of 16).
 template <int ROLE>
 __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* sc, int tid256, int* status,
-                                             int col_base) {
+                                             int col_base, int npiv = 64) {
   const int ti = tid256 >> 4, tj = tid256 & 15;
+  const int nkb = npiv >= 64 ? 16 : ((npiv + 3) >> 2), kstop = 4 * nkb;
   if (ROLE == 1) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -195,14 +199,15 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
       for (int c = 0; c < 4; ++c) t[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
   }
 #pragma unroll 1
-  for (int kb = 0; kb < 16; ++kb) {
+  for (int kb = 0; kb < nkb; ++kb) {
     potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
     potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
   }
   __syncthreads();
   if (ROLE == 0 && tid256 < 32) {
     const int k = 2 * tid256;
-    const double p00 = sc->col[k][k], p01 = sc->col[k][k + 1], p11 = sc->col[k + 1][k + 1];
+    const bool live = k < kstop;
+    const double p00 = live ? sc->col[k][k] : 1.0, p01 = live ? sc->col[k][k + 1] : 0.0, p11 = live ? sc->col[k + 1][k + 1] : 1.0;
     const double g = p01 / p00;
     const double p11e = fma(-g, p01, p11);
     const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
@@ -224,13 +229,21 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
       double val = 0.0;
       if (col <= row) {
         if (ROLE == 0) {
-          val = sc->col[col][row];
-          if (col & 1) val = fma(-sc->g[col], sc->col[col - 1][row], val);
-          val *= sc->rs[col];
+          if (col >= kstop) {
+            val = (row == col) ? 1.0 : 0.0;                  // identity padding: never published, L = I there
+          } else {
+            val = sc->col[col][row];
+            if (col & 1) val = fma(-sc->g[col], sc->col[col - 1][row], val);
+            val *= sc->rs[col];
+          }
         } else {
-          val = sc->row[row][col];
-          if (row & 1) val = fma(-sc->g[row], sc->row[row - 1][col], val);
-          val *= sc->rs[row];
+          if (row >= kstop) {
+            val = (row == col) ? 1.0 : 0.0;
+          } else {
+            val = sc->row[row][col];
+            if (row & 1) val = fma(-sc->g[row], sc->row[row - 1][col], val);
+            val *= sc->rs[row];
+          }
         }
       }
       t[r][c] = val;
@@ -247,7 +260,8 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
 static __device__ __forceinline__ void potrf_first_body8(const double* __restrict__ M, int n, int nsplit,
                                                          size_t slab_stride, double* __restrict__ Lmat,
                                                          double* __restrict__ Linv, int* status,
-                                                         Potrf64Scratch* sc) {
+                                                         Potrf64Scratch* sc, int n_valid = 1 << 30) {
+  const int npiv0 = n_valid < 64 ? n_valid : 64;
   const int tid = threadIdx.x, half = tid >> 8, t256 = tid & 255;
   const int ti = t256 >> 4, tj = t256 & 15;
   double tt[4][4];
@@ -261,13 +275,13 @@ static __device__ __forceinline__ void potrf_first_body8(const double* __restric
         for (int sp = 1; sp < nsplit; ++sp) v += M[(size_t)sp * slab_stride + off];   // index order
         tt[r][c] = v;
       }
-    potrf64_reg8<0>(tt, sc, t256, status, 0);
+    potrf64_reg8<0>(tt, sc, t256, status, 0, npiv0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) Lmat[(size_t)(4 * ti + r) * n + 4 * tj + c] = tt[r][c];
   } else {
-    potrf64_reg8<1>(tt, sc, t256, status, 0);
+    potrf64_reg8<1>(tt, sc, t256, status, 0, npiv0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -337,10 +351,10 @@ constexpr size_t POTRF_STEP_SMEM = 3 * 64 * LD * sizeof(double);
 // contraction index contiguous)
 __device__ __forceinline__ void quad_nt(double4_t (&acc)[2][2], const double (*P)[LD],
                                         const double (*Q)[LD], int row0, int col0, int lane,
-                                        double sign) {
+                                        double sign, int kb0 = 0, int kb1 = 16) {
   const int r = lane & 15, kk = lane >> 4;
 #pragma unroll 4
-  for (int kb = 0; kb < 16; ++kb) {
+  for (int kb = kb0; kb < kb1; ++kb) {
     const int t = kb * 4 + kk;
     const double a0 = sign * P[row0 + r][t], a1 = sign * P[row0 + 16 + r][t];
     const double b0 = Q[col0 + r][t], b1 = Q[col0 + 16 + r][t];
@@ -372,7 +386,7 @@ __device__ __forceinline__ void quad_foreach(int row0, int col0, int lane, F f) 
 
 static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, int n, int j, int i, int k,
                                                        double* __restrict__ Lmat, double* __restrict__ Linv,
-                                                       int* status, unsigned char* smem_raw) {
+                                                       int* status, unsigned char* smem_raw, int n_valid = 1 << 30) {
   double (*Li)[LD] = (double (*)[LD])smem_raw;                       // L_jj^-1
   double (*Mi)[LD] = (double (*)[LD])(smem_raw + 64 * LD * 8);       // M_ij  -> P_i
   double (*Mk)[LD] = (double (*)[LD])(smem_raw + 2 * 64 * LD * 8);   // M_kj  -> P_k
@@ -393,16 +407,26 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
   }
   __syncthreads();
 
-  // P_i = M_ij L_jj^-T (half 0) ; P_k likewise (half 1)
+  // P_i = M_ij L_jj^-T (half 0) ; P_k likewise (half 1).  On a diagonal tile (P_k == P_i; the one of step j + 1 is
+  // the critical path of the whole chain) the two halves split the contraction instead and the partial sums meet in
+  // the idle Mk region: 32 MFMAs per wave instead of 64.
   double4_t pp[2][2];
   quad_zero(pp);
-  if (half == 0) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0);
-  else if (!diag) quad_nt(pp, Mk, Li, wr, wc, lane, 1.0);
+  if (diag) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0, half * 8, half * 8 + 8);
+  else if (half == 0) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0);
+  else quad_nt(pp, Mk, Li, wr, wc, lane, 1.0);
   __syncthreads();
-  if (half == 0)
+  if (diag) {
+    if (half == 1)
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pp[m][nn][r]; });
+    __syncthreads();
+    if (half == 0)
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pp[m][nn][r] + Mk[row][col]; });
+  } else if (half == 0) {
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pp[m][nn][r]; });
-  else if (!diag)
+  } else {
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pp[m][nn][r]; });
+  }
   __syncthreads();
 
   // tile (i, j+1) publishes L_ij
@@ -413,14 +437,31 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
     }
   }
 
-  // M_ik -= P_i P_k^T   (half 0)
+  // M_ik -= P_i P_k^T   (half 0; on a diagonal tile half 1 contracts the second half of k)
   const bool factor_here = diag && i == j + 1;
   double4_t acc[2][2];
+  if (diag) {
+    if (half == 0) {
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+        acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
+      });
+    } else {
+      quad_zero(acc);
+    }
+    quad_nt(acc, Mi, Mi, wr, wc, lane, -1.0, half * 8, half * 8 + 8);      // both halves at once
+    if (half == 1)
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = acc[m][nn][r]; });
+    __syncthreads();                               // (workgroup-uniform branch)
+    if (half == 0)
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { acc[m][nn][r] += Mk[row][col]; });
+  }
   if (half == 0) {
-    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
-      acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
-    });
-    quad_nt(acc, Mi, diag ? Mi : Mk, wr, wc, lane, -1.0);
+    if (!diag) {
+      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+        acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
+      });
+      quad_nt(acc, Mi, Mk, wr, wc, lane, -1.0);
+    }
     if (!factor_here) {
       quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
         M[(size_t)(i * 64 + row) * n + k * 64 + col] = acc[m][nn][r];
@@ -444,14 +485,15 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
       for (int c = 0; c < 4; ++c) tt[r][c] = Li[4 * ti + r][4 * tj + c];
   }
   __syncthreads();                                   // Li fully read before the scratch (which overlaps nothing of Li) is used
+  const int npiv = (n_valid - i * 64) < 64 ? (n_valid - i * 64) : 64;
   if (half == 0) {
-    potrf64_reg8<0>(tt, sc, t256, status, i * 64);
+    potrf64_reg8<0>(tt, sc, t256, status, i * 64, npiv);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) Lmat[(size_t)(i * 64 + 4 * ti + r) * n + i * 64 + 4 * tj + c] = tt[r][c];
   } else {
-    potrf64_reg8<1>(tt, sc, t256, status, i * 64);
+    potrf64_reg8<1>(tt, sc, t256, status, i * 64, npiv);
     double* Linv_n = Linv + (size_t)i * 64 * 64;
 #pragma unroll
     for (int r = 0; r < 4; ++r)

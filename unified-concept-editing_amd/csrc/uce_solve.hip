@@ -27,21 +27,21 @@ __device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
 // Factors diagonal block 0 (body shared with the fused projection+factor launch, uce_potrf64.h).
 __global__ __launch_bounds__(512) void k_potrf_first(const double* __restrict__ M, int n, int nsplit,
                                                      size_t slab_stride, double* __restrict__ Lmat,
-                                                     double* __restrict__ Linv, int* status) {
+                                                     double* __restrict__ Linv, int* status, int n_valid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // every factorisation starts here: reset the status word in this launch (a hipMemsetAsync costs a 4-5 us
   // fill kernel of its own); the first barrier inside the factor orders it before any failure report
   if (threadIdx.x == 0) *status = 0;
-  potrf_first_body8(M, n, nsplit, slab_stride, Lmat, Linv, status, (Potrf64Scratch*)smem_raw);
+  potrf_first_body8(M, n, nsplit, slab_stride, Lmat, Linv, status, (Potrf64Scratch*)smem_raw, n_valid);
 }
 
 __global__ __launch_bounds__(512) void k_potrf_step(double* __restrict__ M, int n, int j,
                                                     double* __restrict__ Lmat,
-                                                    double* __restrict__ Linv, int* status) {
+                                                    double* __restrict__ Linv, int* status, int n_valid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int ta, tb;
   tri_decode(blockIdx.x, ta, tb);
-  potrf_step_tile(M, n, j, j + 1 + ta, j + 1 + tb, Lmat, Linv, status, smem_raw);
+  potrf_step_tile(M, n, j, j + 1 + ta, j + 1 + tb, Lmat, Linv, status, smem_raw, n_valid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
 
 }  // namespace
 
-int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st) {
+int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid) {
+  if (n_valid <= 0 || n_valid > n) n_valid = n;
   const int nb = n / 64;
   const size_t smem = 3 * 64 * LD * sizeof(double);
   const size_t smem_first = sizeof(Potrf64Scratch);
@@ -226,20 +227,20 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
                                     (int)smem_first));
   }
   hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(512), smem_first, st, (const double*)M, n, nsplit,
-                     slab_stride, h->Lmat, h->Linv, h->status);
+                     slab_stride, h->Lmat, h->Linv, h->status, n_valid);
   UCE_LAUNCH_CHECK();
   for (int j = 0; j + 1 < nb; ++j) {
     const int mt = nb - j - 1;
     const int tiles = mt * (mt + 1) / 2;
     hipLaunchKernelGGL(k_potrf_step, dim3(tiles), dim3(512), smem, st, M, n, j, h->Lmat, h->Linv,
-                       h->status);
+                       h->status, n_valid);
     UCE_LAUNCH_CHECK();
   }
   return UCE_OK;
 }
 
-int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st) {
-  return launch_potrf_slabs(h, M, n, 1, 0, st);
+int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st, int n_valid) {
+  return launch_potrf_slabs(h, M, n, 1, 0, st, n_valid);
 }
 
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,

@@ -74,9 +74,12 @@ __device__ __forceinline__ void kmaj_park(const double2_t (&v)[4], double* Kk, i
 //   TA = true : A_sub(k) = A[64k .. 64k+64, r0 .. r0+32]^T         (k-major operand: the transpose is free)
 //   B_sub(k)  = B[64k .. 64k+64, c0 .. c0+32]   (f64, or f32 with rows >= b_rows zero)
 // Returns this THREAD's 4 outputs of the reduced tile: rows (tid >> 3), columns 4 * (tid & 7) .. +3.
+//   Adiag / Bdiag (optional): the inverted 64 x 64 diagonal blocks [nb][64][64]; when given, a 64-block of A (B) that
+//   lies ON the diagonal is read from there (the diagonal blocks of L^-1 are never copied into Winv).
 template <bool TA, bool B32>
 __device__ __forceinline__ void tile_gemm(double (&out)[4], const double* A, int lda, const void* B, int ldb, int b_rows,
-                                          int r0, int c0, int k0, int k1, unsigned char* smem) {
+                                          int r0, int c0, int k0, int k1, unsigned char* smem,
+                                          const double* Adiag = nullptr, const double* Bdiag = nullptr) {
   double* Rs = (double*)smem;                     // [32][RLD]
   double* Ka = Rs + 32 * RLD;                     // [64][KLD]  (A when TA)
   double* Kb = Ka + 64 * KLD;                     // [64][KLD]
@@ -88,19 +91,27 @@ __device__ __forceinline__ void tile_gemm(double (&out)[4], const double* A, int
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
   if (k0 <= k1) {
-    double2_t va[4], vb[4];
-    auto fetch = [&](int k) {
-      if (TA) kmaj_load<false>(va, A, lda, k, r0, tid, 0);
-      else row_load(va, A, lda, r0, k, tid);
-      kmaj_load<B32>(vb, B, ldb, k, c0, tid, b_rows);
+    // two chunks in flight ahead of the MFMAs (an L2 round trip is longer than a chunk's 16 MFMAs per wave); the two
+    // register sets are named (a runtime-indexed set would live in scratch memory)
+    double2_t va0[4], vb0[4], va1[4], vb1[4];
+    auto fetch = [&](int k, double2_t (&xa)[4], double2_t (&xb)[4]) {
+      const bool ad = Adiag && k == (r0 >> 6), bd = !B32 && Bdiag && k == (c0 >> 6);
+      if (TA) {
+        if (ad) kmaj_load<false>(xa, Adiag + (size_t)k * 4096, 64, 0, r0 & 63, tid, 0);
+        else kmaj_load<false>(xa, A, lda, k, r0, tid, 0);
+      } else {
+        if (ad) row_load(xa, Adiag + (size_t)k * 4096, 64, r0 & 63, 0, tid);
+        else row_load(xa, A, lda, r0, k, tid);
+      }
+      if (bd) kmaj_load<false>(xb, Bdiag + (size_t)k * 4096, 64, 0, c0 & 63, tid, 0);
+      else kmaj_load<B32>(xb, B, ldb, k, c0, tid, b_rows);
     };
-    fetch(k0);
-    for (int k = k0; k <= k1; ++k) {
+    auto chunk = [&](int k, double2_t (&xa)[4], double2_t (&xb)[4]) {
       __syncthreads();                            // the previous chunk's fragments are read
-      if (TA) kmaj_park(va, Ka, tid);
-      else row_park(va, Rs, tid);
-      kmaj_park(vb, Kb, tid);
-      if (k < k1) fetch(k + 1);                   // in flight under the MFMAs
+      if (TA) kmaj_park(xa, Ka, tid);
+      else row_park(xa, Rs, tid);
+      kmaj_park(xb, Kb, tid);
+      if (k + 2 <= k1) fetch(k + 2, xa, xb);      // refill this set: in flight under two chunks of MFMAs
       __syncthreads();
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
@@ -114,6 +125,12 @@ __device__ __forceinline__ void tile_gemm(double (&out)[4], const double* A, int
         acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
         acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
       }
+    };
+    fetch(k0, va0, vb0);
+    if (k0 < k1) fetch(k0 + 1, va1, vb1);
+    for (int k = k0; k <= k1; k += 2) {
+      chunk(k, va0, vb0);
+      if (k + 1 <= k1) chunk(k + 1, va1, vb1);
     }
   }
   // ---- sum the four waves' partial tiles (fixed order: bit-repeatable)
@@ -140,30 +157,20 @@ __device__ __forceinline__ void tile_gemm(double (&out)[4], const double* A, int
 }
 static_assert(4 * 32 * 33 * sizeof(double) <= TRINV_SMEM, "the reduction image must fit the operand images");
 
-// Winv <- the inverted diagonal blocks (Linv [nb][64][64]); everything else of the lower triangle is written by the
-// merge stages before it is read, the upper triangle is never read.
-__global__ __launch_bounds__(256) void k_trinv_diag(const double* __restrict__ Linv, double* __restrict__ Winv, int n) {
-  const int b = blockIdx.x;
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Winv[(size_t)(b * 64 + r) * n + b * 64 + c] = Linv[(size_t)b * 4096 + e];
-  }
-}
-
 // Level with segments of S 64-blocks: pair p = segments [2pS, 2pS + S) (A) and [(2p+1)S, ...) (D, possibly short).
 //   STAGE 1: T[i, j]    =  sum_{k in A, k >= j} L[i, k] Winv[k, j]          i in D, j in A
 //   STAGE 2: Winv[i, j] = -sum_{k in D, k <= i} Winv[i, k] T[k, j]
 // grid (32 x 32 tiles): x = column tile inside the A segment (0 .. 2S-1), y = row tile among the D rows of the level.
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_trinv_merge(const double* __restrict__ L, double* __restrict__ Winv,
-                                                     double* __restrict__ T, int n, int S) {
+                                                     double* __restrict__ T, const double* __restrict__ Linv, int n, int S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int yb = blockIdx.y >> 1, p = yb / S, rr = yb % S;
   const int i = (2 * p + 1) * S + rr, a0 = 2 * p * S, j = a0 + (blockIdx.x >> 1);     // 64-blocks of the tile
   const int r0 = i * 64 + (blockIdx.y & 1) * 32, c0 = j * 64 + (blockIdx.x & 1) * 32;
   double o[4];
-  if (STAGE == 1) tile_gemm<false, false>(o, L, n, Winv, n, 0, r0, c0, j, a0 + S - 1, smem);
-  else tile_gemm<false, false>(o, Winv, n, T, n, 0, r0, c0, (2 * p + 1) * S, i, smem);
+  if (STAGE == 1) tile_gemm<false, false>(o, L, n, Winv, n, 0, r0, c0, j, a0 + S - 1, smem, nullptr, Linv);
+  else tile_gemm<false, false>(o, Winv, n, T, n, 0, r0, c0, (2 * p + 1) * S, i, smem, Linv, nullptr);
   double* dst = ((STAGE == 1) ? T : Winv) + (size_t)(r0 + (threadIdx.x >> 3)) * n + c0 + 4 * (threadIdx.x & 7);
   const double sign = (STAGE == 1) ? 1.0 : -1.0;
   *(double2_t*)dst = (double2_t){sign * o[0], sign * o[1]};
@@ -172,29 +179,32 @@ __global__ __launch_bounds__(256) void k_trinv_merge(const double* __restrict__ 
 
 // Y[i, :] = sum_{k <= i} Winv[i, k] RHS[k, :]      (RHS f64 [n, m] or f32 with rows >= rhs_rows zero)
 template <bool B32>
-__global__ __launch_bounds__(256) void k_trinv_fwd(const double* __restrict__ Winv, const void* __restrict__ rhs,
-                                                   int rhs_rows, double* __restrict__ Y, int n, int m) {
+__global__ __launch_bounds__(256) void k_trinv_fwd(const double* __restrict__ Winv, const double* __restrict__ Linv,
+                                                   const void* __restrict__ rhs, int rhs_rows, double* __restrict__ Y,
+                                                   int n, int m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  // row tiles in DESCENDING order: tile i contracts i/2 + 1 chunks, the long ones are dispatched first
+  const int r0 = (gridDim.y - 1 - blockIdx.y) * 32, c0 = blockIdx.x * 32;
   int k1 = r0 >> 6;
   if (B32) {                                   // blocks of zero rows contribute nothing
     const int last = (rhs_rows - 1) / 64;
     k1 = k1 < last ? k1 : last;
   }
   double o[4];
-  tile_gemm<false, B32>(o, Winv, n, rhs, m, rhs_rows, r0, c0, 0, k1, smem);
+  tile_gemm<false, B32>(o, Winv, n, rhs, m, rhs_rows, r0, c0, 0, k1, smem, Linv, nullptr);
   double* dst = Y + (size_t)(r0 + (threadIdx.x >> 3)) * m + c0 + 4 * (threadIdx.x & 7);
   *(double2_t*)dst = (double2_t){o[0], o[1]};
   *(double2_t*)(dst + 2) = (double2_t){o[2], o[3]};
 }
 
 // X[i, :] = sum_{k >= i} Winv[k, i]^T Y[k, :]  ->  out f32, rows < out_rows
-__global__ __launch_bounds__(256) void k_trinv_bwd(const double* __restrict__ Winv, const double* __restrict__ Y,
-                                                   float* __restrict__ out, int out_rows, int n, int m) {
+__global__ __launch_bounds__(256) void k_trinv_bwd(const double* __restrict__ Winv, const double* __restrict__ Linv,
+                                                   const double* __restrict__ Y, float* __restrict__ out, int out_rows,
+                                                   int n, int m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   double o[4];
-  tile_gemm<true, false>(o, Winv, n, Y, m, 0, r0, c0, r0 >> 6, n / 64 - 1, smem);
+  tile_gemm<true, false>(o, Winv, n, Y, m, 0, r0, c0, r0 >> 6, n / 64 - 1, smem, Linv, nullptr);
   const int gr = r0 + (threadIdx.x >> 3);
   if (gr < out_rows)
     *(float4_t*)(out + (size_t)gr * m + c0 + 4 * (threadIdx.x & 7)) = (float4_t){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
@@ -216,26 +226,24 @@ int launch_trisolve_inv(uce_ctx* h, int n, int m, const double* rhs64, const flo
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   }
-  hipLaunchKernelGGL(k_trinv_diag, dim3(nb), dim3(256), 0, st, (const double*)h->Linv, h->Wi, n);
-  UCE_LAUNCH_CHECK();
   for (int S = 1; S < nb; S *= 2) {
     // D rows of the level: every block i with (i / S) odd
     int drows = 0;
     for (int i = 0; i < nb; ++i)
       if ((i / S) & 1) ++drows;
     if (!drows) continue;
-    hipLaunchKernelGGL(k_trinv_merge<1>, dim3(2 * S, 2 * drows), dim3(256), smem, st, (const double*)h->Lmat, h->Wi, scratch, n, S);
-    hipLaunchKernelGGL(k_trinv_merge<2>, dim3(2 * S, 2 * drows), dim3(256), smem, st, (const double*)h->Lmat, h->Wi, scratch, n, S);
+    hipLaunchKernelGGL(k_trinv_merge<1>, dim3(2 * S, 2 * drows), dim3(256), smem, st, (const double*)h->Lmat, h->Wi, scratch, (const double*)h->Linv, n, S);
+    hipLaunchKernelGGL(k_trinv_merge<2>, dim3(2 * S, 2 * drows), dim3(256), smem, st, (const double*)h->Lmat, h->Wi, scratch, (const double*)h->Linv, n, S);
     UCE_LAUNCH_CHECK();
   }
   const dim3 grid(m / 32, 2 * nb);
   if (rhs32)
-    hipLaunchKernelGGL(k_trinv_fwd<true>, grid, dim3(256), smem, st, (const double*)h->Wi, (const void*)rhs32, rhs_rows, h->Yg, n, m);
+    hipLaunchKernelGGL(k_trinv_fwd<true>, grid, dim3(256), smem, st, (const double*)h->Wi, (const double*)h->Linv, (const void*)rhs32, rhs_rows, h->Yg, n, m);
   else
-    hipLaunchKernelGGL(k_trinv_fwd<false>, grid, dim3(256), smem, st, (const double*)h->Wi, (const void*)rhs64, n, h->Yg, n, m);
+    hipLaunchKernelGGL(k_trinv_fwd<false>, grid, dim3(256), smem, st, (const double*)h->Wi, (const double*)h->Linv, (const void*)rhs64, n, h->Yg, n, m);
   const int out_tiles = (out_rows + 31) / 32;
   hipLaunchKernelGGL(k_trinv_bwd, dim3(m / 32, out_tiles < 2 * nb ? out_tiles : 2 * nb), dim3(256), smem, st, (const double*)h->Wi,
-                     (const double*)h->Yg, out, out_rows, n, m);
+                     (const double*)h->Linv, (const double*)h->Yg, out, out_rows, n, m);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
