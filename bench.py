@@ -226,6 +226,19 @@ def kernel_breakdown(H, inp, algo: int, step, iters: int = 30):
             ent["mfma_util"] = t["mfma_util"]
         rows_out.append(ent)
     rows_out.sort(key=lambda e: -e["share"])
+    if path == "dual_lowrank" and N <= 128:
+        # inside uce_edit the projection launch also carries the whole small-system chain (Gram -> Cholesky ->
+        # triangular solves in rider blocks) and ends when the LONGER of the two ends: time the GEMM on its own too
+        Dm = (inp["G"] - inp["C"][:n_e]).contiguous()
+        ms = time_kernel(lambda: H.lowrank_project(inp["W"], Dm), iters)
+        for e in rows_out:
+            if e["kernel"] == "k_lr_project":
+                fl = e["algorithmic_flops"]
+                e["gemm_alone"] = dict(avg_ms=round(ms, 5), achieved=round(fl / (ms * 1e-3) / 1e12, 2),
+                                       frac=round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4),
+                                       frac_issued=round(2.0 * rows * d * round_up(n_e, 64) / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4))
+                e["note"] += ("; in uce_edit this launch also carries the Gram + Cholesky + triangular-solve rider blocks and "
+                              "lasts as long as that latency chain (tools/dbg_chain.py); gemm_alone = the projection launched by itself")
     return path, rows_out, total
 
 

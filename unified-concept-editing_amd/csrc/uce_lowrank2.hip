@@ -470,18 +470,24 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     // once, fixed slab order: bit-repeatable) into the LDS tile the matrix waves then pick their 4x4 tiles from.
     double* Ksum = (double*)smem_raw;                             // [64][GP_TLD] (the Gram staging is dead)
     {
+      // only what the factorisation reads: the 4 x 4 tiles of the lower triangle, rows of real concepts (the padding
+      // rows are identity) - a 50-concept system moves 35 % of the slab bytes
+      const int n4 = (j.N + 3) & ~3;
       double v[GP_NB][8];
 #pragma unroll
       for (int b = 0; b < GP_NB; ++b)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) v[b][p] = ld_sc1(&j.slabs[(size_t)b * 4096 + tid + 512 * p]);
+        for (int p = 0; p < 8; ++p) {
+          const int e = tid + 512 * p, row = e >> 6, col = e & 63;
+          v[b][p] = (row < n4 && col <= (row | 3)) ? ld_sc1(&j.slabs[(size_t)b * 4096 + e]) : 0.0;
+        }
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int e = tid + 512 * p, row = e >> 6, col = e & 63;
         double acc = v[0][p];
 #pragma unroll
         for (int b = 1; b < GP_NB; ++b) acc += v[b][p];
-        if (row == col) acc += diag_term(row);
+        if (row == col) acc = (row < n4 ? acc : 0.0) + diag_term(row);
         Ksum[row * GP_TLD + col] = acc;
       }
     }

@@ -25,6 +25,14 @@ struct Potrf64Scratch {
   double g[64];         // odd k: p01/p00 of its pair
 };
 
+// 1 / sqrt(v): hardware estimate + two Newton steps (the sqrt + divide sequence of `1.0 / sqrt(v)` is ~10x the code)
+static __device__ __forceinline__ double rsqrt_f64(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  y = y * fma(-0.5 * v * y, y, 1.5);
+  y = y * fma(-0.5 * v * y, y, 1.5);
+  return y;
+}
+
 static __device__ __forceinline__ double rcp_f64(double v) {
   double r = __builtin_amdgcn_rcp(v);
   r = fma(fma(-v, r, 1.0), r, r);
@@ -198,25 +206,33 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
 #pragma unroll
       for (int c = 0; c < 4; ++c) t[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
   }
+  if (nkb == 16) {                           // the full block keeps its constant trip count (the compiler pipelines it)
 #pragma unroll 1
-  for (int kb = 0; kb < nkb; ++kb) {
-    potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
-    potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
+    for (int kb = 0; kb < 16; ++kb) {
+      potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
+      potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
+    }
+  } else {
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+      potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
+      potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
+    }
   }
   __syncthreads();
   if (ROLE == 0 && tid256 < 32) {
     const int k = 2 * tid256;
     const bool live = k < kstop;
     const double p00 = live ? sc->col[k][k] : 1.0, p01 = live ? sc->col[k][k + 1] : 0.0, p11 = live ? sc->col[k + 1][k + 1] : 1.0;
-    const double g = p01 / p00;
+    const double g = p01 * rcp_f64(p00);
     const double p11e = fma(-g, p01, p11);
     const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
     if ((bad0 | bad1) && tid256 == 0) {
       const int f0 = bad0 ? 2 * __builtin_ctzll(bad0) : 128, f1 = bad1 ? 2 * __builtin_ctzll(bad1) + 1 : 128;
       atomicCAS(status, 0, col_base + (f0 < f1 ? f0 : f1) + 1);
     }
-    sc->rs[k] = 1.0 / sqrt(p00);
-    sc->rs[k + 1] = 1.0 / sqrt(p11e);
+    sc->rs[k] = rsqrt_f64(p00);          // (a non-positive pivot gives NaN / inf here; it is reported through `status`)
+    sc->rs[k + 1] = rsqrt_f64(p11e);
     sc->g[k] = 0.0;
     sc->g[k + 1] = g;
   }
@@ -407,26 +423,18 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
   }
   __syncthreads();
 
-  // P_i = M_ij L_jj^-T (half 0) ; P_k likewise (half 1).  On a diagonal tile (P_k == P_i; the one of step j + 1 is
-  // the critical path of the whole chain) the two halves split the contraction instead and the partial sums meet in
-  // the idle Mk region: 32 MFMAs per wave instead of 64.
+  // P_i = M_ij L_jj^-T (half 0) ; P_k likewise (half 1)
+  // (splitting the contraction of a diagonal tile over both halves was measured: the two extra barriers cost more
+  //  than the 32 MFMAs per wave they save - the chain is latency-, not MFMA-bound)
   double4_t pp[2][2];
   quad_zero(pp);
-  if (diag) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0, half * 8, half * 8 + 8);
-  else if (half == 0) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0);
-  else quad_nt(pp, Mk, Li, wr, wc, lane, 1.0);
+  if (half == 0) quad_nt(pp, Mi, Li, wr, wc, lane, 1.0);
+  else if (!diag) quad_nt(pp, Mk, Li, wr, wc, lane, 1.0);
   __syncthreads();
-  if (diag) {
-    if (half == 1)
-      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pp[m][nn][r]; });
-    __syncthreads();
-    if (half == 0)
-      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pp[m][nn][r] + Mk[row][col]; });
-  } else if (half == 0) {
+  if (half == 0)
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mi[row][col] = pp[m][nn][r]; });
-  } else {
+  else if (!diag)
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = pp[m][nn][r]; });
-  }
   __syncthreads();
 
   // tile (i, j+1) publishes L_ij
@@ -437,31 +445,14 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
     }
   }
 
-  // M_ik -= P_i P_k^T   (half 0; on a diagonal tile half 1 contracts the second half of k)
+  // M_ik -= P_i P_k^T   (half 0)
   const bool factor_here = diag && i == j + 1;
   double4_t acc[2][2];
-  if (diag) {
-    if (half == 0) {
-      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
-        acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
-      });
-    } else {
-      quad_zero(acc);
-    }
-    quad_nt(acc, Mi, Mi, wr, wc, lane, -1.0, half * 8, half * 8 + 8);      // both halves at once
-    if (half == 1)
-      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Mk[row][col] = acc[m][nn][r]; });
-    __syncthreads();                               // (workgroup-uniform branch)
-    if (half == 0)
-      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { acc[m][nn][r] += Mk[row][col]; });
-  }
   if (half == 0) {
-    if (!diag) {
-      quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
-        acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
-      });
-      quad_nt(acc, Mi, Mk, wr, wc, lane, -1.0);
-    }
+    quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
+      acc[m][nn][r] = M[(size_t)(i * 64 + row) * n + k * 64 + col];
+    });
+    quad_nt(acc, Mi, diag ? Mi : Mk, wr, wc, lane, -1.0);
     if (!factor_here) {
       quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) {
         M[(size_t)(i * 64 + row) * n + k * 64 + col] = acc[m][nn][r];
