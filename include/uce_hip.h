@@ -188,6 +188,13 @@ int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const
 int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
                        uce_stream_t stream);
 
+/* The same convolution as ONE implicit-GEMM kernel (csrc/uce_conv_igemm.hip): the nine taps are gathered on the way
+ * into LDS, no patch matrix exists.  x [N, H, W, Cin] (or [N, H/2, W/2, Cin] with upsample = 1), w [Cout, 3, 3, Cin] (a
+ * channels-last Conv2d weight), bias [Cout] or NULL, y [N, H, W, Cout]; bf16 or f16, f32 accumulation; Cin % 64 == 0,
+ * Cout % 8 == 0. */
+int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const void* bias, void* y, int N, int H, int W,
+                         int Cin, int Cout, int upsample, int dtype, uce_stream_t stream);
+
 /* e - the one exchange step of the multi-GPU generation path (broadcast of the edited weights from rank 0) is issued by
  * the host through torch.distributed (backend "nccl" = RCCL over xGMI): see uce_amd/generate.py.  The library holds
  * no communicator and exports no collective. */

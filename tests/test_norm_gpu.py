@@ -148,6 +148,32 @@ def test_conv3x3_im2col_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias)
     assert O.rel_fro(y_chunked.float().cpu(), ref.cpu()) < tol
 
 
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,dtype,bias,up", [
+    (2, 320, 320, 64, 64, torch.bfloat16, True, False),      # 256 x 64 tiles (Cout % 128 == 64)
+    (3, 64, 32, 5, 7, torch.bfloat16, False, False),         # ragged pixels and channels, every border case
+    (2, 960, 320, 16, 16, torch.bfloat16, True, False),
+    (2, 64, 64, 8, 8, torch.float16, True, False),
+    (5, 128, 128, 40, 24, torch.bfloat16, True, False),      # 128 x 128 tiles, tiles that straddle image rows / images
+    (2, 1920, 640, 8, 6, torch.bfloat16, True, False),
+    (1, 512, 256, 32, 32, torch.bfloat16, True, False),      # VAE-like
+    (2, 640, 640, 16, 16, torch.bfloat16, True, True),       # fused 2x nearest upsample (Upsample2D)
+    (3, 64, 72, 6, 10, torch.float16, False, True),
+])
+def test_conv3x3_implicit_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias, up):
+    """uce_conv3x3_nhwc_fwd (one launch, taps gathered into LDS, no patch matrix) against F.conv2d evaluated in fp32;
+    with `up` against conv(interpolate(x, 2, "nearest")) for a half-resolution input."""
+    g = torch.Generator().manual_seed(Cin + Hh + Cout)
+    hs, ws = (Hh // 2, Ww // 2) if up else (Hh, Ww)
+    x = torch.randn(N, Cin, hs, ws, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).to("cuda", dtype).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+        ref = F.conv2d(xin, conv.weight.float(), None if conv.bias is None else conv.bias.float(), padding=1)
+        y = H.conv3x3_igemm(x, conv.weight, conv.bias, upsample=up)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert O.rel_fro(y.float().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
 @pytest.mark.parametrize("N,C,Hh,Ww", [(2, 64, 5, 7), (3, 320, 16, 16), (1, 1288, 4, 3), (2, 2560, 3, 5), (1, 8, 1, 1)])
 def test_im2col_patch_matrix_is_bit_exact(H, N, C, Hh, Ww):
     """Both patch-matrix kernels (row kernel for C <= 1280, flat kernel above) against nine shifted slices of the

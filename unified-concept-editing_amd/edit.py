@@ -45,6 +45,23 @@ def _f32c(t: torch.Tensor, device: torch.device) -> torch.Tensor:
 CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "4096")) << 20
 
 
+# which 3x3 convolutions go through the implicit-GEMM kernel instead of im2col + library GEMM: "auto" = where it measured
+# faster on an MI355X (tools/probe_igemm.py: the high-resolution, narrow layers of the VAE decoder - 2.7x at 128 -> 128
+# channels on 512 x 512 - where the patch matrix is all traffic and no arithmetic), "always", "never"
+CONV_IGEMM = os.environ.get("UCE_CONV_IGEMM", "auto")
+
+
+def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int) -> bool:
+    if CONV_IGEMM == "never" or Cin % 64 or Cout % 8:
+        return False
+    if CONV_IGEMM == "always":
+        return True
+    # VAE decoder, 256^2 and 512^2 layers: 1.5-2.8x.  (The U-Net's 64 x 64 layers with 320 output channels are 14-16 %
+    # faster in isolation - 572-668 TF/s against 480-574 - but the generation loop measured the same 6.2 images/s with
+    # them on either path; the other U-Net layers run at 0.7-0.97 PF/s in the library GEMM against 0.5-0.66 here.)
+    return H * W >= 256 * 256 and Cin <= 512
+
+
 def even_chunk(n: int, cap: int) -> int:
     """Chunk length for walking `n` items at most `cap` at a time: the fewest chunks that respect the cap, evenly
     sized (32 items, cap 15 -> 11 + 11 + 10 rather than 15 + 15 + 2; a small tail launch cannot fill the chip)."""
@@ -268,6 +285,19 @@ class UceHandle:
                                                   _stream_ptr(self.device)), "uce_add_bias_nhwc_fwd")
         return y
 
+    def conv3x3_igemm(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                      upsample: bool = False) -> torch.Tensor:
+        """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor as ONE implicit-GEMM launch
+        (uce_conv3x3_nhwc_fwd): no patch matrix.  Cin % 64 == 0, Cout % 8 == 0, channels-last weight."""
+        N, Cc, Hs, Ws = x.shape
+        Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        Cout = weight.shape[0]
+        y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        _lib.check(self.lib.uce_conv3x3_nhwc_fwd(self._h, _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), N, Hh, Ww, Cc, Cout,
+                                                 int(upsample), dt, _stream_ptr(self.device)), "uce_conv3x3_nhwc_fwd")
+        return y
+
     def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                      max_cols_bytes: int = CONV_COLS_BYTES, upsample: bool = False) -> torch.Tensor:
         """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor: patch matrix through
@@ -277,6 +307,8 @@ class UceHandle:
         N, Cc, Hs, Ws = x.shape
         Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         Cout = weight.shape[0]
+        if conv_prefers_igemm(Hh, Ww, Cc, Cout):
+            return self.conv3x3_igemm(x, weight, bias, upsample=upsample)
         wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         y_rows = y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout)     # NHWC view of the same storage

@@ -44,6 +44,7 @@ SIGNATURES = {
     "uce_add_bias_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "uce_geglu_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "uce_im2col3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "uce_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "uce_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
 }
 
