@@ -115,6 +115,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const unsigned short* __r
     b_src[p] = (n0 + row < Cout) ? (long)(n0 + row) * K + ch * 8 : -1;
   }
 
+  // Buffer loads: a tap outside the image (or a weight row >= Cout) gets an offset beyond num_records and reads as
+  // zero - no branch around any load, so the whole chunk is one basic block the compiler can interleave with the MFMAs.
+  const long x_bytes = (M / ((long)H * W)) * (long)Hs * Ws * Cin * 2;
+  const long w_bytes = (long)Cout * K * 2;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, x_bytes > 0x7fffffffL ? 0x7fffffff : (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, w_bytes > 0x7fffffffL ? 0x7fffffff : (int)w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   uint4_t ra[PA], rb[PB];
   auto fetch = [&](int kc) {
     const int tap = kc / cchunks, c0 = (kc - tap * cchunks) * CG_BK;
@@ -124,11 +131,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const unsigned short* __r
       const int yy = a_y[p] + dy, xx = a_x[p] + dx;
       const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
       const long off = a_img[p] + ((long)(yy >> up) * Ws + (xx >> up)) * Cin + c0;
-      ra[p] = ok ? *(const uint4_t*)(X + off) : (uint4_t){0u, 0u, 0u, 0u};
+      ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(off * 2) : OOB, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p)
-      rb[p] = (b_src[p] >= 0) ? *(const uint4_t*)(Wt + b_src[p] + (long)kc * CG_BK) : (uint4_t){0u, 0u, 0u, 0u};
+      rb[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_src[p] >= 0 ? (unsigned)((b_src[p] + (long)kc * CG_BK) * 2) : OOB, 0, 0);
   };
   auto park = [&](int buf) {
 #pragma unroll
@@ -235,6 +242,10 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
   if (upsample && ((H | W) & 1)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const long M = (long)N * H * W;
+  // 32-bit buffer offsets: the stored activation and the weight must each stay below 2 GB (SD-1.4 at batch 32: 84 MB;
+  // a 16-image VAE decode at 512 x 512 x 128: 1.07 GB); the host walks larger batches in chunks
+  if ((long)N * (H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL)
+    return UCE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // 128 x 128 tiles (a ragged last output-channel tile is masked: Cout = 320 runs 3 tiles, 572 TF/s against 389 for the
   // 256 x 64 form); 256 x 64 only where a 128-wide tile would be at least half empty (Cout <= 64)

@@ -51,15 +51,18 @@ CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "4096")) << 20
 CONV_IGEMM = os.environ.get("UCE_CONV_IGEMM", "auto")
 
 
-def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int) -> bool:
+def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32) -> bool:
+    """Measured on an MI355X (tools/probe_igemm.py, bf16): the implicit-GEMM kernel runs 600-820 TF/s once there are
+    enough pixel tiles and a long enough contraction; the library GEMM reaches 0.85-0.95 PF/s on the small-spatial,
+    wide layers but pays the patch-matrix round trip everywhere."""
     if CONV_IGEMM == "never" or Cin % 64 or Cout % 8:
         return False
     if CONV_IGEMM == "always":
         return True
-    # VAE decoder, 256^2 and 512^2 layers: 1.5-2.8x.  (The U-Net's 64 x 64 layers with 320 output channels are 14-16 %
-    # faster in isolation - 572-668 TF/s against 480-574 - but the generation loop measured the same 6.2 images/s with
-    # them on either path; the other U-Net layers run at 0.7-0.97 PF/s in the library GEMM against 0.5-0.66 here.)
-    return H * W >= 256 * 256 and Cin <= 512
+    M = N * H * W
+    if M >= 128 * 1024:                              # U-Net 64 x 64 at the generation batch, every VAE layer >= 128^2
+        return True
+    return M >= 32 * 1024 and Cin >= 640             # 32 x 32 layers with a long contraction (640 -> 640, 1920 -> 640)
 
 
 def even_chunk(n: int, cap: int) -> int:
@@ -294,8 +297,13 @@ class UceHandle:
         Cout = weight.shape[0]
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
-        _lib.check(self.lib.uce_conv3x3_nhwc_fwd(self._h, _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), N, Hh, Ww, Cc, Cout,
-                                                 int(upsample), dt, _stream_ptr(self.device)), "uce_conv3x3_nhwc_fwd")
+        xs, ys = x.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)            # NHWC views of the same storage
+        step = even_chunk(N, max(1, ((1 << 31) - 1) // max(1, Hs * Ws * Cc * x.element_size() + 1)))   # < 2 GB per launch
+        for n0 in range(0, N, step):
+            nb = min(step, N - n0)
+            _lib.check(self.lib.uce_conv3x3_nhwc_fwd(self._h, xs[n0].data_ptr(), _ptr(weight), _ptr(bias), ys[n0].data_ptr(),
+                                                     nb, Hh, Ww, Cc, Cout, int(upsample), dt, _stream_ptr(self.device)),
+                       "uce_conv3x3_nhwc_fwd")
         return y
 
     def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -307,7 +315,7 @@ class UceHandle:
         N, Cc, Hs, Ws = x.shape
         Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         Cout = weight.shape[0]
-        if conv_prefers_igemm(Hh, Ww, Cc, Cout):
+        if conv_prefers_igemm(Hh, Ww, Cc, Cout, N):
             return self.conv3x3_igemm(x, weight, bias, upsample=upsample)
         wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
