@@ -504,7 +504,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     __syncthreads();                                              // Ksum is read before the scratch (same LDS) is used
     DBG(3);
     if (half == 0) {
-      potrf64_reg8<0>(tt, sc, t256, j.status, 0, j.N);
+      UCE_POTRF64<0>(tt, sc, t256, j.status, 0, j.N);
       DBG(4);
       if (!j.R) {                                                 // (with solve riders nobody reads L: only L^-1 leaves)
 #pragma unroll
@@ -513,7 +513,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
           for (int cc = 0; cc < 4; ++cc) st_sc1(&j.Lmat[(4 * tti + r) * 64 + 4 * ttj + cc], tt[r][cc]);
       }
     } else {
-      potrf64_reg8<1>(tt, sc, t256, j.status, 0, j.N);
+      UCE_POTRF64<1>(tt, sc, t256, j.status, 0, j.N);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
