@@ -23,9 +23,6 @@ struct Potrf64Scratch {
   double row[64][64];   // row[k][j]: row k of the partial inverse when it was published
   double rs[64];        // 1/sqrt(effective pivot k)
   double g[64];         // odd k: p01/p00 of its pair
-  double gi[16][16];    // potrf64_mfma8: inverse of the Cholesky factor of pivot block b (lower 4 x 4, row-major)
-  double q[2][16];      // potrf64_mfma8: P^-1 of the pivot block of step s in slot s & 1 (written one step ahead by its owner wave)
-  double pn[16];        // potrf64_mfma8: the owner wave's private hand-over of the next pivot block
 };
 
 // 1 / sqrt(v): hardware estimate + two Newton steps (the sqrt + divide sequence of `1.0 / sqrt(v)` is ~10x the code)
@@ -269,212 +266,13 @@ __device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// MFMA form of the 64 x 64 factor + inverse (512 threads): FOUR pivots per barrier, the rank-4 trailing update IS one
-// v_mfma_f64_16x16x4_f64 per 16 x 16 tile (K = 4).  Same elimination, same published LDS lines (sc->col[k][i] = column k
-// of the Schur complement, sc->row[k][j] = row k of the partial inverse, each as it stood when its 4 x 4 pivot block
-// came up), 16 steps instead of 32:
-//   * waves 0-3 hold tile-row w of the lower triangle of the matrix, waves 4-7 tile-row w - 4 of X (starts as I), as MFMA
-//     accumulators (D layout: lane (c, rq) holds rows rq + 4q of column c);
-//   * step s (pivot block K = 4s .. 4s + 3 in tile tp = s / 4): owners publish the four pivot columns / rows, ONE
-//     barrier, every lane inverts the 4 x 4 pivot block P by 2 x 2 blocks (two reciprocal chains), forms its fragment
-//     of U = C P^-1 (four LDS reads, four FMAs) and issues one MFMA per live tile:  A_ij -= U_i C_j^T,  X_ij -= U_i Xrow_j;
-//   * assembly: with P_b = G_b G_b^T per block (16 threads factor the 16 blocks side by side at the end),
-//     L[:, block b] = C_b G_b^-T and L^-1[block b, :] = G_b^-1 Xrow_b.
-// The rank-2 form above spends ~1 250 cycles per two pivots on ~150 f64 VALU instructions per SIMD plus barrier, LDS
-// broadcast and a reciprocal chain; here the update is 1-4 MFMAs per wave and a step covers four pivots.
-// Same interface as potrf64_reg8 (4 x 4 register sub-blocks in, L / L^-1 sub-blocks out), so the callers do not change.
-// ---------------------------------------------------------------------------------------------
-struct Inv4 { double q[4][4]; };
-
-// inverse of a symmetric positive definite 4 x 4 (upper part given) by 2 x 2 blocks
-static __device__ __forceinline__ void inv4_spd(double p00, double p01, double p02, double p03, double p11, double p12,
-                                                double p13, double p22, double p23, double p33, Inv4& o) {
-  const double ia = rcp_f64(fma(p00, p11, -p01 * p01));
-  const double a00 = p11 * ia, a01 = -p01 * ia, a11 = p00 * ia;               // A^-1
-  const double t00 = fma(a00, p02, a01 * p12), t01 = fma(a00, p03, a01 * p13);  // T = A^-1 B
-  const double t10 = fma(a01, p02, a11 * p12), t11 = fma(a01, p03, a11 * p13);
-  const double s00 = p22 - fma(p02, t00, p12 * t10);                           // S = D - B^T T
-  const double s01 = p23 - fma(p02, t01, p12 * t11);
-  const double s11 = p33 - fma(p03, t01, p13 * t11);
-  const double is = rcp_f64(fma(s00, s11, -s01 * s01));
-  const double i00 = s11 * is, i01 = -s01 * is, i11 = s00 * is;               // S^-1
-  const double q02 = -fma(t00, i00, t01 * i01), q03 = -fma(t00, i01, t01 * i11);   // -T S^-1
-  const double q12 = -fma(t10, i00, t11 * i01), q13 = -fma(t10, i01, t11 * i11);
-  o.q[0][0] = a00 - fma(q02, t00, q03 * t01);
-  o.q[0][1] = o.q[1][0] = a01 - fma(q02, t10, q03 * t11);
-  o.q[1][1] = a11 - fma(q12, t10, q13 * t11);
-  o.q[0][2] = o.q[2][0] = q02;  o.q[0][3] = o.q[3][0] = q03;
-  o.q[1][2] = o.q[2][1] = q12;  o.q[1][3] = o.q[3][1] = q13;
-  o.q[2][2] = i00;  o.q[2][3] = o.q[3][2] = i01;  o.q[3][3] = i11;
-}
-
-// The wave that owns the pivot block of step s1 (4 x 4 block jn of its diagonal tile `d`, already updated by every
-// earlier step) inverts it and leaves P^-1 in sc->q[s1 & 1] - one step AHEAD of its use, beside the other waves' MFMAs,
-// so the two reciprocal chains of the 4 x 4 inverse are off every other wave's path.  The 16 entries sit in 16 lanes
-// (columns 4jn .. 4jn+3, register jn): through a wave-private LDS line, then every lane inverts (redundantly: uniform).
-static __device__ __forceinline__ void potrf64_next_q(const double4_t& d, int jn, int s1, Potrf64Scratch* sc, int lane) {
-  const int c = lane & 15, rq = lane >> 4;
-  const double v = jn == 0 ? d[0] : (jn == 1 ? d[1] : (jn == 2 ? d[2] : d[3]));   // row 4jn + rq of column c
-  if ((c >> 2) == jn) sc->pn[4 * rq + (c & 3)] = v;
-  __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0): the wave's own LDS writes have landed
-  __builtin_amdgcn_wave_barrier();
-  Inv4 Q;
-  inv4_spd(sc->pn[0], sc->pn[1], sc->pn[2], sc->pn[3], sc->pn[5], sc->pn[6], sc->pn[7], sc->pn[10], sc->pn[11], sc->pn[15], Q);
-  if (lane < 16) sc->q[s1 & 1][lane] = Q.q[lane >> 2][lane & 3];
-}
-
-// one pivot tile TP (static: accumulator indices are compile-time), its four 4-pivot steps j = 0..3 (runtime)
-template <int TP>
-__device__ __forceinline__ void potrf64_mfma_tile(double4_t (&acc)[4], Potrf64Scratch* sc, int role, int tr, int lane,
-                                                  int nsteps) {
-  const int c = lane & 15, rq = lane >> 4;
-#pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
-    const int s = 4 * TP + j, K = 4 * s;
-    if (s >= nsteps) return;                                       // (workgroup-uniform)
-    // ---- publish the pivot columns (matrix waves, tile (tr, TP)) and pivot rows (X wave tr == TP, tiles (TP, 0..TP))
-    if (role == 0) {
-      if (tr >= TP && (c >> 2) == j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sc->col[K + (c & 3)][16 * tr + rq + 4 * q] = acc[TP][q];
-      }
-    } else if (tr == TP) {
-#pragma unroll
-      for (int tc = 0; tc <= TP; ++tc) {
-        const double v = j == 0 ? acc[tc][0] : (j == 1 ? acc[tc][1] : (j == 2 ? acc[tc][2] : acc[tc][3]));
-        sc->row[K + rq][16 * tc + c] = v;                            // row 4j + rq of the tile
-      }
-    }
-    __syncthreads();
-    if (tr < TP) continue;                                           // (wave-uniform) this tile-row is finished
-    // ---- this lane's column kk = rq of P^-1 (left in sc->q by the owner wave during the previous step)
-    const double* qs = sc->q[s & 1];
-    // ---- A operand: -(C P^-1)[16 tr + c][rq]
-    const int urow = 16 * tr + c;
-    double u = sc->col[K][urow] * qs[rq];
-    u = fma(sc->col[K + 1][urow], qs[4 + rq], u);
-    u = fma(sc->col[K + 2][urow], qs[8 + rq], u);
-    u = fma(sc->col[K + 3][urow], qs[12 + rq], u);
-    u = -u;
-    // ---- one MFMA per live tile: B[kk = rq][col c] = C[16 tc + c][kk] (matrix) / Xrow[kk][16 tc + c] (X).
-    // Diagonal tile first: the owner of the NEXT pivot block needs it first.
-    if (role == 0) {
-#pragma unroll
-      for (int tc = 3; tc >= TP; --tc)
-        if (tc <= tr) acc[tc] = mfma_f64(u, sc->col[K + rq][16 * tc + c], acc[tc]);
-      // ---- look-ahead: the wave holding the next pivot block inverts it now
-      if (s + 1 < nsteps) {
-        if (j < 3) {
-          if (tr == TP) potrf64_next_q(acc[TP], j + 1, s + 1, sc, lane);
-        } else if (TP < 3) {
-          if (tr == TP + 1) potrf64_next_q(acc[TP < 3 ? TP + 1 : 3], 0, s + 1, sc, lane);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int tc = 0; tc <= TP; ++tc) acc[tc] = mfma_f64(u, sc->row[K + rq][16 * tc + c], acc[tc]);
-    }
-    // (no second barrier: the next step publishes lines K + 4 .. K + 7 and P^-1 goes to the other slot - nobody
-    //  rewrites what is still being read)
-  }
-}
-
-template <int ROLE>
-__device__ __forceinline__ void potrf64_mfma8(double (&t)[4][4], Potrf64Scratch* sc, int tid256, int* status,
-                                              int col_base, int npiv = 64) {
-  const int ti = tid256 >> 4, tj = tid256 & 15;
-  const int lane = tid256 & 63, w = tid256 >> 6;                     // wave within the role: tile-row
-  const int c = lane & 15, rq = lane >> 4;
-  const int nsteps = npiv >= 64 ? 16 : ((npiv + 3) >> 2), kstop = 4 * nsteps;
-  // ---- 4 x 4 register sub-blocks -> MFMA accumulator tiles, through the (still unused) `col` lines
-  double4_t acc[4];
-  if (ROLE == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) sc->row[4 * ti + r][4 * tj + cc] = t[r][cc];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int tc = 0; tc < 4; ++tc)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = 16 * w + rq + 4 * q, col = 16 * tc + c;
-      acc[tc][q] = (ROLE == 0) ? sc->row[row][col] : (row == col ? 1.0 : 0.0);
-    }
-  if (ROLE == 0 && w == 0) potrf64_next_q(acc[0], 0, 0, sc, lane);   // P^-1 of the first pivot block
-  __syncthreads();
-  potrf64_mfma_tile<0>(acc, sc, ROLE, w, lane, nsteps);
-  potrf64_mfma_tile<1>(acc, sc, ROLE, w, lane, nsteps);
-  potrf64_mfma_tile<2>(acc, sc, ROLE, w, lane, nsteps);
-  potrf64_mfma_tile<3>(acc, sc, ROLE, w, lane, nsteps);
-  __syncthreads();
-  // ---- per pivot block: G = chol(P), gi = G^-1 (16 threads, one block each), non-positive pivots reported
-  if (ROLE == 0 && tid256 < 16) {
-    const int b = tid256, K = 4 * b;
-    const bool live = b < nsteps;
-    const double p00 = live ? sc->col[K][K] : 1.0, p01 = live ? sc->col[K][K + 1] : 0.0, p02 = live ? sc->col[K][K + 2] : 0.0,
-                 p03 = live ? sc->col[K][K + 3] : 0.0, p11 = live ? sc->col[K + 1][K + 1] : 1.0,
-                 p12 = live ? sc->col[K + 1][K + 2] : 0.0, p13 = live ? sc->col[K + 1][K + 3] : 0.0,
-                 p22 = live ? sc->col[K + 2][K + 2] : 1.0, p23 = live ? sc->col[K + 2][K + 3] : 0.0,
-                 p33 = live ? sc->col[K + 3][K + 3] : 1.0;
-    const double r0 = rsqrt_f64(p00);
-    const double g10 = p01 * r0, g20 = p02 * r0, g30 = p03 * r0;
-    const double d1 = fma(-g10, g10, p11), r1 = rsqrt_f64(d1);
-    const double g21 = fma(-g20, g10, p12) * r1, g31 = fma(-g30, g10, p13) * r1;
-    const double d2 = fma(-g21, g21, fma(-g20, g20, p22)), r2 = rsqrt_f64(d2);
-    const double g32 = fma(-g31, g21, fma(-g30, g20, p23)) * r2;
-    const double d3 = fma(-g32, g32, fma(-g31, g31, fma(-g30, g30, p33))), r3 = rsqrt_f64(d3);
-    const int bad = !(p00 > 0.0) ? 0 : (!(d1 > 0.0) ? 1 : (!(d2 > 0.0) ? 2 : (!(d3 > 0.0) ? 3 : 4)));
-    const unsigned long long anybad = __ballot(bad < 4);
-    const int fb = anybad ? __builtin_ctzll(anybad) : 0;             // first block with a non-positive pivot
-    const int fk = __shfl(bad, fb);                                  // (all 16 lanes take part in the shuffle)
-    if (anybad && tid256 == 0) atomicCAS(status, 0, col_base + 4 * fb + fk + 1);
-    const double i10 = -g10 * r0 * r1;
-    const double i20 = -fma(g20, r0, g21 * i10) * r2, i21 = -g21 * r1 * r2;
-    const double i30 = -fma(g30, r0, fma(g31, i10, g32 * i20)) * r3, i31 = -fma(g31, r1, g32 * i21) * r3,
-                 i32 = -g32 * r2 * r3;
-    double* gi = sc->gi[b];
-    gi[0] = r0;   gi[1] = 0.0;  gi[2] = 0.0;   gi[3] = 0.0;
-    gi[4] = i10;  gi[5] = r1;   gi[6] = 0.0;   gi[7] = 0.0;
-    gi[8] = i20;  gi[9] = i21;  gi[10] = r2;   gi[11] = 0.0;
-    gi[12] = i30; gi[13] = i31; gi[14] = i32;  gi[15] = r3;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int row = 4 * ti + r, col = 4 * tj + cc;
-      double val = 0.0;
-      if (col <= row) {
-        if (ROLE == 0) {                                             // L[row][col] = sum_{m' <= m} C_b[row][m'] gi_b[m][m']
-          if (col >= kstop) {
-            val = (row == col) ? 1.0 : 0.0;
-          } else {
-            const int b = col >> 2, m = col & 3;
-            for (int mp = 0; mp <= m; ++mp) val = fma(sc->col[4 * b + mp][row], sc->gi[b][4 * m + mp], val);
-          }
-        } else {                                                     // L^-1[row][col] = sum_{m' <= m} gi_b[m][m'] Xrow_b[m'][col]
-          if (row >= kstop) {
-            val = (row == col) ? 1.0 : 0.0;
-          } else {
-            const int b = row >> 2, m = row & 3;
-            for (int mp = 0; mp <= m; ++mp) val = fma(sc->gi[b][4 * m + mp], sc->row[4 * b + mp][col], val);
-          }
-        }
-      }
-      t[r][cc] = val;
-    }
-}
-
-// The 64 x 64 factor the callers use: the MFMA rank-4 form; -DUCE_POTRF_RANK2 builds the rank-2 VALU form (A/B runs).
-#ifdef UCE_POTRF_RANK2
+// The 64 x 64 factor the callers use.  (Round 2 also built the rank-4 form with the trailing update on
+// v_mfma_f64_16x16x4_f64 - K = 4 is exactly one MFMA per 16 x 16 tile, 16 steps instead of 32, pivot-block inverse by
+// 2 x 2 blocks, computed either by every wave after the barrier or by its owner wave one step ahead: parity green,
+// 20.5 and 22 us per 64 x 64 block against 17.4 us here (git history: "experiment: MFMA rank-4 form").  A step is
+// bound by its dependent chain - barrier, LDS broadcast, reciprocal(s), ~10 dependent f64 operations - not by the
+// update arithmetic the MFMA removes, and a 4 x 4 inverse is a longer chain than two 2 x 2 ones.)
 #define UCE_POTRF64 potrf64_reg8
-#else
-#define UCE_POTRF64 potrf64_mfma8
-#endif
 
 // (A four-pivots-per-barrier VALU variant was tried and is SLOWER on MI355X - ~20 us vs ~14 us for the 64x64 factor +
 // inverse: the step time is set by the f64 VALU instruction count (f64 FMA issues at half rate on gfx950, ~8
