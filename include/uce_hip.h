@@ -169,6 +169,15 @@ int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, co
 int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const void* bias, void* y, long pixels, int C,
                           int dtype, uce_stream_t stream);
 
+/* Classifier-free-guidance combine + PNDM (PLMS) scheduler step in one pass (diffusers' `noise_pred_uncond + g *
+ * (noise_pred_text - noise_pred_uncond)` and `PNDMScheduler.step`, reached from generate-images-sd.py:37-42):
+ *   e = eps[0:n] + guidance * (eps[n:2n] - eps[0:n])  (cfg != 0; else e = eps[0:n])          -> eps_out [n]
+ *   prev = cs * sample - ce * (w[0] e + w[1] h1 + w[2] h2 + w[3] h3)                           -> prev_out [n]
+ * h1..h3: earlier model outputs (NULL = absent), w: the multistep weights (host floats), bf16 or f16, n % 8 == 0. */
+int uce_cfg_pndm_step(uce_handle_t h, const void* eps, int cfg, float guidance, const void* h1, const void* h2,
+                      const void* h3, const float* w, const void* sample, float cs, float ce, void* eps_out, void* prev_out,
+                      long n, int dtype, uce_stream_t stream);
+
 /* GEGLU of the transformer feed-forward (diffusers GEGLU, exact erf GELU): x [rows, 2*inner] -> y [rows, inner] =
  * x[:, :inner] * gelu(x[:, inner:]), bf16 or f16, inner % 8 == 0. */
 int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, int inner, int dtype, uce_stream_t stream);

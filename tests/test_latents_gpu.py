@@ -29,7 +29,7 @@ from uce_amd import REPO_ROOT
 pytestmark = pytest.mark.gpu
 
 PER_CALL_TOL = 6e-2          # measured 4.1e-2 .. 4.7e-2 (torch bf16 ops on the same model: 4.9e-2 .. 6.0e-2)
-FINAL_TOL = 5e-2             # measured 2.9e-2 after 51 U-Net calls (torch bf16 ops: 2.9e-2)
+FINAL_TOL = 3e-2             # measured 1.3e-2 after 51 U-Net calls (torch bf16 ops incl. their bf16 scheduler arithmetic: 2.9e-2)
 PROMPT = "a photo of an astronaut riding a horse"
 SEED = 1234
 STEPS = 50
@@ -76,6 +76,7 @@ def test_latents_at_sd14_size_match_fp32_within_stated_tolerance():
         pipe.to(dev, torch.bfloat16)
         _set_hip(True)
         pipe.use_graph = True
+        pipe.fused_step = True                                      # guidance combine + PLMS step as one HIP launch
         prod = pipe(PROMPT, num_inference_steps=STEPS, latents=lat0, output_type="latent").latents.float()
         assert len(pipe._graphs) == 1                               # the step really was replayed from a hipGraph
         pe, ne = pipe.encode_prompt(PROMPT, dev, 1, True)
@@ -89,6 +90,7 @@ def test_latents_at_sd14_size_match_fp32_within_stated_tolerance():
         # ---- (c) torch bf16 path (no hand-written kernels)
         _set_hip(False)
         pipe.use_graph = False
+        pipe.fused_step = False
         tb = pipe(PROMPT, num_inference_steps=STEPS, latents=lat0, output_type="latent").latents.float()
         per_call_torch = {i: O.rel_fro(_guided_eps(pipe, lat.to(torch.bfloat16), t, ctx).float(), eps)
                           for i, (t, lat, eps) in probes.items()}

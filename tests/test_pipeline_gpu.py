@@ -172,3 +172,36 @@ def test_debias_loop_with_real_sampling_on_gpu(tmp_path):
     assert seen and all(n == 4 for n in seen) and len(seen) % 2 == 0 and len(seen) <= 4
     state = load_file(path)
     assert len(state) == 32 and all(torch.isfinite(v).all() for v in state.values())
+
+
+def test_fused_cfg_pndm_step_matches_the_torch_scheduler():
+    """uce_cfg_pndm_step (guidance combine + PLMS step, one launch) against PNDMScheduler.step on the same sequence of
+    U-Net outputs: every branch of the multistep formula (first step, the repeated timestep, 2 / 3 / 4 stored outputs)."""
+    from uce_amd import edit as E
+    from uce_amd.sd.scheduler import PNDMScheduler
+    H = E.UceHandle.get("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    a, b = PNDMScheduler(), PNDMScheduler()
+    a.set_timesteps(8)
+    b.set_timesteps(8)
+    xa = torch.randn(2, 4, 16, 16, generator=g).cuda()
+    xb = xa.to(torch.bfloat16)
+    for t in a.timesteps.tolist():
+        raw = torch.randn(4, 4, 16, 16, generator=g).cuda()
+        raw16 = raw.to(torch.bfloat16)
+        eu, ec = raw16.float().chunk(2)
+        xa = a.step(eu + 7.5 * (ec - eu), t, xa)                       # fp32 reference on the bf16-rounded outputs
+        xb = b.step_fused(raw16, True, 7.5, t, xb, H)
+        assert xb.dtype == torch.bfloat16 and O.rel_fro(xb.float().cpu(), xa.cpu()) < 2e-2, t
+    assert len(b.ets) == len(a.ets) and b.counter == a.counter
+
+
+def test_fused_step_latents_match_the_unfused_path():
+    pipe = _tiny_gpu_pipe()
+    g = lambda: torch.Generator().manual_seed(11)
+    kw = dict(num_inference_steps=6, output_type="latent")
+    pipe.fused_step = True
+    fused = pipe("a photo of a dog", generator=g(), **kw).latents.float()
+    pipe.fused_step = False
+    plain = pipe("a photo of a dog", generator=g(), **kw).latents.float()
+    assert O.rel_fro(fused, plain) < 2e-2

@@ -128,7 +128,7 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
 
 extern "C" {
 
-int uce_version(void) { return 107; }
+int uce_version(void) { return 108; }
 
 const char* uce_strerror(int code) {
   switch (code) {

@@ -313,6 +313,69 @@ __global__ __launch_bounds__(256) void k_add_bias(const unsigned short* __restri
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Classifier-free-guidance combine + PNDM (PLMS) scheduler step in ONE pass over the latents (SURVEY.md 8f row 3;
+// reference: `noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)` and `scheduler.step(...)` inside
+// `pipe(...)`, evalscripts/generate-images-sd.py:37-42 - a dozen tiny elementwise launches per denoising step in torch):
+//   e      = eps[0:n] + g * (eps[n:2n] - eps[0:n])       (cfg; otherwise e = eps[0:n])   -> eps_out (history entry)
+//   m      = w0 * e + w1 * h1 + w2 * h2 + w3 * h3          (the linear multistep combination of the stored outputs)
+//   prev   = cs * sample - ce * m                          -> prev_out
+// f32 arithmetic on 16-bit tensors, one rounding per output (e is re-read as rounded: it is what the history holds).
+// ---------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void k_cfg_pndm(const unsigned short* __restrict__ eps, int cfg, float g,
+                                                  const unsigned short* __restrict__ h1, const unsigned short* __restrict__ h2,
+                                                  const unsigned short* __restrict__ h3, float w0, float w1, float w2, float w3,
+                                                  const unsigned short* __restrict__ sample, float cs, float ce,
+                                                  unsigned short* __restrict__ eps_out, unsigned short* __restrict__ prev_out,
+                                                  long n8) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n8; e += (long)gridDim.x * 256) {
+    float eu[8], ec[8], a[8], b[8], c[8], sv[8];
+    unpack8<F16>(*(const uint4_t*)(eps + e * 8), eu);
+    if (cfg) {
+      unpack8<F16>(*(const uint4_t*)(eps + (n8 + e) * 8), ec);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) eu[i] = fmaf(g, ec[i] - eu[i], eu[i]);
+    }
+    const uint4_t er = {pack2<F16>(eu[0], eu[1]), pack2<F16>(eu[2], eu[3]), pack2<F16>(eu[4], eu[5]), pack2<F16>(eu[6], eu[7])};
+    *(uint4_t*)(eps_out + e * 8) = er;
+    unpack8<F16>(er, eu);                                           // the rounded value, as the history stores it
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = b[i] = c[i] = 0.f;
+    if (h1) unpack8<F16>(*(const uint4_t*)(h1 + e * 8), a);
+    if (h2) unpack8<F16>(*(const uint4_t*)(h2 + e * 8), b);
+    if (h3) unpack8<F16>(*(const uint4_t*)(h3 + e * 8), c);
+    unpack8<F16>(*(const uint4_t*)(sample + e * 8), sv);
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float m = fmaf(w3, c[i], fmaf(w2, b[i], fmaf(w1, a[i], w0 * eu[i])));
+      o[i] = fmaf(cs, sv[i], -ce * m);
+    }
+    *(uint4_t*)(prev_out + e * 8) = (uint4_t){pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3]), pack2<F16>(o[4], o[5]), pack2<F16>(o[6], o[7])};
+  }
+}
+
+extern "C" int uce_cfg_pndm_step(uce_handle_t h, const void* eps, int cfg, float guidance, const void* h1, const void* h2,
+                                 const void* h3, const float* w, const void* sample, float cs, float ce, void* eps_out,
+                                 void* prev_out, long n, int dtype, uce_stream_t stream) {
+  if (!h || !eps || !w || !sample || !eps_out || !prev_out || n <= 0 || (n & 7)) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  const long n8 = n / 8;
+  long blocks = (n8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL(k_cfg_pndm<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)eps, cfg,
+                       guidance, (const unsigned short*)h1, (const unsigned short*)h2, (const unsigned short*)h3, w[0], w[1], w[2],
+                       w[3], (const unsigned short*)sample, cs, ce, (unsigned short*)eps_out, (unsigned short*)prev_out, n8);
+  else
+    hipLaunchKernelGGL(k_cfg_pndm<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)eps, cfg,
+                       guidance, (const unsigned short*)h1, (const unsigned short*)h2, (const unsigned short*)h3, w[0], w[1], w[2],
+                       w[3], (const unsigned short*)sample, cs, ce, (unsigned short*)eps_out, (unsigned short*)prev_out, n8);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
 extern "C" int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const void* bias, void* y, long pixels,
                                      int C, int dtype, uce_stream_t stream) {
   if (!h || !a || !y || pixels <= 0 || C <= 0 || C % 8) return UCE_EINVAL;

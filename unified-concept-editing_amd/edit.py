@@ -346,6 +346,20 @@ class UceHandle:
                                               rows, Cc, float(eps), dt, _stream_ptr(self.device)), "uce_layernorm_fwd")
         return y if residual is None else (s, y)
 
+    def cfg_pndm_step(self, eps: torch.Tensor, cfg: bool, guidance: float, hist, weights, sample: torch.Tensor, cs: float,
+                      ce: float):
+        """Guidance combine + PLMS step in one launch (uce_cfg_pndm_step).  eps: [2n, ...] (uncond; cond) when cfg else
+        [n, ...]; hist: up to three earlier model outputs (most recent first); weights: 4 floats.  -> (eps_guided, prev)."""
+        n = sample.numel()
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[sample.dtype]
+        eps_out, prev = torch.empty_like(sample), torch.empty_like(sample)
+        hs = [None if i >= len(hist) else hist[i] for i in range(3)]
+        w = (ctypes.c_float * 4)(*[float(x) for x in weights])
+        _lib.check(self.lib.uce_cfg_pndm_step(self._h, _ptr(eps), int(cfg), float(guidance), _ptr(hs[0]), _ptr(hs[1]), _ptr(hs[2]),
+                                              w, _ptr(sample), float(cs), float(ce), _ptr(eps_out), _ptr(prev), n, dt,
+                                              _stream_ptr(self.device)), "uce_cfg_pndm_step")
+        return eps_out, prev
+
     def geglu(self, x: torch.Tensor) -> torch.Tensor:
         """x [..., 2*inner] -> x[..., :inner] * gelu(x[..., inner:]) through uce_geglu_fwd."""
         inner = x.shape[-1] // 2

@@ -42,6 +42,7 @@ SIGNATURES = {
     "uce_groupnorm_chunks": (_i, [_i]),
     "uce_groupnorm_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "uce_add_bias_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "uce_cfg_pndm_step": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, C.POINTER(_f), _vp, _f, _f, _vp, _vp, _l, _i, _vp]),
     "uce_geglu_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "uce_im2col3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "uce_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -201,10 +201,12 @@ class _GraphedStep:
     every attn2 (rewritten per prompt by `set_context`).  Parameters are captured by address, so an
     in-place weight patch (`patch_unet`) is picked up without re-capturing."""
 
-    def __init__(self, pipe, n: int, hh: int, ww: int, cfg: bool, guidance_scale: float, ctx: torch.Tensor):
+    def __init__(self, pipe, n: int, hh: int, ww: int, cfg: bool, guidance_scale: float, ctx: torch.Tensor,
+                 raw: bool = False):
         from .unet import Attention
         unet, dev = pipe.unet, pipe.device
         self.unet = unet
+        self.raw = raw
         self.lat = torch.zeros((n, unet.cfg.in_channels, hh, ww), device=dev, dtype=pipe.dtype)
         self.t = torch.zeros((1,), device=dev, dtype=torch.long)
         self.ctx = ctx.clone()
@@ -215,7 +217,7 @@ class _GraphedStep:
         def body():
             x = torch.cat([self.lat] * 2) if cfg else self.lat
             eps = unet(x, self.t, self.ctx)
-            if cfg:
+            if cfg and not raw:                            # raw: the guidance combine rides in the fused scheduler step
                 eu, ec = eps.chunk(2)
                 eps = eu + guidance_scale * (ec - eu)
             return eps
@@ -248,7 +250,7 @@ class _GraphedStep:
         self.lat.copy_(latents)
         self.t.fill_(int(t))
         self.graph.replay()
-        return self.eps.clone()                            # PNDM keeps a history of past outputs
+        return self.eps if self.raw else self.eps.clone()  # PNDM keeps a history of past outputs (raw: consumed at once)
 
 
 class StableDiffusionPipeline:
@@ -260,6 +262,7 @@ class StableDiffusionPipeline:
         self.dtype = torch.float32
         self.hoist_context = True        # K/V of the (step-invariant) text context computed once per prompt
         self.use_graph = True            # on a GPU: replay the denoising evaluation from a hipGraph
+        self.fused_step = True           # on a GPU in bf16/f16: guidance combine + PLMS step as one HIP launch
         self.channels_last = True        # on a GPU: NHWC weights/activations for the convolutions
         self._graphs: Dict[tuple, _GraphedStep] = {}
 
@@ -347,13 +350,20 @@ class StableDiffusionPipeline:
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, device="cpu")
         latents = latents * sch.init_noise_sigma
+        # guidance combine + scheduler step in one launch (uce_cfg_pndm_step) where the tensors allow it
+        fused = (self.fused_step and callback is None and self.device.type == "cuda" and isinstance(sch, PNDMScheduler)
+                 and self.dtype in (torch.bfloat16, torch.float16) and latents.numel() % 8 == 0)
+        handle = None
+        if fused:
+            from .. import edit as _edit
+            handle = _edit.UceHandle.get(self.device)
         graphed = None
         if self.use_graph and self.hoist_context and self.device.type == "cuda":
-            key = (n, hh, ww, cfg, float(guidance_scale), tuple(ctx.shape), self.dtype)
+            key = (n, hh, ww, cfg, float(guidance_scale), tuple(ctx.shape), self.dtype, fused)
             graphed = self._graphs.get(key)
             if graphed is None:
                 try:
-                    graphed = self._graphs[key] = _GraphedStep(self, n, hh, ww, cfg, float(guidance_scale), ctx)
+                    graphed = self._graphs[key] = _GraphedStep(self, n, hh, ww, cfg, float(guidance_scale), ctx, raw=fused)
                 except RuntimeError as err:               # capture refused: same kernels, eager launches
                     import warnings
                     warnings.warn(f"hipGraph capture of the denoising step failed ({err}); launching eagerly")
@@ -370,9 +380,12 @@ class StableDiffusionPipeline:
                 else:
                     x = torch.cat([latents] * 2) if cfg else latents
                     eps = self.unet(x, torch.tensor([t], device=self.device), ctx)
-                    if cfg:
+                    if cfg and not fused:
                         eu, ec = eps.chunk(2)
                         eps = eu + guidance_scale * (ec - eu)
+                if fused:
+                    latents = sch.step_fused(eps, cfg, float(guidance_scale), t, latents, handle)
+                    continue
                 if callback is not None:                   # (step index, timestep, latents fed to the U-Net, guided eps)
                     callback(step_index, t, latents, eps)
                 latents = sch.step(eps, t, latents)

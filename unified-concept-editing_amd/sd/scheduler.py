@@ -71,6 +71,44 @@ class PNDMScheduler:
         self.counter += 1
         return prev
 
+    def step_fused(self, eps_raw: torch.Tensor, cfg: bool, guidance_scale: float, timestep: int, sample: torch.Tensor,
+                   handle) -> torch.Tensor:
+        """The same PLMS step with the guidance combine in front of it as ONE HIP launch (uce_cfg_pndm_step): `eps_raw`
+        is the U-Net output for [uncond; cond] (cfg) or the plain output.  Branch selection as in `step`; the linear
+        combination of the stored outputs and the two coefficients of `_prev_sample` go to the kernel as scalars."""
+        t = int(timestep)
+        t_prev = t - self.step_ratio
+        second = self.counter == 1                       # the repeated timestep: uses the first output, appends nothing
+        if second:
+            t_prev, t = t, t + self.step_ratio
+        hist = list(reversed(self.ets[-3:])) if not second else [self.ets[-1]]
+        n_after = len(self.ets[-3:]) + 1 if not second else 1
+        if second:
+            w, src = (0.5, 0.5, 0.0, 0.0), self.cur_sample
+        elif n_after == 1:
+            w, src = (1.0, 0.0, 0.0, 0.0), sample
+        elif n_after == 2:
+            w, src = (1.5, -0.5, 0.0, 0.0), sample
+        elif n_after == 3:
+            w, src = (23 / 12, -16 / 12, 5 / 12, 0.0), sample
+        else:
+            w, src = (55 / 24, -59 / 24, 37 / 24, -9 / 24), sample
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[t_prev] if t_prev >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cs = float((a_prev / a_t) ** 0.5)
+        ce = float((a_prev - a_t) / (a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5))
+        eps, prev = handle.cfg_pndm_step(eps_raw.contiguous(), cfg, guidance_scale, hist, w, src.contiguous(), cs, ce)
+        if not second:
+            self.ets = self.ets[-3:]
+            self.ets.append(eps)
+            if n_after == 1 and self.counter == 0:
+                self.cur_sample = sample
+        else:
+            self.cur_sample = None
+        self.counter += 1
+        return prev
+
 
 class EulerDiscreteScheduler:
     """Euler (ancestral-free) discrete scheduler as SDXL-base ships it (scheduler/scheduler_config.json: scaled_linear betas
