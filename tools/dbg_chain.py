@@ -36,4 +36,6 @@ t0 = a[:, 0][a[:, 0] > 0].min()
 for b in range(64):
     row = [(int(x) - int(t0)) / 100.0 if x > 0 else None for x in a[b, :6]]
     if b < 20 or b % 16 == 0:
-        print(b, row)
+        cyc = [int(a[b, 8 + k + 1]) - int(a[b, 8 + k]) if a[b, k + 1] > 0 and a[b, k] > 0 else None for k in range(5)]
+        print(b, row, "shader-clock cycles per phase:", cyc)
+

@@ -1,0 +1,103 @@
+// Latency probes on gfx950 (one workgroup): dependent f64 FMA chain, v_rcp_f64, LDS write->barrier->read round trip,
+// s_memtime overhead.  hipcc --offload-arch=gfx950 -O3 lat.hip -o lat && ./lat
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+// s_memtime ordered against the value `v` (the compiler may not move the arithmetic on v across the stamp)
+#define STAMP(t, v) asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(v) :: "memory")
+
+__global__ void k(double* out, unsigned long long* cyc, double seed, int nwaves_active) {
+  __shared__ double lds[64 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  unsigned long long t0, t1;
+  double x = seed + tid * 1e-9, y = 1.000000001;
+  // (0) s_memtime back to back
+  STAMP(t0, x);
+  STAMP(t1, x);
+  if (tid == 0) cyc[0] = t1 - t0;
+  // (1) 64 dependent f64 FMAs
+  STAMP(t0, x);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) x = fma(x, y, 1e-12);
+  STAMP(t1, x);
+  if (tid == 0) cyc[1] = t1 - t0;
+  // (2) 64 independent f64 FMAs (8 chains x 8)
+  double z[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = x + j;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(z[j]));
+  STAMP(t0, z[0]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = fma(z[j], y, 1e-12);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(z[j]));
+  STAMP(t1, z[7]);
+  if (tid == 0) cyc[2] = t1 - t0;
+  // (3) 16 dependent v_rcp_f64
+  double r = x;
+  STAMP(t0, r);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r = __builtin_amdgcn_rcp(r);
+  STAMP(t1, r);
+  if (tid == 0) cyc[3] = t1 - t0;
+  // (4) LDS: write b128 -> waitcnt -> barrier -> broadcast read b128 -> use, 16 rounds
+  double acc = 0.0;
+  __syncthreads();
+  STAMP(t0, acc);
+  for (int i = 0; i < 16; ++i) {
+    if (wave < nwaves_active) {
+      if ((tid & 63) < 4) { lds[(i & 3) * 64 + 2 * tid] = x + i; lds[(i & 3) * 64 + 2 * tid + 1] = r; }
+    }
+    __syncthreads();
+    if (wave < nwaves_active) acc += lds[(i & 3) * 64 + 2] + lds[(i & 3) * 64 + 3];
+  }
+  STAMP(t1, acc);
+  if (tid == 0) cyc[4] = t1 - t0;
+  // (5) LDS read latency alone: 16 dependent reads (pointer chase)
+  int idx = tid & 63;
+  lds[tid & 4095] = 0.0;
+  __syncthreads();
+  int* li = (int*)lds;
+  li[tid] = (tid + 1) & 63;
+  __syncthreads();
+  STAMP(t0, idx);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) idx = li[idx];
+  STAMP(t1, idx);
+  if (tid == 0) cyc[5] = t1 - t0;
+  // (6) barrier alone, 16 rounds
+  STAMP(t0, idx);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) __syncthreads();
+  STAMP(t1, idx);
+  if (tid == 0) cyc[6] = t1 - t0;
+  // (7) 16 dependent f32 FMAs x4
+  float f = (float)x;
+  STAMP(t0, f);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) f = fmaf(f, 1.0000001f, 1e-12f);
+  STAMP(t1, f);
+  if (tid == 0) cyc[7] = t1 - t0;
+  out[tid] = x + z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7] + r + acc + idx + f;
+}
+
+int main() {
+  double* out;
+  unsigned long long* cyc;
+  hipMalloc(&out, 1024 * 8);
+  hipMalloc(&cyc, 64 * 8);
+  for (int threads : {64, 256, 512}) {
+    for (int rep = 0; rep < 3; ++rep) k<<<1, threads>>>(out, cyc, 1.5, 8);
+    hipDeviceSynchronize();
+    unsigned long long h[8];
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    printf("threads %d: memtime pair %llu | 64 dep f64 fma %llu (%.1f each) | 64 indep f64 fma %llu (%.1f each) | 16 dep rcp_f64 %llu (%.1f each) | "
+           "16 LDS publish rounds %llu (%.1f each) | 16 dep LDS reads %llu (%.1f each) | 16 barriers %llu (%.1f each) | 64 dep f32 fma %llu (%.1f)\n",
+           threads, h[0], h[1], h[1] / 64.0, h[2], h[2] / 64.0, h[3], h[3] / 16.0, h[4], h[4] / 16.0, h[5], h[5] / 16.0, h[6], h[6] / 16.0,
+           h[7], h[7] / 64.0);
+  }
+  return 0;
+}

@@ -1,0 +1,84 @@
+// Times the 64 x 64 f64 Cholesky-inverse building block (uce_potrf64.h) alone: one 512-thread workgroup, the SPD
+// block in LDS, s_memtime around the call (-DPK_STAMPS: per-phase stamps).  Checks X A X^T = I, X lower triangular.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I include -I unified-concept-editing_amd/csrc tools/ubench/potrf.hip -o /tmp/potrf && /tmp/potrf
+#include "uce_potrf64.h"
+#include <cstdio>
+#include <cmath>
+#include <vector>
+
+__global__ __launch_bounds__(512) void k(const double* A, double* Lo, double* Xo, int* status, unsigned long long* cyc, int npiv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* As = (double*)(smem_raw + sizeof(Potrf64Scratch));
+  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 4096; e += 512) As[(e >> 6) * 66 + (e & 63)] = A[e];
+  __syncthreads();
+  const unsigned long long t0 = clock64();
+  UCE_POTRF64([&](int r, int c, double (&v)[4]) { for (int e = 0; e < 4; ++e) v[e] = As[r * 66 + c + e]; },
+              [&](int row, int col, const double (&v)[4]) { for (int e = 0; e < 4; ++e) Xo[row * 64 + col + e] = v[e]; },
+              sc, tid, status, 0, npiv);
+  const unsigned long long t1 = clock64();
+  if (tid == 0) cyc[0] = t1 - t0;
+#ifdef PK_STAMPS
+  __syncthreads();
+  if (tid == 0) for (int i = 0; i < 6; ++i) cyc[1 + i] = g_pkst[i] - t0;
+#endif
+}
+
+int main() {
+  const int n = 64;
+  std::vector<double> A(n * n), B(n * n);
+  unsigned s = 12345;
+  for (auto& v : B) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0 - 0.5; }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double a = (i == j) ? 0.5 : 0.0;
+      for (int k = 0; k < n; ++k) a += B[i * n + k] * B[j * n + k];
+      A[i * n + j] = a;
+    }
+  double *dA, *dL, *dX;
+  int* st;
+  unsigned long long* cyc;
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&st, 4); hipMalloc(&cyc, 64);
+  hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+  hipMemset(st, 0, 4);
+  const size_t smem = sizeof(Potrf64Scratch) + 64 * 66 * 8;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  for (int npiv : {64, 50, 8}) {
+    unsigned long long best = ~0ull;
+    for (int rep = 0; rep < 5; ++rep) {
+      k<<<1, 512, smem>>>(dA, dL, dX, st, cyc, npiv);
+      hipDeviceSynchronize();
+      unsigned long long h, st[8];
+      hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+      if (h < best) best = h;
+      hipMemcpy(st, cyc, 56, hipMemcpyDeviceToHost);
+#ifdef PK_STAMPS
+      if (rep == 4) printf("  stamps (cycles from entry): start %llu | tiles loaded %llu | lines initialised, first pair out %llu | loop done %llu | pivots scaled %llu | assembled %llu\n", st[1], st[2], st[3], st[4], st[5], st[6]);
+#endif
+    }
+    std::vector<double> L(n * n), X(n * n);
+    hipMemcpy(L.data(), dL, n * n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(X.data(), dX, n * n * 8, hipMemcpyDeviceToHost);
+    double e1 = 0, e2 = 0;
+    if (npiv == 64) {
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          // the factor hands out L^-1 only: check X A X^T = I and that X is lower triangular
+          double b = 0;
+          for (int k2 = 0; k2 < n; ++k2) {
+            double t = 0;
+            for (int k3 = 0; k3 < n; ++k3) t += A[k2 * n + k3] * X[j * n + k3];
+            b += X[i * n + k2] * t;
+          }
+          e2 = fmax(e2, fabs(b - (i == j ? 1.0 : 0.0)));
+          if (j > i) e1 = fmax(e1, fabs(X[i * n + j]));
+        }
+    }
+    int hs;
+    hipMemcpy(&hs, st, 4, hipMemcpyDeviceToHost);
+    printf("npiv %d: %llu cycles (%.0f per pair step)  max |upper(X)| %.2e  |X A X^T - I| %.2e  status %d\n", npiv, best,
+           (double)best / (2 * ((npiv + 3) / 4)), e1, e2, hs);
+  }
+  return 0;
+}

@@ -26,6 +26,7 @@ PUBLIC_HEADER = os.path.normpath(os.path.join(PKG, "..", "include", "uce_hip.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 if os.environ.get("UCE_CHAIN_DEBUG"):          # phase stamps of the rider chain (tools/dbg_chain.py); never in the product build
     FLAGS.append("-DUCE_CHAIN_DEBUG")
+FLAGS += os.environ.get("UCE_DEFINES", "").split()            # experiment switches (-DNAME=VALUE ...), empty in the product build
 
 
 def sources() -> list[str]:

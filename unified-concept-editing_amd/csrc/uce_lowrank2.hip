@@ -19,7 +19,7 @@
 // (tools/dbg_chain.py); compiled out of the product library.
 #ifdef UCE_CHAIN_DEBUG
 __device__ unsigned long long g_dbg[64][16];
-#define DBG(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_dbg[blockIdx.x][slot] = wall_clock64(); } while (0)
+#define DBG(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) { g_dbg[blockIdx.x][slot] = wall_clock64(); g_dbg[blockIdx.x][8 + slot] = clock64(); } } while (0)
 extern "C" int uce_debug_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
 }
@@ -492,33 +492,17 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
       }
     }
     __syncthreads();
-    const int t256 = tid & 255;
-    const int tti = t256 >> 4, ttj = t256 & 15;
-    double tt[4][4];
-    if (half == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) tt[r][cc] = Ksum[(4 * tti + r) * GP_TLD + 4 * ttj + cc];
-    }
-    __syncthreads();                                              // Ksum is read before the scratch (same LDS) is used
     DBG(3);
-    if (half == 0) {
-      UCE_POTRF64<0>(tt, sc, t256, j.status, 0, j.N);
-      DBG(4);
-      if (!j.R) {                                                 // (with solve riders nobody reads L: only L^-1 leaves)
+    UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+                  const pk_d2 a = *(const pk_d2*)&Ksum[row * GP_TLD + col], b = *(const pk_d2*)&Ksum[row * GP_TLD + col + 2];
+                  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+                },
+                [&](int row, int col, const double (&v)[4]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) st_sc1(&j.Lmat[(4 * tti + r) * 64 + 4 * ttj + cc], tt[r][cc]);
-      }
-    } else {
-      UCE_POTRF64<1>(tt, sc, t256, j.status, 0, j.N);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) st_sc1(&j.Linv[(4 * tti + r) * 64 + 4 * ttj + cc], tt[r][cc]);
-    }
+                  for (int e = 0; e < 4; ++e) st_sc1(&j.Linv[row * 64 + col + e], v[e]);
+                },
+                sc, tid, j.status, 0, j.N);
+    DBG(4);
     announce_factor(j, false);
     DBG(5);
     return;

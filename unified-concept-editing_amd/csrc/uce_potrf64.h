@@ -6,23 +6,20 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// Register-tiled Cholesky + inverse of one 64x64 SPD block by 256 threads.
-// Thread (ti, tj) = (tid >> 4, tid & 15) owns the 4x4 sub-block rows 4ti.., cols 4tj.. of the
-// matrix (a) and of X (x, starts as I, ends as L^-1).  Right-looking block elimination, TWO pivots
-// per step (32 steps, one barrier each): at step (k, k+1) the owners publish
-// columns k, k+1 of the current Schur complement and rows k, k+1 of X into LDS lines; everybody
-// reads the 2x2 pivot block P, inverts it, and applies the rank-2 update
+// Cholesky inverse of one 64x64 SPD block: A = L L^T, the block hands out L^-1.
+// Right-looking block elimination on [A | I], TWO pivots per step (32 steps, one barrier each).  Threads own 4x4
+// register tiles of the current Schur complement (a) and of X (starts as I, ends as L^-1 up to the row scaling).  At
+// step (k, k+1) the owners publish columns k, k+1 of the Schur complement and rows k, k+1 of X into LDS LINES;
+// everybody reads the 2x2 pivot block P, inverts it, and applies the rank-2 update
 //     a_ij -= [a_ik a_i,k+1] P^-1 [a_jk a_j,k+1]^T ,   x_ij -= [a_ik a_i,k+1] P^-1 [x_kj x_k+1,j]^T .
-// The published lines are final as published (later register updates of eliminated rows/columns
-// are harmless garbage that is never read), so nothing is masked.  L and L^-1 are assembled from
-// the lines in one pass at the end: an even column is scaled by 1/sqrt(p00); an odd one first
-// gets the pivot-k elimination it skipped:  (c1 - c0 p01/p00) / sqrt(p11 - p01^2/p00).
+// The published lines are final as published (later register updates of eliminated rows/columns are harmless
+// garbage that is never read), so nothing is masked.  L^-1 is assembled from the row lines in one pass at the end:
+// an even row is scaled by 1/sqrt(p00); an odd one first gets the pivot-k elimination it skipped:
+// (r1 - r0 p01/p00) / sqrt(p11 - p01^2/p00).
 // ---------------------------------------------------------------------------------------------
 struct Potrf64Scratch {
-  double col[64][64];   // col[k][i]: column k of the Schur complement when it was published
-  double row[64][64];   // row[k][j]: row k of the partial inverse when it was published
-  double rs[64];        // 1/sqrt(effective pivot k)
-  double g[64];         // odd k: p01/p00 of its pair
+  double col[64][64];   // column line k: column k of the Schur complement when it was published (element order: pk_pos)
+  double row[64][64];   // row line k: row k of the partial inverse when it was published
 };
 
 // 1 / sqrt(v): hardware estimate + two Newton steps (the sqrt + divide sequence of `1.0 / sqrt(v)` is ~10x the code)
@@ -40,325 +37,246 @@ static __device__ __forceinline__ double rcp_f64(double v) {
   return r;
 }
 
-// One pair of pivots K = 4*kb + KR, K + 1 (KR in {0, 2} is static so register indices are static;
-// kb is a loop variable: the 32 steps are a 16-trip loop of two bodies, ~3 KB of code.  A fully
-// unrolled version of this loop is instruction-fetch bound: 50 KB of run-once straight-line code
-// took 31-38 us regardless of how many barriers it contained).
+// ---------------------------------------------------------------------------------------------
+// How the elimination is laid out on the CU (tools/ubench/potrf.hip times the block alone).  A pair step costs what
+// its LDS round trip costs - write lines, barrier, ~10 b128 reads per wave at ~20-30 cycles each, 60 f64 VALU
+// instructions at 4 cycles - so the layout minimises LDS instructions, exposed latencies and branches:
+//  * only LIVE tiles carry work, packed into four waves (one per SIMD): tile (ti, tj) of the matrix is live while
+//    kb <= tj and only the lower block triangle is ever read; tile (ti, tj) of X only once kb >= tj (row K of X is
+//    zero right of column K + 1).  In 16-column groups:  matrix 0..15: kb < 4 | 16..31: kb < 8 | 32..63: always;
+//    X 0..15: always | 16..31: kb >= 4 | 32..47: kb >= 8 | 48..63: kb >= 12.  So
+//        wave 0: matrix cols 32..63 (48 lanes, lower block triangle) + X cols 48..63 (16 lanes)
+//        wave 1: X cols 0..15
+//        wave 2: matrix cols 16..31 (rows >= 16); from kb = 8 on: X cols 32..47 (rows >= 32)
+//        wave 3: matrix cols 0..15;               from kb = 4 on: X cols 16..31 (rows >= 16)
+//    Waves 4-7 of the 512-thread callers only meet the barriers and come back for the assembly.
+//  * X tiles are held TRANSPOSED, so both roles run one instruction stream:  w[b][a] -= [F0[a] F1[a]] Q [S0[b] S1[b]]^T
+//    with S = the column lines at the tile's second index and F = the column (matrix) or row (X) lines at its first
+//    index; the line a thread reads F from is the line it publishes to.  No role branches in the step; tiles that
+//    are not live yet subtract exact zeros (the row lines start as the identity), dead tiles compute garbage nobody
+//    reads.
+//  * every LDS read of a step is issued right after the barrier (one exposed latency, not three dependent ones);
+//  * the two columns the NEXT pair publishes are updated first and written to LDS before the rest of the update;
+//  * run-once code (tile load, line initialisation, assembly) executes at instruction-fetch speed, ~1.7 cycles per
+//    byte: no divergent blocks (the compiler parks them far away), vector loads, one assembly pass for L^-1 only.
+// `loadA(row, col, v[4])` supplies 4 consecutive columns of a row of the SPD block (it may read LDS that the scratch
+// aliases: everything is fetched, then a barrier, then the scratch is touched).
+// ---------------------------------------------------------------------------------------------
+typedef double pk_d2 __attribute__((ext_vector_type(2)));
+
+// A line (512 B) keeps element j at pk_pos(j): the first two elements of every 4-group in its lower half, the last two
+// in its upper half - the 16 tiles' 16-byte pieces are contiguous, so the b128 reads of a step are conflict-free
+// (with the natural order they sit at a 32-byte stride: two-way conflicts, measured +27 % per read).
+__device__ __forceinline__ constexpr int pk_pos(int j) { return ((j & 2) << 4) + ((j >> 2) << 1) + (j & 1); }
+
 template <int KR>
-__device__ __forceinline__ void potrf64_pair(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
-                                             int ti, int tj, int kb) {
+__device__ __forceinline__ void pk_step(double (&w)[4][4], char* lds, unsigned foff, unsigned soff, int i2, int kb, int kstop) {
   const int K = 4 * kb + KR;
-  if (tj == kb) {
+  char* lk = lds + K * 512;                                  // line K (column array; the row array sits 32 KB above)
+  const unsigned poff = (KR ? 256u : 0u) + 16u * (unsigned)kb;
+  const pk_d2 pp = *(const pk_d2*)(lk + poff);               // col[K][K], col[K][K + 1]
+  const double p11 = *(const double*)(lk + 512 + poff + 8);  // col[K + 1][K + 1]
+  pk_d2 s0[2], s1[2], f0[2], f1[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sc->col[K][4 * ti + r] = a[r][KR];
-      sc->col[K + 1][4 * ti + r] = a[r][KR + 1];
-    }
+  for (int h = 0; h < 2; ++h) {
+    s0[h] = *(const pk_d2*)(lk + soff + 256 * h);
+    s1[h] = *(const pk_d2*)(lk + 512 + soff + 256 * h);
+    f0[h] = *(const pk_d2*)(lk + foff + 256 * h);
+    f1[h] = *(const pk_d2*)(lk + 512 + foff + 256 * h);
   }
-  if (ti == kb) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      sc->row[K][4 * tj + c] = x[KR][c];
-      sc->row[K + 1][4 * tj + c] = x[KR + 1][c];
-    }
-  }
-  __syncthreads();
-  const double p00 = sc->col[K][K], p01 = sc->col[K][K + 1], p11 = sc->col[K + 1][K + 1];
+  const double p00 = pp[0], p01 = pp[1];
   const double idet = rcp_f64(fma(p00, p11, -p01 * p01));
   const double q00 = p11 * idet, q01 = -p01 * idet, q11 = p00 * idet;
-  double u[4], v[4], c0[4], c1[4], x0[4], x1[4];
+  double u[4], v[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double a0 = sc->col[K][4 * ti + r], a1 = sc->col[K + 1][4 * ti + r];
-    u[r] = fma(a0, q00, a1 * q01);
-    v[r] = fma(a0, q01, a1 * q11);
+  for (int b = 0; b < 4; ++b) {
+    const double c0 = s0[b >> 1][b & 1], c1 = s1[b >> 1][b & 1];
+    u[b] = fma(c0, q00, c1 * q01);
+    v[b] = fma(c0, q01, c1 * q11);
+  }
+  constexpr int BN = (KR + 2) & 3;                            // the columns the next pair publishes: updated first
+#pragma unroll
+  for (int b = BN; b < BN + 2; ++b)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) w[b][a] = fma(-f0[a >> 1][a & 1], u[b], fma(-f1[a >> 1][a & 1], v[b], w[b][a]));
+  const int kbn = KR == 0 ? kb : kb + 1;
+  if (i2 == kbn && K + 2 < kstop) {
+    char* ln = lk + 1024 + foff;
+    *(pk_d2*)(ln) = (pk_d2){w[BN][0], w[BN][1]};
+    *(pk_d2*)(ln + 256) = (pk_d2){w[BN][2], w[BN][3]};
+    *(pk_d2*)(ln + 512) = (pk_d2){w[BN + 1][0], w[BN + 1][1]};
+    *(pk_d2*)(ln + 768) = (pk_d2){w[BN + 1][2], w[BN + 1][3]};
   }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    c0[c] = sc->col[K][4 * tj + c];
-    c1[c] = sc->col[K + 1][4 * tj + c];
-    x0[c] = sc->row[K][4 * tj + c];
-    x1[c] = sc->row[K + 1][4 * tj + c];
-  }
+  for (int b = KR; b < KR + 2; ++b)
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a[r][c] = fma(-u[r], c0[c], fma(-v[r], c1[c], a[r][c]));
-      x[r][c] = fma(-u[r], x0[c], fma(-v[r], x1[c], x[r][c]));
-    }
+    for (int a = 0; a < 4; ++a) w[b][a] = fma(-f0[a >> 1][a & 1], u[b], fma(-f1[a >> 1][a & 1], v[b], w[b][a]));
 }
 
-// a[][] holds this thread's 4x4 sub-block of the SPD tile on entry (lower triangle is what
-// matters); on exit a = sub-block of L (zero above the diagonal), x = sub-block of L^-1.
-__device__ __forceinline__ void potrf64_reg(double (&a)[4][4], double (&x)[4][4], Potrf64Scratch* sc,
-                                            int tid, int* status, int col_base) {
-  const int ti = tid >> 4, tj = tid & 15;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) x[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
-#pragma unroll 1
-  for (int kb = 0; kb < 16; ++kb) {
-    potrf64_pair<0>(a, x, sc, ti, tj, kb);
-    potrf64_pair<2>(a, x, sc, ti, tj, kb);
-  }
-  __syncthreads();
-  if (tid < 32) {
-    const int k = 2 * tid;
-    const double p00 = sc->col[k][k], p01 = sc->col[k][k + 1], p11 = sc->col[k + 1][k + 1];
-    const double g = p01 / p00;
-    const double p11e = fma(-g, p01, p11);           // pivot k+1 after eliminating pivot k
-    // first non-positive (or NaN) pivot wins; everything after it is garbage anyway
-    const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
-    if ((bad0 | bad1) && tid == 0) {
-      const int f0 = bad0 ? 2 * __builtin_ctzll(bad0) : 128, f1 = bad1 ? 2 * __builtin_ctzll(bad1) + 1 : 128;
-      atomicCAS(status, 0, col_base + (f0 < f1 ? f0 : f1) + 1);
-    }
-    sc->rs[k] = 1.0 / sqrt(p00);
-    sc->rs[k + 1] = 1.0 / sqrt(p11e);
-    sc->g[k] = 0.0;
-    sc->g[k + 1] = g;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = 4 * ti + r, col = 4 * tj + c;
-      double lv = 0.0, xv = 0.0;
-      if (col <= row) {
-        lv = sc->col[col][row];
-        if (col & 1) lv = fma(-sc->g[col], sc->col[col - 1][row], lv);
-        lv *= sc->rs[col];
-        xv = sc->row[row][col];
-        if (row & 1) xv = fma(-sc->g[row], sc->row[row - 1][col], xv);
-        xv *= sc->rs[row];
-      }
-      a[r][c] = lv;
-      x[r][c] = xv;
-    }
-}
+#ifdef PK_STAMPS
+__device__ unsigned long long g_pkst[8];
+#define PKS(i) do { if (tid == 0) g_pkst[i] = clock64(); } while (0)
+#else
+#define PKS(i) do { } while (0)
+#endif
 
-// Factors diagonal block 0.  With nsplit > 1 the block is first summed from the split-K slabs of
-// the Gram kernel (single-block systems skip the separate reduction launch).
-// ---------------------------------------------------------------------------------------------
-// 8-wave variant (512 threads): waves 0-3 own the matrix tiles (a), waves 4-7 own the tiles of X.
-// Same block elimination, same LDS lines, same single barrier per pivot pair; each thread issues
-// half the f64 FMAs and half the LDS traffic of the 4-wave version.  role = 0 (a) / 1 (x); `t` holds
-// this thread's 4x4 tile of its matrix on entry (role 1: ignored, X starts as I) and of L resp.
-// L^-1 on exit.
-// ---------------------------------------------------------------------------------------------
-template <int KR, int ROLE>
-__device__ __forceinline__ void potrf64_pair8(double (&t)[4][4], Potrf64Scratch* sc, int ti, int tj, int kb) {
-  const int K = 4 * kb + KR;
-  if (ROLE == 0) {
-    if (tj == kb) {
+template <class LoadA, class StoreX>
+__device__ __forceinline__ void potrf64_pk(LoadA loadA, StoreX storeX, Potrf64Scratch* sc, int tid, int* status, int col_base,
+                                           int npiv) {
+  const int wave = tid >> 6, lane = tid & 63;
+  PKS(0);
+  // role 0: matrix tile, (i1, i2) = (row block, column block); role 1: X tile, transposed, (i1, i2) = (column block, row block)
+  int role = -1, i1 = 0, i2 = -1;          // what this thread carries now (i2 < 0: nothing - it never publishes)
+  int sw = 64, j1 = 0, j2 = -1;            // at kb == sw it becomes the X tile (j1, j2)
+  if (wave == 0) {
+    if (lane < 32) { role = 0; i2 = 8 + (lane >> 3); i1 = 8 + (lane & 7); }
+    else if (lane < 48) { role = 0; i2 = 12 + ((lane - 32) >> 2); i1 = 12 + (lane & 3); }
+    else { role = 1; i1 = 12 + ((lane - 48) >> 2); i2 = 12 + (lane & 3); }
+  } else if (wave == 1) {
+    role = 1; i2 = lane & 15; i1 = lane >> 4;
+  } else if (wave == 2) {
+    if (lane < 48) { role = 0; i2 = 4 + lane / 12; i1 = 4 + lane % 12; }
+    sw = 8;
+    if (lane < 32) { j2 = 8 + (lane & 7); j1 = 8 + (lane >> 3); }
+  } else if (wave == 3) {
+    role = 0; i1 = lane & 15; i2 = lane >> 4;
+    sw = 4;
+    if (lane < 48) { j1 = 4 + lane / 12; j2 = 4 + lane % 12; }
+  }
+  double w[4][4];                          // w[b][a]: element (4 i1 + a, 4 i2 + b) of the tile's matrix (X: of X^T)
+  {
+    // every lane loads (no divergent blocks: run-once code is fetch-bound, and the compiler parks masked blocks far away);
+    // lanes that carry no matrix tile fetch tile (0, 0) and drop it
+    const int li = role == 0 ? i1 : 0, lj = role == 0 ? i2 : 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sc->col[K][4 * ti + r] = t[r][KR];
-        sc->col[K + 1][4 * ti + r] = t[r][KR + 1];
-      }
+    for (int a = 0; a < 4; ++a) {
+      double r4[4];
+      loadA(4 * li + a, 4 * lj, r4);                                    // 4 consecutive columns of one row
+#pragma unroll
+      for (int b = 0; b < 4; ++b) w[b][a] = role == 0 ? r4[b] : ((a == b && i1 == i2) ? 1.0 : 0.0);   // X tiles start as the identity
     }
-  } else {
-    if (ti == kb) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        sc->row[K][4 * tj + c] = t[KR][c];
-        sc->row[K + 1][4 * tj + c] = t[KR + 1][c];
-      }
-    }
   }
-  __syncthreads();
-  const double p00 = sc->col[K][K], p01 = sc->col[K][K + 1], p11 = sc->col[K + 1][K + 1];
-  const double idet = rcp_f64(fma(p00, p11, -p01 * p01));
-  const double q00 = p11 * idet, q01 = -p01 * idet, q11 = p00 * idet;
-  double u[4], v[4], y0[4], y1[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double a0 = sc->col[K][4 * ti + r], a1 = sc->col[K + 1][4 * ti + r];
-    u[r] = fma(a0, q00, a1 * q01);
-    v[r] = fma(a0, q01, a1 * q11);
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    y0[c] = (ROLE == 0) ? sc->col[K][4 * tj + c] : sc->row[K][4 * tj + c];
-    y1[c] = (ROLE == 0) ? sc->col[K + 1][4 * tj + c] : sc->row[K + 1][4 * tj + c];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) t[r][c] = fma(-u[r], y0[c], fma(-v[r], y1[c], t[r][c]));
-}
-
-// All 512 threads call this (tid = 0..511).  role 0 threads pass their tile of the SPD block.
-// `npiv`: the leading npiv rows / columns are the real system, the rest of the block is the identity padding of a
-// system whose size is not a multiple of 64 (K_pad = diag(K, I)): its pivots are 1 and touch nothing, so the
-// elimination stops after ceil(npiv / 4) of the 16 iterations (a 5-concept edit: 2 iterations instead of 16).
-template <int ROLE>
-__device__ __forceinline__ void potrf64_reg8(double (&t)[4][4], Potrf64Scratch* sc, int tid256, int* status,
-                                             int col_base, int npiv = 64) {
-  const int ti = tid256 >> 4, tj = tid256 & 15;
+  __syncthreads();                                                      // loadA may have read what the scratch aliases
+  PKS(1);
   const int nkb = npiv >= 64 ? 16 : ((npiv + 3) >> 2), kstop = 4 * nkb;
-  if (ROLE == 1) {
+  char* lds = (char*)sc;
+  unsigned foff = (role == 1 ? 32768u : 0u) + 16u * (unsigned)i1, soff = 16u * (unsigned)(i2 < 0 ? 0 : i2);
+  {
+    // row lines start as the identity: a tile of X that is not live yet subtracts exact zeros, and a diagonal tile
+    // that joins its wave only at a segment boundary is still pristine when its first pair of rows is due.  (The
+    // pieces the first pair publishes - rows 0, 1, columns 0..15 - are left to it: no barrier in between.)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) t[r][c] = (4 * ti + r == 4 * tj + c) ? 1.0 : 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const int ch = tid + 512 * q, r = ch >> 5, i = ch & 15, j0 = 4 * i + 2 * ((ch >> 4) & 1);   // 16-byte piece: elements j0, j0 + 1 of line r
+      if (!(r < 2 && i < 4)) *(pk_d2*)(lds + 32768 + ch * 16) = (pk_d2){r == j0 ? 1.0 : 0.0, r == j0 + 1 ? 1.0 : 0.0};
+    }
   }
-  if (nkb == 16) {                           // the full block keeps its constant trip count (the compiler pipelines it)
-#pragma unroll 1
-    for (int kb = 0; kb < 16; ++kb) {
-      potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
-      potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
-    }
-  } else {
-#pragma unroll 1
-    for (int kb = 0; kb < nkb; ++kb) {
-      potrf64_pair8<0, ROLE>(t, sc, ti, tj, kb);
-      potrf64_pair8<2, ROLE>(t, sc, ti, tj, kb);
-    }
+  if (i2 == 0) {                                                        // the first pair
+    *(pk_d2*)(lds + foff) = (pk_d2){w[0][0], w[0][1]};
+    *(pk_d2*)(lds + foff + 256) = (pk_d2){w[0][2], w[0][3]};
+    *(pk_d2*)(lds + foff + 512) = (pk_d2){w[1][0], w[1][1]};
+    *(pk_d2*)(lds + foff + 768) = (pk_d2){w[1][2], w[1][3]};
   }
   __syncthreads();
-  if (ROLE == 0 && tid256 < 32) {
-    const int k = 2 * tid256;
-    const bool live = k < kstop;
-    const double p00 = live ? sc->col[k][k] : 1.0, p01 = live ? sc->col[k][k + 1] : 0.0, p11 = live ? sc->col[k + 1][k + 1] : 1.0;
+  PKS(2);
+  // three segments: the tile map changes at kb = 4 (wave 3) and kb = 8 (wave 2)
+#pragma unroll 1
+  for (int seg = 0; seg < 3; ++seg) {
+    const int kb0 = seg == 0 ? 0 : 4 * seg, kb1 = seg == 2 ? 16 : 4 * seg + 4;
+    if (kb0 >= nkb) break;
+    if (kb0 == sw) {
+      i1 = j1; i2 = j2;
+      foff = 32768u + 16u * (unsigned)i1;
+      soff = 16u * (unsigned)(i2 < 0 ? 0 : i2);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) w[b][a] = (a == b && i1 == i2) ? 1.0 : 0.0;
+    }
+    const int kbe = kb1 < nkb ? kb1 : nkb;
+#pragma unroll 1
+    for (int kb = kb0; kb < kbe; ++kb) {
+      if (wave < 4) pk_step<0>(w, lds, foff, soff, i2, kb, kstop);
+      __syncthreads();
+      if (wave < 4) pk_step<2>(w, lds, foff, soff, i2, kb, kstop);
+      __syncthreads();
+    }
+  }
+  PKS(3);
+  // assembly of L^-1 from the row lines, all 512 threads: thread = rows k = 4 A + 2 hq and k + 1 (one pivot pair) x
+  // columns 4 B .. 4 B + 3.  Row k is scaled by 1 / sqrt(p00); row k + 1 first gets the pivot-k elimination it skipped:
+  // (r1 - r0 p01 / p00) / sqrt(p11 - p01^2 / p00).  Every thread derives its pair's scalars itself (16 threads per
+  // pair repeat ~20 instructions: cheaper than a phase + barrier of run-once code, which executes at instruction-
+  // fetch speed, ~1.7 cycles per byte).  storeX(row, col, v[4]) receives 4 consecutive columns of a row.
+  // L itself is not assembled: nothing reads the DIAGONAL blocks of the factor - the blocked factorisation and every
+  // solve work with L_jj^-1 (the off-diagonal blocks L_ij = M_ij L_jj^-T are formed by the tile update).
+  {
+    const int hq = tid >> 8, t256 = tid & 255;
+    const int A = t256 >> 4, B = t256 & 15;
+    const int k = 4 * A + 2 * hq;
+    const bool pad = k >= kstop;                                        // identity padding: never published
+    const char* lb = lds + 32768 + k * 512 + 16 * B;
+    const pk_d2 e0[2] = {*(const pk_d2*)(lb), *(const pk_d2*)(lb + 256)};
+    const pk_d2 o0[2] = {*(const pk_d2*)(lb + 512), *(const pk_d2*)(lb + 768)};
+    const char* pl = lds + k * 512 + (hq ? 256 : 0) + 16 * A;           // pk_pos(k) of column line k
+    const pk_d2 pp = *(const pk_d2*)pl;
+    const double p00 = pad ? 1.0 : pp[0], p01 = pad ? 0.0 : pp[1], p11 = pad ? 1.0 : *(const double*)(pl + 512 + 8);
     const double g = p01 * rcp_f64(p00);
-    const double p11e = fma(-g, p01, p11);
-    const unsigned long long bad0 = __ballot(!(p00 > 0.0)), bad1 = __ballot(!(p11e > 0.0));
-    if ((bad0 | bad1) && tid256 == 0) {
-      const int f0 = bad0 ? 2 * __builtin_ctzll(bad0) : 128, f1 = bad1 ? 2 * __builtin_ctzll(bad1) + 1 : 128;
-      atomicCAS(status, 0, col_base + (f0 < f1 ? f0 : f1) + 1);
-    }
-    sc->rs[k] = rsqrt_f64(p00);          // (a non-positive pivot gives NaN / inf here; it is reported through `status`)
-    sc->rs[k + 1] = rsqrt_f64(p11e);
-    sc->g[k] = 0.0;
-    sc->g[k + 1] = g;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = 4 * ti + r, col = 4 * tj + c;
-      double val = 0.0;
-      if (col <= row) {
-        if (ROLE == 0) {
-          if (col >= kstop) {
-            val = (row == col) ? 1.0 : 0.0;                  // identity padding: never published, L = I there
-          } else {
-            val = sc->col[col][row];
-            if (col & 1) val = fma(-sc->g[col], sc->col[col - 1][row], val);
-            val *= sc->rs[col];
-          }
-        } else {
-          if (row >= kstop) {
-            val = (row == col) ? 1.0 : 0.0;
-          } else {
-            val = sc->row[row][col];
-            if (row & 1) val = fma(-sc->g[row], sc->row[row - 1][col], val);
-            val *= sc->rs[row];
-          }
-        }
+    const double p11e = fma(-g, p01, p11);                              // pivot k + 1 after eliminating pivot k
+    if (B == 0 && (!(p00 > 0.0) || !(p11e > 0.0))) {                    // smallest failing pivot index wins
+      const int want = col_base + k + (!(p00 > 0.0) ? 1 : 2);
+      int cur = *(volatile int*)status;
+      while (cur == 0 || cur > want) {
+        const int prev = atomicCAS(status, cur, want);
+        if (prev == cur) break;
+        cur = prev;
       }
-      t[r][c] = val;
     }
+    const double rs0 = rsqrt_f64(p00), rs1 = rsqrt_f64(p11e);           // (a non-positive pivot gives NaN / inf; reported above)
+    double v0[4], v1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = 4 * B + e;
+      const double x0 = e0[e >> 1][e & 1] * rs0, x1 = fma(-g, e0[e >> 1][e & 1], o0[e >> 1][e & 1]) * rs1;
+      v0[e] = pad ? (k == col ? 1.0 : 0.0) : (col <= k ? x0 : 0.0);
+      v1[e] = pad ? (k + 1 == col ? 1.0 : 0.0) : (col <= k + 1 ? x1 : 0.0);
+    }
+    storeX(k, 4 * B, v0);
+    storeX(k + 1, 4 * B, v1);
+  }
+  PKS(5);
 }
 
-// The 64 x 64 factor the callers use.  (Round 2 also built the rank-4 form with the trailing update on
-// v_mfma_f64_16x16x4_f64 - K = 4 is exactly one MFMA per 16 x 16 tile, 16 steps instead of 32, pivot-block inverse by
-// 2 x 2 blocks, computed either by every wave after the barrier or by its owner wave one step ahead: parity green,
-// 20.5 and 22 us per 64 x 64 block against 17.4 us here (git history: "experiment: MFMA rank-4 form").  A step is
-// bound by its dependent chain - barrier, LDS broadcast, reciprocal(s), ~10 dependent f64 operations - not by the
-// update arithmetic the MFMA removes, and a 4 x 4 inverse is a longer chain than two 2 x 2 ones.)
-#define UCE_POTRF64 potrf64_reg8
+// The 64 x 64 factor the callers use.  History, all measured on MI355X with tools/ubench/potrf.hip (cycles for the full
+// block, 2.4 GHz):  8 waves, every tile at every step, branches per role, L and L^-1 assembled with strided line reads:
+// 43 400;  this form: 27 100 (pair step 1400 -> 800 cycles, run-once code 7 000 -> 3 200).  Also tried and dropped:
+// rank-4 steps with the trailing update on v_mfma_f64_16x16x4_f64 (K = 4 is exactly one MFMA per 16 x 16 tile, 16 steps
+// instead of 32; 49 000 - 53 000: a 4 x 4 pivot-block inverse is a longer dependent chain than two 2 x 2 ones and the
+// update arithmetic the MFMA removes is a fifth of the step), four pivots per barrier on the VALU (48 000), a fully
+// unrolled loop (instruction-fetch bound: 50 KB of run-once code took 75 000 - 90 000).
+#define UCE_POTRF64 potrf64_pk
 
-// (A four-pivots-per-barrier VALU variant was tried and is SLOWER on MI355X - ~20 us vs ~14 us for the 64x64 factor +
-// inverse: the step time is set by the f64 VALU instruction count (f64 FMA issues at half rate on gfx950, ~8
-// cycles per wave instruction), not by the barrier / LDS / reciprocal latencies, and the rank-4 form needs ~170
-// f64 operations per thread per step (4x4 block inverse, W = C Q, update) against ~50 per pair step.  A faster
-// factor has to move the rank-k update onto v_mfma_f64_16x16x4_f64 with the accumulators in D layout.)
-
-// 512-thread version of potrf_first_body (waves 0-3: matrix tiles, waves 4-7: tiles of L^-1)
+// Factors diagonal block 0 (512 threads).  With nsplit > 1 the block is first summed from the split-K slabs of the
+// Gram kernel (single-block systems skip the separate reduction launch).
 static __device__ __forceinline__ void potrf_first_body8(const double* __restrict__ M, int n, int nsplit,
                                                          size_t slab_stride, double* __restrict__ Lmat,
                                                          double* __restrict__ Linv, int* status,
                                                          Potrf64Scratch* sc, int n_valid = 1 << 30) {
   const int npiv0 = n_valid < 64 ? n_valid : 64;
-  const int tid = threadIdx.x, half = tid >> 8, t256 = tid & 255;
-  const int ti = t256 >> 4, tj = t256 & 15;
-  double tt[4][4];
-  if (half == 0) {
+  const int tid = threadIdx.x;
+  UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+    const size_t off = (size_t)row * n + col;
+    pk_d2 a = *(const pk_d2*)(M + off), b = *(const pk_d2*)(M + off + 2);
+    for (int sp = 1; sp < nsplit; ++sp) {                                          // index order
+      a += *(const pk_d2*)(M + (size_t)sp * slab_stride + off);
+      b += *(const pk_d2*)(M + (size_t)sp * slab_stride + off + 2);
+    }
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  }, [&](int row, int col, const double (&v)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const size_t off = (size_t)(4 * ti + r) * n + 4 * tj + c;
-        double v = M[off];
-        for (int sp = 1; sp < nsplit; ++sp) v += M[(size_t)sp * slab_stride + off];   // index order
-        tt[r][c] = v;
-      }
-    UCE_POTRF64<0>(tt, sc, t256, status, 0, npiv0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Lmat[(size_t)(4 * ti + r) * n + 4 * tj + c] = tt[r][c];
-  } else {
-    UCE_POTRF64<1>(tt, sc, t256, status, 0, npiv0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Linv[(4 * ti + r) * 64 + 4 * tj + c] = tt[r][c];
-  }
+    for (int e = 0; e < 4; ++e) Linv[row * 64 + col + e] = v[e];
+  }, sc, tid, status, 0, npiv0);
 }
-
-static __device__ __forceinline__ void potrf_first_body(const double* __restrict__ M, int n, int nsplit,
-                                                        size_t slab_stride, double* __restrict__ Lmat,
-                                                        double* __restrict__ Linv, int* status,
-                                                        Potrf64Scratch* sc) {
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  double a[4][4], x[4][4];
-  typedef double double2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[r][c] = 0.0;
-  // slabs summed in index order (bit-repeatable); 2 slabs = 16 independent 16-byte loads per batch
-  for (int sp = 0; sp < nsplit; sp += 2) {
-    double2_t v[2][4][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int sq = (sp + q < nsplit) ? sp + q : sp;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-          v[q][r][hh] = *(const double2_t*)(M + (size_t)sq * slab_stride + (size_t)(4 * ti + r) * n + 4 * tj + 2 * hh);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (sp + q < nsplit) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            a[r][2 * hh] += v[q][r][hh][0];
-            a[r][2 * hh + 1] += v[q][r][hh][1];
-          }
-      }
-    }
-  }
-  potrf64_reg(a, x, sc, tid, status, 0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      Lmat[(size_t)(4 * ti + r) * n + 4 * tj + c] = a[r][c];
-      Linv[(4 * ti + r) * 64 + 4 * tj + c] = x[r][c];
-    }
-}
-
 
 
 // ---------------------------------------------------------------------------------------------
@@ -473,32 +391,18 @@ static __device__ __forceinline__ void potrf_step_tile(double* __restrict__ M, i
   if (half == 0)
     quad_foreach(wr, wc, lane, [&](int m, int nn, int r, int row, int col) { Li[row][col] = acc[m][nn][r]; });
   __syncthreads();
-  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;    // all three tile regions are dead once tt is in registers
-  const int t256 = tid & 255;
-  const int ti = t256 >> 4, tj = t256 & 15;
-  double tt[4][4];
-  if (half == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) tt[r][c] = Li[4 * ti + r][4 * tj + c];
-  }
-  __syncthreads();                                   // Li fully read before the scratch (which overlaps nothing of Li) is used
+  Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;    // aliases the tile regions: the factor fetches Li, then a barrier, then the scratch
   const int npiv = (n_valid - i * 64) < 64 ? (n_valid - i * 64) : 64;
-  if (half == 0) {
-    UCE_POTRF64<0>(tt, sc, t256, status, i * 64, npiv);
+  double* Linv_n = Linv + (size_t)i * 64 * 64;
+  UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+                const pk_d2 a = *(const pk_d2*)&Li[row][col], b = *(const pk_d2*)&Li[row][col + 2];
+                v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+              },
+              [&](int row, int col, const double (&v)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Lmat[(size_t)(i * 64 + 4 * ti + r) * n + i * 64 + 4 * tj + c] = tt[r][c];
-  } else {
-    UCE_POTRF64<1>(tt, sc, t256, status, i * 64, npiv);
-    double* Linv_n = Linv + (size_t)i * 64 * 64;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Linv_n[(4 * ti + r) * 64 + 4 * tj + c] = tt[r][c];
-  }
+                for (int e = 0; e < 4; ++e) Linv_n[row * 64 + col + e] = v[e];
+              },
+              sc, tid, status, i * 64, npiv);
 }
 
 }  // namespace
