@@ -205,38 +205,47 @@ __device__ __forceinline__ void announce_factor(const GramPotrfJob& j, bool fenc
 }
 
 // ---------------------------------------------------------------------------------------------
-// Solve riders (blocks after the Gram riders, one per 64 columns of R): wait for the factorisation of THIS launch,
+// Solve riders (blocks after the Gram riders, one per SV_COLS = 32 columns of R): wait for the factorisation of THIS launch,
 // then  R[:, cols] = rows 0..N_edit-1 of  L^-T L^-1 C[:, cols]  with the inverted diagonal blocks - the triangular
-// solves that used to be a launch of their own between the projection and the update.  64 x 64 f64 tiles in LDS
-// (stride SV_LD), 8 waves x two 16 x 16 MFMA tiles, full contraction per wave (no partial sums to combine).
+// solves that used to be a launch of their own between the projection and the update.  f64 tiles in LDS (stride SV_LD),
+// 8 waves x one 16 x 16 MFMA tile, contraction over the non-zero part of the triangular operand (sv_prod).
 // ---------------------------------------------------------------------------------------------
 constexpr int SV_LD = 66;
+constexpr int SV_COLS = 32;     // columns of R per solve rider: 8 waves x one 16 x 16 tile, twice as many riders as 64 would give
 constexpr size_t SV_TILE = (size_t)64 * SV_LD * sizeof(double);
 __host__ __device__ constexpr size_t sv_smem(int nb) { return (nb <= 1 ? 3 : 4) * SV_TILE; }
 
-// dst = base - / + op(A) * B :  A, B, dst (, base) are LDS tiles [64][SV_LD]; TA: op(A)[i][k] = A[k][i].
-// B is read as [k][col].  base == nullptr: dst = op(A) B.  (dst may alias base, never A or B.)
-template <bool TA>
+// dst = base - / + op(A) * B :  A [64][64], B / dst / base [64][SV_COLS] are LDS tiles of stride SV_LD; TA: op(A)[i][k] =
+// A[k][i].  B is read as [k][col].  base == nullptr: dst = op(A) B.  (dst may alias base, never A or B.)
+// TRI: A is LOWER triangular (an inverted diagonal block) - the 16-row block rb of op(A) B only contracts over
+// k < 16 (rb + 1) (TA: k >= 16 rb).  One 16 x 16 tile per wave; the waves of a SIMD (w, w + 4) take row blocks rb and
+// 3 - rb, so every SIMD issues 20 of the 32 MFMAs a full contraction would.  (A 64 x 64 x 64 f64 product is MFMA-bound
+// at 2048 cycles on one CU: the riders are sized so that this chain link is ~600 cycles instead.)
+template <bool TA, bool TRI>
 __device__ __forceinline__ void sv_prod(double* dst, const double* A, const double* B, const double* base, double sign) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
-  const int row0 = 16 * (w & 3), col0 = 32 * (w >> 2);
-  double4_t acc[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
-#pragma unroll 4
+  const int rb = w < 4 ? w : 7 - w;
+  const int row0 = 16 * rb, col0 = 16 * (w >> 2);
+  const int kb0 = (TRI && TA) ? 4 * rb : 0, kb1 = (TRI && !TA) ? 4 * rb + 4 : 16;
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // all fragments first (one exposed LDS latency), then the dependent MFMA chain over the live k-steps
+  double fa[16], fb[16];
+#pragma unroll
   for (int kb = 0; kb < 16; ++kb) {
     const int t = 4 * kb + kk;
-    const double a = TA ? A[t * SV_LD + row0 + r] : A[(row0 + r) * SV_LD + t];
-    acc[0] = mfma_f64(a, B[t * SV_LD + col0 + r], acc[0]);
-    acc[1] = mfma_f64(a, B[t * SV_LD + col0 + 16 + r], acc[1]);
+    fa[kb] = TA ? A[t * SV_LD + row0 + r] : A[(row0 + r) * SV_LD + t];
+    fb[kb] = B[t * SV_LD + col0 + r];
   }
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+    if (kb >= kb0 && kb < kb1) acc = mfma_f64(fa[kb], fb[kb], acc);
   // D layout: row = kk + 4q, col = r
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int o = (row0 + kk + 4 * q) * SV_LD + col0 + 16 * n + r;
-      dst[o] = (base ? base[o] : 0.0) + sign * acc[n][q];
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int o = (row0 + kk + 4 * q) * SV_LD + col0 + r;
+    dst[o] = (base ? base[o] : 0.0) + sign * acc[q];
+  }
 }
 
 template <int D>
@@ -250,11 +259,11 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
   // 64 concepts x this block's 64 columns of C (rows >= N are zero) -> LDS, widened to f64.  Needs nothing from the
   // factorisation: loaded before the wait.
   auto load_c = [&](double* Wt, int kblk) {
-    for (int e = tid; e < 64 * 16; e += 512) {
-      const int r = e >> 4, c4 = (e & 15) << 2;
+    for (int e = tid; e < 64 * (SV_COLS / 4); e += 512) {
+      const int r = e / (SV_COLS / 4), c4 = (e % (SV_COLS / 4)) << 2;
       const int row = kblk * 64 + r;
       float4_t v = {0.f, 0.f, 0.f, 0.f};
-      if (row < j.N) v = *(const float4_t*)(j.C + (size_t)row * D + colblk * 64 + c4);
+      if (row < j.N) v = *(const float4_t*)(j.C + (size_t)row * D + colblk * SV_COLS + c4);
       Wt[r * SV_LD + c4] = (double)v[0];
       Wt[r * SV_LD + c4 + 1] = (double)v[1];
       Wt[r * SV_LD + c4 + 2] = (double)v[2];
@@ -285,11 +294,11 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
     }
   };
   auto store_r = [&](const double* Wt, int kblk) {        // rows of X -> R (fp32), rows < N_edit only
-    for (int e = tid; e < 64 * 16; e += 512) {
-      const int r = e >> 4, c4 = (e & 15) << 2;
+    for (int e = tid; e < 64 * (SV_COLS / 4); e += 512) {
+      const int r = e / (SV_COLS / 4), c4 = (e % (SV_COLS / 4)) << 2;
       const int row = kblk * 64 + r;
       if (row < j.N_edit)
-        *(float4_t*)(j.R + (size_t)row * D + colblk * 64 + c4) =
+        *(float4_t*)(j.R + (size_t)row * D + colblk * SV_COLS + c4) =
             (float4_t){(float)Wt[r * SV_LD + c4], (float)Wt[r * SV_LD + c4 + 1], (float)Wt[r * SV_LD + c4 + 2],
                        (float)Wt[r * SV_LD + c4 + 3]};
     }
@@ -316,9 +325,9 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
     load_m(Linv0, 64);
     __syncthreads();
     DBG(3);
-    sv_prod<false>(W1, Ms, W0, nullptr, 1.0);             // Y = L^-1 C
+    sv_prod<false, true>(W1, Ms, W0, nullptr, 1.0);       // Y = L^-1 C
     __syncthreads();
-    sv_prod<true>(W0, Ms, W1, nullptr, 1.0);              // X = L^-T Y
+    sv_prod<true, true>(W0, Ms, W1, nullptr, 1.0);        // X = L^-T Y
     __syncthreads();
     DBG(4);
     store_r(W0, 0);
@@ -329,27 +338,27 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
   const double* L10 = j.Lmat + (size_t)64 * n;            // block (1, 0) of L
   load_m(Linv0, 64);
   __syncthreads();
-  sv_prod<false>(W1, Ms, W0, nullptr, 1.0);               // Y0 = L00^-1 C0
+  sv_prod<false, true>(W1, Ms, W0, nullptr, 1.0);         // Y0 = L00^-1 C0
   __syncthreads();
   load_c(W0, 1);
   load_m(L10, n);
   __syncthreads();
-  sv_prod<false>(W0, Ms, W1, W0, -1.0);                   // C1 - L10 Y0
+  sv_prod<false, false>(W0, Ms, W1, W0, -1.0);            // C1 - L10 Y0
   __syncthreads();
   load_m(Linv1, 64);
   __syncthreads();
-  sv_prod<false>(W2, Ms, W0, nullptr, 1.0);               // Y1
+  sv_prod<false, true>(W2, Ms, W0, nullptr, 1.0);         // Y1
   __syncthreads();
-  sv_prod<true>(W0, Ms, W2, nullptr, 1.0);                // X1 = L11^-T Y1
+  sv_prod<true, true>(W0, Ms, W2, nullptr, 1.0);          // X1 = L11^-T Y1
   __syncthreads();
   store_r(W0, 1);
   load_m(L10, n);
   __syncthreads();
-  sv_prod<true>(W1, Ms, W0, W1, -1.0);                    // Y0 - L10^T X1
+  sv_prod<true, false>(W1, Ms, W0, W1, -1.0);             // Y0 - L10^T X1
   __syncthreads();
   load_m(Linv0, 64);
   __syncthreads();
-  sv_prod<true>(W2, Ms, W1, nullptr, 1.0);                // X0
+  sv_prod<true, true>(W2, Ms, W1, nullptr, 1.0);          // X0
   __syncthreads();
   store_r(W2, 0);
 }
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ T, long rows, int Ne, int NEP, GramPotrfJob job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_gram = job.C ? gp_riders(job.nb) : 0;
-  const int n_solve = (job.C && job.R) ? D / 64 : 0;
+  const int n_solve = (job.C && job.R) ? D / SV_COLS : 0;
   const int has_rider = n_gram + n_solve;
   if ((int)blockIdx.x < n_gram) {
     gram_potrf_rider<D>(job, smem_raw);
@@ -809,7 +818,7 @@ int launch_project(const float* W_old, const float* Dm, const float* Csub, float
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
   }
-  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) + (job.R ? D / 64 : 0) : 0);
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) + (job.R ? D / SV_COLS : 0) : 0);
   hipLaunchKernelGGL((k_lr_project<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
                      N_edit, NEP64, job);
   UCE_LAUNCH_CHECK();
