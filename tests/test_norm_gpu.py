@@ -174,6 +174,23 @@ def test_conv3x3_implicit_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bia
     assert O.rel_fro(y.float().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
 
 
+def test_narrow_output_conv_goes_through_the_padded_implicit_gemm():
+    """The VAE's conv_out (128 -> 3 channels at image resolution): sd.unet.conv2d pads the weight to 8 output channels,
+    runs uce_conv3x3_nhwc_fwd and slices - against F.conv2d in fp32; an in-place weight update rebuilds the padded copy."""
+    from uce_amd.sd import unet as U
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 128, 256, 256, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(128, 3, 3, padding=1).to("cuda", torch.bfloat16).to(memory_format=torch.channels_last)
+    assert U._conv3x3_narrow_ok(conv, x)
+    with torch.no_grad():
+        for _ in range(2):
+            ref = F.conv2d(x.float(), conv.weight.float(), conv.bias.float(), padding=1)
+            y = U.conv2d(conv, x)
+            assert y.shape == ref.shape and O.rel_fro(y.float().cpu(), ref.cpu()) < 6e-3
+            conv.weight.mul_(-0.5)                                  # the cached padded weight must follow
+            conv.bias.add_(1.0)
+
+
 @pytest.mark.parametrize("N,C,Hh,Ww", [(2, 64, 5, 7), (3, 320, 16, 16), (1, 1288, 4, 3), (2, 2560, 3, 5), (1, 8, 1, 1)])
 def test_im2col_patch_matrix_is_bit_exact(H, N, C, Hh, Ww):
     """Both patch-matrix kernels (row kernel for C <= 1280, flat kernel above) against nine shifted slices of the

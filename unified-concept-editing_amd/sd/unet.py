@@ -158,6 +158,31 @@ def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
             and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
 
 
+def _conv3x3_narrow_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    return (USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels < 8
+            and conv.in_channels % 64 == 0 and conv.weight.dtype == x.dtype
+            and x.shape[0] * x.shape[2] * x.shape[3] >= 128 * 1024)
+
+
+def _padded_out_channels(conv: nn.Conv2d):
+    """(weight, bias) of `conv` zero-padded to 8 output channels, channels-last, cached on the module (keyed by the
+    parameter versions, so an in-place weight update rebuilds it)."""
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else conv.bias._version)
+    cached = getattr(conv, "_uce_pad8", None)
+    if cached is None or cached[0] != key:
+        co = conv.out_channels
+        w8 = torch.zeros((8,) + tuple(conv.weight.shape[1:]), dtype=conv.weight.dtype, device=conv.weight.device)
+        w8[:co] = conv.weight.detach()
+        w8 = w8.contiguous(memory_format=torch.channels_last)
+        b8 = torch.zeros(8, dtype=conv.weight.dtype, device=conv.weight.device)
+        if conv.bias is not None:
+            b8[:co] = conv.bias.detach()
+        cached = (key, w8, b8)
+        conv._uce_pad8 = cached
+    return cached[1], cached[2]
+
+
 def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Tensor:
     """`conv(x)`.  3x3 / stride 1 / pad 1 convolutions of channels-last 16-bit activations on a GPU go through
     uce_im2col3x3_nhwc + one library GEMM (1.7-2.3x MIOpen's implicit GEMM on an MI355X); everything else is MIOpen."""
@@ -165,6 +190,14 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Te
     if _conv3x3_fast_ok(conv, x):
         from .. import edit as _edit
         return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias)
+    if _conv3x3_narrow_ok(conv, x):
+        # a 3- / 4-channel output (the VAE's conv_out): the implicit-GEMM kernel on the weight zero-padded to 8 output
+        # channels (its 16-byte store granule), result sliced back - 0.9 ms against 2.6 ms for the library's direct kernel
+        # at 16 x 512 x 512 x 128
+        from .. import edit as _edit
+        w8, b8 = _padded_out_channels(conv)
+        y8 = _edit.UceHandle.get(x.device).conv3x3_igemm(x, w8, b8 if with_bias else None)
+        return y8[:, :conv.out_channels]
     if USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) \
             and conv.padding == (0, 0) and conv.groups == 1 and conv.weight.dtype == x.dtype:
         # a 1x1 convolution of a channels-last tensor IS a GEMM over the pixel rows: hand it to the GEMM library
