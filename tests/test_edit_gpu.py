@@ -345,6 +345,41 @@ def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
         assert O.rel_fro(out.cpu(), (W64 + W64 @ Delta).cpu()) < EPS_BUILD
 
 
+@pytest.mark.parametrize("N_e,N_p", [(1, 0), (2, 1), (4, 0), (3, 5), (16, 0), (10, 7), (20, 0), (31, 0), (32, 0), (20, 13),
+                                     (47, 0), (48, 0), (40, 9), (63, 0), (64, 0), (66, 0), (96, 0), (127, 0)])
+def test_edit_every_segment_of_the_64x64_block(H, N_e, N_p):
+    """The in-launch Cholesky inverse runs ceil(N / 4) of its 16 elimination iterations in up to three segments (its
+    tile map changes at iteration 4 and 8, identity padding beyond N): every boundary of that schedule, for one- and
+    two-block systems, against torch fp64; run twice (ticket / sequence words re-used)."""
+    N, d, rows_ = N_e + N_p, 768, 1536
+    Call = O.clip_like_embeddings(N + 1, d, seed=3 * N + 1)
+    C, G = Call[:N], np.repeat(Call[N:N + 1], N_e, axis=0)
+    s = (0.5 + np.random.Generator(np.random.PCG64(N)).random(N)).astype(np.float32)
+    Cd, Gd, sd = _dev(C), _dev(G), _dev(s)
+    Wd = _dev(O.linear_default_weight(rows_, d, np.random.Generator(np.random.PCG64(N + 9))))
+    C64, W64, s64 = Cd.double(), Wd.double(), sd.double()
+    A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda:0") + C64.T @ (s64[:, None] * C64)
+    Delta = torch.linalg.solve(A, (s64[:N_e, None] * C64[:N_e]).T @ (Gd - Cd[:N_e]).double()).T
+    want = (W64 + W64 @ Delta).cpu()
+    for _ in range(2):
+        assert O.rel_fro(H.edit(Cd, Gd, sd, 0.5, Wd, check=True).cpu(), want) < EPS_BUILD
+
+
+@pytest.mark.parametrize("N,bad", [(50, 0), (50, 33), (64, 63), (9, 8)])
+def test_single_block_rider_reports_indefinite_system(H, N, bad):
+    """A non-positive scale in a system of one 64-block: the factorising rider block reports the pivot through uce_status."""
+    d = 768
+    Call = O.clip_like_embeddings(N + 1, d, seed=11)
+    C, G = Call[:N], np.repeat(Call[N:N + 1], N, axis=0)
+    s = np.ones(N, dtype=np.float32)
+    s[bad] = -1.0
+    W = _dev(O.linear_default_weight(2048, d, np.random.Generator(np.random.PCG64(2))))
+    with pytest.raises(L.UceError):
+        H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, check=True)
+    s[bad] = 1.0
+    assert torch.isfinite(H.edit(_dev(C), _dev(G), _dev(s), 0.5, W, check=True)).all()
+
+
 def test_rider_path_reports_indefinite_system(H):
     """A non-positive scale in the SECOND 64-block of a 100-concept dual system: the rider blocks' in-launch
     factorisation must flag it through uce_status (the reference would return an LU garbage inverse)."""
