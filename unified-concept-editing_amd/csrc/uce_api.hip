@@ -320,8 +320,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   const int n_pad = round_up(N, 64);
   rc = uce_ensure(h, d, n_pad);
   if (rc) return rc;
-  static const int no_split = getenv("UCE_NO_SPLIT") ? atoi(getenv("UCE_NO_SPLIT")) : 0;
-  if (!no_split && N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
+  if (N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
     // N <= 128: THREE launches on the caller's stream, no events (forking the Gram -> Cholesky -> solve chain onto a
     // side stream beside a rider-less projection was measured at 105 us against 70: the two cross-stream event
     // waits cost more than the overlap buys):

@@ -206,8 +206,7 @@ __global__ void k_cast_bf16(const float* __restrict__ src, unsigned short* __res
 }  // namespace
 
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st) {
-  static const int one_per_cu = getenv("UCE_APPLY_1WG") ? atoi(getenv("UCE_APPLY_1WG")) : 0;
-  const size_t smem = one_per_cu ? (size_t)100 * 1024 : (size_t)2 * (BM + BN) * TLD * sizeof(float);
+  const size_t smem = (size_t)2 * (BM + BN) * TLD * sizeof(float);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
   if (attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -250,9 +250,6 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
   // 128 x 128 tiles (a ragged last output-channel tile is masked: Cout = 320 runs 3 tiles, 572 TF/s against 389 for the
   // 256 x 64 form); 256 x 64 only where a 128-wide tile would be at least half empty (Cout <= 64)
   const int rem = Cout % 128;
-  static const int force = getenv("UCE_CONV_TILE") ? atoi(getenv("UCE_CONV_TILE")) : 0;      // 22 / 41: A/B measurements
-  if (force == 22) return launch_igemm<2, 2>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);
-  if (force == 41) return launch_igemm<4, 1>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);
   if (Cout <= 64 && rem != 0) return launch_igemm<4, 1>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);
   return launch_igemm<2, 2>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);
 }

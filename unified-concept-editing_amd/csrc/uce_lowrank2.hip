@@ -877,15 +877,8 @@ int launch_update_s(const float* W_old, const float* T, const float* R, float* W
 template <int D>
 int launch_update_d(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
                     int NEP64, hipStream_t st) {
-  static const int variant = getenv("UCE_UPDATE_VARIANT") ? atoi(getenv("UCE_UPDATE_VARIANT")) : 20;
-  if (N_edit <= 128) {
-    switch (variant) {
-      case 20:   // default (measured best at N_edit 16..128 on MI355X, tools/sweep_update.sh)
-        return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      case 21: return launch_update_s<D, 2, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-      default: break;
-    }
-  }
+  // 16-row tiles, 2 waves per SIMD: measured best at N_edit 16..128 on MI355X (32-row tiles: +4-9 %)
+  if (N_edit <= 128) return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
   return launch_update_v<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);   // 129 <= N_edit <= 256: ring-buffered form
 }
 
