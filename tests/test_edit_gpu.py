@@ -396,6 +396,20 @@ def test_rider_path_reports_indefinite_system(H):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("N,d", [(20, 64), (100, 64), (300, 128)])
+def test_flux_bias_direction_both_forms(H, N, d):
+    """u = A^-1 sum_i s_i c_i of the biased-Linear variant: dual form (N < d) and primal form (N >= d, through
+    uce_gram + uce_solve_delta) against torch fp64."""
+    from uce_amd import flux
+    C = _dev(O.clip_like_embeddings(N, d, seed=N + d))
+    s = _dev((0.5 + np.random.Generator(np.random.PCG64(N)).random(N)).astype(np.float32))
+    u = flux.bias_direction(H, C, s, 0.5)
+    C64, s64 = C.double(), s.double()
+    A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda:0") + C64.T @ (s64[:, None] * C64)
+    want = torch.linalg.solve(A, (C64 * s64[:, None]).sum(dim=0))
+    assert u.dtype == torch.float32 and O.rel_fro(u.cpu(), want.cpu()) < 1e-5
+
+
 def test_flux_variant_matches_reference_golden(H, tmp_path):
     """uce_amd.flux.UCE (biased Linear modules, T5 / pooled-CLIP embedding families) on the fakes
     the golden was generated with, against the reference's uce_flux_edit.py output."""
