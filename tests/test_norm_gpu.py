@@ -158,6 +158,13 @@ def test_conv3x3_im2col_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias)
     (1, 512, 256, 32, 32, torch.bfloat16, True, False),      # VAE-like
     (2, 640, 640, 16, 16, torch.bfloat16, True, True),       # fused 2x nearest upsample (Upsample2D)
     (3, 64, 72, 6, 10, torch.float16, False, True),
+    # >= 16 384 pixels and 256 / 320-multiple outputs: the direct-to-LDS 256-pixel form (uce_conv_dma.hip)
+    (2, 320, 320, 96, 96, torch.bfloat16, True, False),      # 256 x 320 tiles
+    (3, 64, 640, 75, 75, torch.bfloat16, True, False),       # ragged last pixel tile, tiles straddling images, two channel tiles
+    (1, 192, 256, 128, 128, torch.float16, True, False),     # 256 x 256 tiles, f16, 6 k-tiles per tap
+    (2, 128, 512, 96, 96, torch.bfloat16, False, False),
+    (2, 128, 320, 128, 128, torch.bfloat16, True, True),     # fused upsample through the DMA gather
+    (1, 64, 256, 130, 126, torch.bfloat16, True, False),     # two k-tiles per tap: the ring spans taps
 ])
 def test_conv3x3_implicit_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias, up):
     """uce_conv3x3_nhwc_fwd (one launch, taps gathered into LDS, no patch matrix) against F.conv2d evaluated in fp32;

@@ -79,6 +79,9 @@ struct UceProfScope {
 
 // ---- internal launchers (defined across the .hip files) -------------------------------------
 int uce_ensure(uce_ctx* h, int d, int n);
+// uce_conv_dma.hip: 1 = launched (*rc = status), 0 = shape not taken by the direct-to-LDS form
+int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
+                    int dtype, hipStream_t st, int* rc);
 
 int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
                        int d, float lamb, double* A, double* Bt, hipStream_t st);

@@ -1,0 +1,248 @@
+// Implicit-GEMM 3x3 / stride 1 / pad 1 convolution, direct-to-LDS form (the second implementation behind
+// uce_conv3x3_nhwc_fwd; same contract as uce_conv_igemm.hip, which remains the kernel for narrow outputs):
+//
+//   * workgroup = 256 pixels x BN output channels, 8 waves, f32 accumulators in registers:
+//       BN = 256: waves 2 (pixels) x 4 (channels), wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16 tiles
+//       BN = 320: waves 4 x 2, wave tile 64 x 160 = 2 x 5 tiles  (the U-Net's 320 / 640 / 960 / 1280 / 1920-channel layers
+//                 tile exactly; with 256-wide tiles a 320-channel layer would waste 37 % of its MFMAs)
+//     6 - 7 fragment reads per 8 - 10 MFMAs (the 128 x 128 kernel: 1 per MFMA);
+//   * k-tile = one tap x 32 input channels = one 64-byte segment of a (shifted) source pixel per output pixel, moved by
+//     `buffer_load_dwordx4 ... lds` STRAIGHT into LDS (16 rows x 64 B per wave instruction): no staging registers, no
+//     ds_write pass; a tap outside the image, a pixel >= M or a weight row >= Cout gets an out-of-range buffer offset
+//     and lands as zeros;
+//   * the LDS image of such an instruction is lane-linear, so the bank swizzle is applied to the SOURCE: the 16-byte
+//     piece p of row R holds source piece p ^ ((R >> 2) & 3) - the 16 rows a b128 fragment read touches for one piece
+//     index fall on 16 distinct bank slots; the fragment reads apply the same XOR;
+//   * a ring of FOUR LDS stages with three k-tiles in flight: the loads of tile t + 3 are issued when tile t starts
+//     computing and are waited for - counted s_waitcnt vmcnt, never 0 - only at the end of tile t + 1, behind RAW
+//     s_barriers (a __syncthreads would make the compiler drain the DMA queue).  Every wave waits for its OWN loads of
+//     tile t + 1 and then passes the barrier, so after the barrier the whole tile is in LDS (the wait comes one barrier
+//     before the first read); a stage is re-filled only after the barrier that follows its last read.
+// Measured against the register-staged 128 x 128 kernel in tools/probe_igemm.py; DESIGN.md section 4.
+#include "uce_common.h"
+
+namespace {
+
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int CD_BM = 256, CD_BK = 32, CD_NST = 4;
+
+template <bool F16>
+__device__ __forceinline__ float16_t cd_mfma(uint4_t a, uint4_t b, float16_t c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned cd_pack2(float lo, float hi) {
+  const float2_t v = {lo, hi};
+  if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <bool F16>
+__device__ __forceinline__ float cd_tof(unsigned short v) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+
+template <int BN>
+constexpr size_t cd_smem() { return (size_t)CD_NST * (CD_BM + BN) * CD_BK * 2; }
+
+// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 4 or 5)
+__device__ __forceinline__ void cd_wait_two_tiles(int per) {
+  if (per == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+}
+
+template <int WGM, int WGN, int TM, int TN, bool F16>
+__global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
+                                                     const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
+                                                     long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles) {
+  static_assert(WGM * WGN == 8 && 32 * TM * WGM == CD_BM, "eight waves, 256 pixels");
+  constexpr int BN = 32 * TN * WGN;
+  constexpr int STAGE = (CD_BM + BN) * CD_BK * 2;
+  constexpr int NB = BN / 16;                                         // wave instructions per B image (16 or 20)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w % WGM, wn = w / WGM;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // tile of this block: the output-channel tiles of one pixel tile are consecutive on one XCD (they share the pixels)
+  long tile = blockIdx.x;
+  {
+    const long T = (long)mtiles * ntiles;
+    if ((T & 7) == 0) tile = (long)(blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+  }
+  const long m0 = (tile / ntiles) * CD_BM;
+  const int n0 = (int)(tile % ntiles) * BN;
+  const int Hs = H >> up, Ws = W >> up;
+  const int cch = Cin / CD_BK, NK = 9 * cch;
+  const long K = 9L * Cin;
+
+  // ---- staging coordinates (k-tile invariant).  A wave instruction fills 16 rows x 64 B; lane = (row r, piece p).
+  const int r = lane >> 2, p = lane & 3;
+  constexpr unsigned OOB = 0x80000000u;
+  int a_y[2], a_x[2];
+  unsigned a_base[2];                                                  // byte offset of (image, channel piece); OOB: no pixel
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int R = 16 * (8 * j + w) + r;
+    const int c = p ^ ((R >> 2) & 3);
+    const long m = m0 + R;
+    if (m < M) {
+      const long img = m / ((long)H * W);
+      const int rem = (int)(m - img * (long)H * W);
+      a_y[j] = rem / W;
+      a_x[j] = rem - a_y[j] * W;
+      a_base[j] = (unsigned)((img * (long)Hs * Ws * Cin + c * 8) * 2);
+    } else {
+      a_y[j] = -4;                                                     // every tap lands outside the image
+      a_x[j] = -4;
+      a_base[j] = 0;
+    }
+  }
+  unsigned b_base[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int g = 8 * j + w;
+    const int R = 16 * g + r;
+    const int c = p ^ ((R >> 2) & 3);
+    b_base[j] = (g < NB && n0 + R < Cout) ? (unsigned)(((long)(n0 + R) * K + c * 8) * 2) : OOB;
+  }
+  const int per = 2 + ((w < NB - 16) ? 3 : 2);                         // this wave's DMAs per k-tile
+  const long x_bytes = (M / ((long)H * W)) * (long)Hs * Ws * Cin * 2;
+  const long w_bytes = (long)Cout * K * 2;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)w_bytes, 0x00020000);
+
+  auto stage = [&](int st, int kt) {
+    const int tap = kt / cch, c0 = (kt - tap * cch) * CD_BK;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    unsigned char* sbase = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+      const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const unsigned off = a_base[j] + (unsigned)((((yy >> up) * Ws + (xx >> up)) * Cin + c0) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16, ok ? off : OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (8 * j + w < NB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + CD_BM * 64 + (8 * j + w) * 1024), 16,
+                                                 b_base[j] == OOB ? OOB : b_base[j] + (unsigned)(kt * CD_BK * 2), 0, 0, 0);
+    }
+  };
+
+  float16_t acc[TN][TM];                                               // [channel tile][pixel tile]
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  int arow[TM], brow[TN];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) arow[b] = (wm * TM + b) * 32 + li;
+#pragma unroll
+  for (int a = 0; a < TN; ++a) brow[a] = (wn * TN + a) * 32 + li;
+
+  const int last = NK - 1;                                             // (past the last tile the ring re-loads it: constant counts)
+  stage(0, 0);
+  stage(1, 1 < last ? 1 : last);
+  stage(2, 2 < last ? 2 : last);
+  cd_wait_two_tiles(per);
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < NK; ++kt) {
+    stage((kt + 3) & 3, kt + 3 < last ? kt + 3 : last);
+    const unsigned char* Ab = smem + (kt & 3) * STAGE;
+    const unsigned char* Bb = Ab + CD_BM * 64;
+#pragma unroll
+    for (int s = 0; s < CD_BK / 16; ++s) {
+      const int c = 2 * s + lh;
+      uint4_t pf[TM], cf[TN];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * 64 + ((c ^ ((arow[b] >> 2) & 3)) << 4));
+#pragma unroll
+      for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * 64 + ((c ^ ((brow[a] >> 2) & 3)) << 4));
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = cd_mfma<F16>(cf[a], pf[b], acc[a][b]);   // rows = channels, columns = pixels
+    }
+    cd_wait_two_tiles(per);                                            // this wave's part of tile kt + 1 has landed
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
+
+  // ---- epilogue: + bias, convert, 8-byte stores (a lane holds 4 consecutive output channels of one pixel)
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + (wn * TN + a) * 32 + 8 * g + 4 * lh;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias && n < Cout) {
+        const uint2_t b2 = *(const uint2_t*)(bias + n);
+        bv[0] = cd_tof<F16>((unsigned short)(b2[0] & 0xffffu));
+        bv[1] = cd_tof<F16>((unsigned short)(b2[0] >> 16));
+        bv[2] = cd_tof<F16>((unsigned short)(b2[1] & 0xffffu));
+        bv[3] = cd_tof<F16>((unsigned short)(b2[1] >> 16));
+      }
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const long m = m0 + (wm * TM + b) * 32 + li;
+        if (m < M && n < Cout) {
+          const uint2_t o = {cd_pack2<F16>(acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1]),
+                             cd_pack2<F16>(acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3])};
+          *(uint2_t*)(Y + m * Cout + n) = o;
+        }
+      }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
+               hipStream_t st) {
+  constexpr int BN = 32 * TN * WGN;
+  const long mtiles = (M + CD_BM - 1) / CD_BM;
+  const int ntiles = (Cout + BN - 1) / BN;
+  const long nwg = mtiles * ntiles;
+  if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
+  const size_t smem = cd_smem<BN>();
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+                       (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
+                       (int)mtiles, ntiles);
+  else
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+                       (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
+                       (int)mtiles, ntiles);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+}  // namespace
+
+// 0: this form does not take the shape (the caller falls back to the 128 x 128 kernel); 1: launched; < 0: error
+int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
+                    int dtype, hipStream_t st, int* rc) {
+  *rc = UCE_OK;
+  if (Cin % CD_BK || Cout % 4) return 0;
+  if (Cout % 320 == 0) { *rc = launch_dma<4, 2, 2, 5>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
+  if (Cout % 256 == 0) { *rc = launch_dma<2, 4, 4, 2>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
+  return 0;
+}

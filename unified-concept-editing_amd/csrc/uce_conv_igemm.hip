@@ -249,6 +249,14 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
   hipStream_t st = (hipStream_t)stream;
   // 128 x 128 tiles (a ragged last output-channel tile is masked: Cout = 320 runs 3 tiles, 572 TF/s against 389 for the
   // 256 x 64 form); 256 x 64 only where a 128-wide tile would be at least half empty (Cout <= 64)
+  {
+    // wide outputs (multiples of 256 / 320 channels) with enough pixel tiles: the direct-to-LDS 256-pixel form
+    const char* e = getenv("UCE_CONV_DMA");                  // 0: always the 128 x 128 kernel (A/B measurements); read per call
+    int rc;
+    if (!(e && atoi(e) == 0) && M >= 256 * 64 &&          // (fewer than 64 pixel tiles leave most of the 256 CUs idle)
+        launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc))
+      return rc;
+  }
   const int rem = Cout % 128;
   if (Cout <= 64 && rem != 0) return launch_igemm<4, 1>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);
   return launch_igemm<2, 2>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);

@@ -52,9 +52,9 @@ CONV_IGEMM = os.environ.get("UCE_CONV_IGEMM", "auto")
 
 
 def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32) -> bool:
-    """Measured on an MI355X (tools/probe_igemm.py, bf16): the implicit-GEMM kernel runs 600-820 TF/s once there are
-    enough pixel tiles and a long enough contraction; the library GEMM reaches 0.85-0.95 PF/s on the small-spatial,
-    wide layers but pays the patch-matrix round trip everywhere."""
+    """Measured on an MI355X (tools/probe_igemm.py, bf16): the implicit-GEMM kernels run 800-1110 TF/s (direct-to-LDS
+    256-pixel form, outputs of 256 / 320-multiples) or 600-820 TF/s (128 x 128 form) once there are enough pixel tiles; the
+    library GEMM reaches 0.85-0.95 PF/s on the small-spatial, wide layers but pays the patch-matrix round trip everywhere."""
     if CONV_IGEMM == "never" or Cin % 64 or Cout % 8:
         return False
     if CONV_IGEMM == "always":
@@ -62,7 +62,10 @@ def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32) -> bool
     M = N * H * W
     if M >= 128 * 1024:                              # U-Net 64 x 64 at the generation batch, every VAE layer >= 128^2
         return True
-    return M >= 32 * 1024 and Cin >= 640             # 32 x 32 layers with a long contraction (640 -> 640, 1920 -> 640)
+    # 32 x 32 layers: the direct-to-LDS form (outputs that are multiples of 256 / 320 channels: 835-1113 TF/s against
+    # 736-761 for im2col + GEMM) or a long contraction on the 128 x 128 kernel; 16 x 16 and 8 x 8 layers have too few
+    # pixel tiles for either (library GEMM 0.88-0.95 PF/s there)
+    return M >= 32 * 1024 and (Cin >= 640 or Cout % 256 == 0 or Cout % 320 == 0)
 
 
 def even_chunk(n: int, cap: int) -> int:
