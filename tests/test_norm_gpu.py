@@ -165,6 +165,7 @@ def test_conv3x3_im2col_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias)
     (2, 128, 512, 96, 96, torch.bfloat16, False, False),
     (2, 128, 320, 128, 128, torch.bfloat16, True, True),     # fused upsample through the DMA gather
     (1, 64, 256, 130, 126, torch.bfloat16, True, False),     # two k-tiles per tap: the ring spans taps
+    (1, 128, 128, 160, 128, torch.bfloat16, True, False),    # 256 x 128 tiles (the VAE's 128-channel layers)
 ])
 def test_conv3x3_implicit_gemm_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, bias, up):
     """uce_conv3x3_nhwc_fwd (one launch, taps gathered into LDS, no patch matrix) against F.conv2d evaluated in fp32;

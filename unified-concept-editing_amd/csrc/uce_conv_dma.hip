@@ -5,6 +5,7 @@
 //       BN = 256: waves 2 (pixels) x 4 (channels), wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16 tiles
 //       BN = 320: waves 4 x 2, wave tile 64 x 160 = 2 x 5 tiles  (the U-Net's 320 / 640 / 960 / 1280 / 1920-channel layers
 //                 tile exactly; with 256-wide tiles a 320-channel layer would waste 37 % of its MFMAs)
+//       BN = 128: waves 4 x 2, wave tile 64 x 64 = 2 x 2 tiles   (the VAE decoder's 128-channel layers)
 //     6 - 7 fragment reads per 8 - 10 MFMAs (the 128 x 128 kernel: 1 per MFMA);
 //   * k-tile = one tap x 32 input channels = one 64-byte segment of a (shifted) source pixel per output pixel, moved by
 //     `buffer_load_dwordx4 ... lds` STRAIGHT into LDS (16 rows x 64 B per wave instruction): no staging registers, no
@@ -56,10 +57,11 @@ __device__ __forceinline__ float cd_tof(unsigned short v) {
 template <int BN>
 constexpr size_t cd_smem() { return (size_t)CD_NST * (CD_BM + BN) * CD_BK * 2; }
 
-// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 4 or 5)
+// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 3, 4 or 5)
 __device__ __forceinline__ void cd_wait_two_tiles(int per) {
   if (per == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if (per == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
 }
 
 template <int WGM, int WGN, int TM, int TN, bool F16>
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     const int c = p ^ ((R >> 2) & 3);
     b_base[j] = (g < NB && n0 + R < Cout) ? (unsigned)(((long)(n0 + R) * K + c * 8) * 2) : OOB;
   }
-  const int per = 2 + ((w < NB - 16) ? 3 : 2);                         // this wave's DMAs per k-tile
+  const int per = 2 + (w < NB ? 1 : 0) + (8 + w < NB ? 1 : 0) + (16 + w < NB ? 1 : 0);   // this wave's DMAs per k-tile (3, 4 or 5)
   const long x_bytes = (M / ((long)H * W)) * (long)Hs * Ws * Cin * 2;
   const long w_bytes = (long)Cout * K * 2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
@@ -244,5 +246,6 @@ int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, lon
   if (Cin % CD_BK || Cout % 4) return 0;
   if (Cout % 320 == 0) { *rc = launch_dma<4, 2, 2, 5>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
   if (Cout % 256 == 0) { *rc = launch_dma<2, 4, 4, 2>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
+  if (Cout % 128 == 0) { *rc = launch_dma<4, 2, 2, 2>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
   return 0;
 }
