@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import math
 import zlib
-from typing import Dict, Iterable, List, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -1,6 +1,5 @@
 """CPU: the C-ABI library loads and exports every symbol include/uce_hip.h declares; the
 product path fails loudly (no fallback) when there is no GPU."""
-import ctypes
 import os
 import re
 

@@ -13,7 +13,7 @@ import torch
 
 from oracle import uce_oracle as O
 from tests import fakepipe
-from tests.golden_io import Case, ERASE_CASES, DEBIAS_CASES, CLI_CASES, rows
+from tests.golden_io import Case, ERASE_CASES, DEBIAS_CASES, CLI_CASES
 from uce_amd import lib as L
 
 pytestmark = pytest.mark.gpu

@@ -1,5 +1,4 @@
 """CPU: the oracle restatement vs the reference's own outputs (golden fixtures)."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """GPU parity of the cross-attention kernel (through the C ABI) against the oracle and the
 golden outputs of torch's CPU scaled_dot_product_attention."""
-import numpy as np
 import pytest
 import torch
 

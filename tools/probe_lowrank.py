@@ -1,7 +1,7 @@
 """GPU probe: low-rank apply kernels vs N_edit (fused and two-kernel forms) + whole-edit time."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from uce_amd import edit as E, synth
 
 H = E.UceHandle.get("cuda:0")
