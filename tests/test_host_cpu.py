@@ -218,3 +218,27 @@ def test_edit_slab_rejects_negative_scales_and_nonpositive_lambda():
         E.edit_slab(None, slab, C, G, torch.tensor([1.0, -0.5, 1.0]), 0.5)
     with pytest.raises(ValueError, match="lamb"):
         E.edit_slab(None, slab, C, G, torch.ones(3), 0.0)
+
+
+def test_conv_dispatch_rule_and_padded_narrow_weights():
+    """Host logic of the convolution dispatch: which layers go to the implicit-GEMM kernels (measured rule), and the
+    zero-padded copy of a narrow-output weight (VAE conv_out) follows in-place updates of the parameters."""
+    from uce_amd import edit as E
+    from uce_amd.sd import unet as U
+    if E.CONV_IGEMM == "auto":
+        assert E.conv_prefers_igemm(64, 64, 320, 320, 32)            # U-Net 64 x 64 at the generation batch
+        assert E.conv_prefers_igemm(32, 32, 320, 640, 32)            # 32 x 32, 320-multiple output: direct-to-LDS form
+        assert E.conv_prefers_igemm(32, 32, 1920, 640, 32)
+        assert not E.conv_prefers_igemm(16, 16, 1280, 1280, 32)      # too few pixel tiles: im2col + library GEMM
+        assert not E.conv_prefers_igemm(8, 8, 1280, 1280, 32)
+        assert E.conv_prefers_igemm(512, 512, 128, 128, 16)          # VAE decoder
+    assert not E.conv_prefers_igemm(64, 64, 4, 320, 32)              # conv_in: Cin % 64 != 0
+    conv = torch.nn.Conv2d(128, 3, 3, padding=1)
+    w8, b8 = U._padded_out_channels(conv)
+    assert w8.shape == (8, 128, 3, 3) and torch.equal(w8[:3], conv.weight) and not w8[3:].any()
+    assert torch.equal(b8[:3], conv.bias) and not b8[3:].any()
+    assert U._padded_out_channels(conv)[0] is w8                     # cached
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    w8b, _ = U._padded_out_channels(conv)
+    assert w8b is not w8 and torch.equal(w8b[:3], conv.weight)
