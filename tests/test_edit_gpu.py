@@ -220,13 +220,21 @@ def test_UCE_dropin_matches_reference_cli(H, name, tmp_path):
     state = load_file(str(tmp_path / (name + ".safetensors")))
     assert sorted(state) == sorted(m["st_keys"])
     assert pipe.encode_calls == m["encode_calls"]
+    # the arbiter of the three-way protocol: the same formula in float64 on the rows the fixture
+    # keeps, from the embeddings the (deterministic) fake pipe returns for the job's concept lists
+    emb = E.last_token_embeddings(pipe, list(job.edit_concepts) + list(job.guide_concepts) + list(job.preserve_concepts), "cpu")
+    row = lambda names: [emb[x][None].cpu() for x in names]
+    olds = [c.t(f"W_old_{i}") for i in range(len(m["modules"]))]
+    exact = O.uce_edit_exact64(olds, row(job.edit_concepts), row(job.guide_concepts), row(job.preserve_concepts),
+                               job.erase_scale, job.preserve_scale, job.lamb)
     for i, (n, shp) in enumerate(zip(m["modules"], m["shapes"])):
         got = state[n + ".weight"]
         assert list(got.shape) == shp and got.dtype == torch.float32
         ref = c.t(f"W_ref32_{i}")
-        w_old = c.t(f"W_old_{i}")
-        assert torch.equal(w_old, unet.get_submodule(n).weight[: w_old.shape[0]])
-        assert O.rel_fro(got[: ref.shape[0]], ref) < 2.5e-3   # the reference's own fp32 noise level (eps_ref)
+        assert torch.equal(olds[i], unet.get_submodule(n).weight[: olds[i].shape[0]])
+        eps_ref = O.rel_fro(ref, exact[i])                     # the reference's own fp32 error on these rows
+        assert O.rel_fro(got[: ref.shape[0]], exact[i]) < EPS_BUILD
+        assert O.rel_fro(got[: ref.shape[0]], ref) < max(1e-4, 1.5 * eps_ref)
 
 
 # ------------------------------------------------------------------------------------ full size
