@@ -212,3 +212,173 @@ def test_euler_scheduler_matches_its_closed_form():
     assert torch.allclose(s.scale_model_input(x), x / (float(s.sigmas[0]) ** 2 + 1) ** 0.5)
     y = s.step(eps, 951.0, x)
     assert torch.allclose(y, x + 0.5 * (float(s.sigmas[1]) - float(s.sigmas[0])))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# PNDMScheduler.step against the PUBLISHED algorithm, not against its own code: the scheduler config SD-1.4 ships
+# (scaled-linear betas 0.00085 -> 0.012, 1000 train steps, steps_offset 1, skip_prk_steps: the PLMS branch only) with
+#  * the transfer x_t -> x_{t-d} written as the DDIM deterministic update (Song et al. 2021, eq. 12 with sigma = 0), which
+#    PNDM's eq. 9 (Liu et al. 2022) - the form diffusers' `_get_prev_sample` codes - is an algebraic rearrangement of;
+#  * the linear-multistep weights DERIVED here as the Adams-Bashforth weights of order k (the unique weights that
+#    integrate polynomials of degree < k exactly over one step from the k latest equidistant nodes), not typed in;
+#  * the start-up rule of diffusers' `step_plms`: call 0 is an Euler step, call 1 repeats the timestep and redoes the
+#    first step with the average of the two outputs (its output is NOT stored), then orders 2, 3, 4, 4, ...
+# Everything in float64 on the host; generate-images-sd.py:13-15,37-42 reaches this through pipe(...).
+# --------------------------------------------------------------------------------------------------------------
+
+def _adams_bashforth(k: int) -> np.ndarray:
+    """w with  sum_i w_i p(-i) = integral_0^1 p  for every polynomial p of degree < k  (nodes 0, -1, ..., -(k-1))."""
+    nodes = -np.arange(k, dtype=np.float64)
+    V = np.vander(nodes, k, increasing=True).T              # V[j, i] = nodes_i ** j
+    rhs = 1.0 / np.arange(1, k + 1, dtype=np.float64)       # integral of t^j over [0, 1]
+    return np.linalg.solve(V, rhs)
+
+
+def _ddim_transfer(x, eps, a_t, a_prev):
+    x0 = (x - np.sqrt(1.0 - a_t) * eps) / np.sqrt(a_t)
+    return np.sqrt(a_prev) * x0 + np.sqrt(1.0 - a_prev) * eps
+
+
+def _plms_reference(x, eps_seq, n_steps: int):
+    """float64 rollout of the published PLMS schedule for scripted model outputs eps_seq[call]."""
+    T = 1000
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, T, dtype=np.float64) ** 2
+    ac = np.cumprod(1.0 - betas)
+    ratio = T // n_steps
+    ts = [i * ratio + 1 for i in range(n_steps)][::-1]      # "leading" spacing + steps_offset 1: 981, 961, ..., 1
+    alpha = lambda t: ac[t] if t >= 0 else ac[0]            # set_alpha_to_one = False -> final alpha = alphas_cumprod[0]
+    hist, call = [], 0
+    # call 0: Euler step from ts[0]; call 1: same timestep pair, trapezoid with the new output (not stored)
+    x_start = x
+    e0 = eps_seq[call]; call += 1
+    hist.append(e0)
+    x1 = _ddim_transfer(x_start, e0, alpha(ts[0]), alpha(ts[0] - ratio))
+    e1 = eps_seq[call]; call += 1
+    x = _ddim_transfer(x_start, 0.5 * (e0 + e1), alpha(ts[0]), alpha(ts[0] - ratio))
+    outs = [x1, x]
+    for t in ts[1:]:
+        hist.append(eps_seq[call]); call += 1
+        k = min(len(hist), 4)
+        w = _adams_bashforth(k)
+        e = sum(w[i] * hist[-1 - i] for i in range(k))
+        x = _ddim_transfer(x, e, alpha(t), alpha(t - ratio))
+        outs.append(x)
+    return outs, ac
+
+
+def test_adams_bashforth_weights_are_the_plms_coefficients():
+    assert np.allclose(_adams_bashforth(2) * 2, [3, -1])
+    assert np.allclose(_adams_bashforth(3) * 12, [23, -16, 5])
+    assert np.allclose(_adams_bashforth(4) * 24, [55, -59, 37, -9])
+
+
+@pytest.mark.parametrize("n_steps", [50, 20])
+def test_pndm_step_matches_the_published_plms_algorithm(n_steps):
+    s = PNDMScheduler()
+    s.set_timesteps(n_steps)
+    ts = s.timesteps.tolist()
+    assert len(ts) == n_steps + 1
+    rng = np.random.Generator(np.random.PCG64(n_steps))
+    x0 = rng.standard_normal((1, 4, 8, 8))
+    eps_seq = [rng.standard_normal((1, 4, 8, 8)) for _ in ts]
+    want, ac = _plms_reference(x0, eps_seq, n_steps)
+    # the noise schedule itself: scaled-linear betas, cumulative product (float32 in the scheduler)
+    assert np.allclose(s.alphas_cumprod.double().numpy(), ac, rtol=2e-6, atol=0)
+    assert abs(ac[0] - (1 - 0.00085)) < 1e-12 and abs(ac[-1] - 0.00466) < 5e-5     # SD's well-known end points
+    x = torch.from_numpy(x0).double()
+    for call, t in enumerate(ts):
+        x = s.step(torch.from_numpy(eps_seq[call]).double(), t, x)
+        err = float((x - torch.from_numpy(want[call])).norm() / np.linalg.norm(want[call]))
+        assert err < 2e-6, (call, t, err)     # float64 tensors, float32 schedule constants
+    # the schedule: the second timestep is the repeated one, the last is steps_offset
+    ratio = 1000 // n_steps
+    assert ts[0] == (n_steps - 1) * ratio + 1 and ts[1] == ts[2] == ts[0] - ratio and ts[-1] == 1
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The reference's REAL prompt table (data/coco_30k.csv: BASELINE config 5): tests/golden/coco30k_rows.csv holds 71 of
+# its records - the first rows, every multi-line (quoted newline) caption among the first 5000, quoted commas / doubled
+# quotes, the extreme seeds, the last record - and coco30k_rows.json what the reference's own generate_images() did on
+# that file with a recording stand-in for the pipeline (tools/make_coco_fixture.py, run in the build container).
+# --------------------------------------------------------------------------------------------------------------
+
+class _RecordingPipe:
+    """Stands where pipe(...) stands in generate.generate_images: records the call, returns 8 x 8 images."""
+
+    def __init__(self):
+        self.calls = []
+        self.unet = torch.nn.Linear(1, 1)
+
+    def __call__(self, prompt, num_inference_steps, guidance_scale, num_images_per_prompt, generator):
+        from PIL import Image
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        gens = [generator] if isinstance(generator, torch.Generator) else list(generator)
+        assert len(prompts) == len(gens)
+        for p, g in zip(prompts, gens):
+            self.calls.append({"prompt": p, "seed": int(g.initial_seed()), "n": int(num_images_per_prompt),
+                               "generator_device": str(g.device), "steps": int(num_inference_steps),
+                               "guidance": float(guidance_scale)})
+        return type("Out", (), {"images": [Image.new("RGB", (8, 8)) for _ in range(len(prompts) * num_images_per_prompt)]})()
+
+
+def _coco_fixture():
+    import json
+    root = os.path.join(REPO_ROOT, "tests", "golden")
+    return os.path.join(root, "coco30k_rows.csv"), json.load(open(os.path.join(root, "coco30k_rows.json")))
+
+
+@pytest.mark.parametrize("batch_prompts", [1, 4])
+def test_generation_loop_on_real_coco30k_rows_matches_the_reference(tmp_path, batch_prompts):
+    csv_path, meta = _coco_fixture()
+    df = pd.read_csv(csv_path)
+    assert len(df) == meta["records"] and list(df.columns) == ["case_number", "source", "prompt", "evaluation_seed", "coco_id"]
+    assert int(df.prompt.str.contains("\n").sum()) == meta["multi_line_prompts"] >= 10     # quoted newlines survive parsing
+    assert int(df.evaluation_seed.max()) == 99998
+    for win in meta["windows"]:
+        pipe = _RecordingPipe()
+        out = tmp_path / f"w{win['from_case']}_{batch_prompts}"
+        stats = generate.generate_images("CompVis/stable-diffusion-v1-4", None, csv_path, str(out), exp_name="coco", device="cpu",
+                                         guidance_scale=7.5, num_inference_steps=50,
+                                         num_images_per_prompt=win["num_images_per_prompt"], from_case=win["from_case"],
+                                         till_case=win["till_case"], pipe=pipe, batch_prompts=batch_prompts, png_workers=2)
+        # the same pipe(...) arguments row by row: prompt text (incl. embedded newlines), CPU generator, seed, n
+        assert pipe.calls == win["calls"]
+        assert sorted(os.listdir(out / "coco")) == win["files"]
+        assert stats["images"] == len(win["files"])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_real_coco30k_rows_shard_disjointly_and_completely(world):
+    csv_path, meta = _coco_fixture()
+    df = pd.read_csv(csv_path)
+    win = meta["windows"][1]
+    shards = [[int(r.case_number) for _, r in generate.select_rows(df, win["from_case"], win["till_case"], rank, world)]
+              for rank in range(world)]
+    flat = sorted(c for s in shards for c in s)
+    want = sorted({int(f.split("_")[0]) for f in win["files"]})
+    assert flat == want and len(flat) == len(set(flat))
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1            # round-robin balance
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_bench_generation_leg_two_ranks_gloo(tmp_path, fail_rank):
+    """bench.py's generation leg as the N > 1 driver line runs it: weight broadcast, barrier, timed loop, barrier,
+    MAX-reduce of (seconds, failure flag), all-gather of the per-rank seconds - on two gloo ranks with the tiny model.
+    With a failure injected on rank 1 BOTH ranks must still pass every collective (no hang) and report the error."""
+    import json
+    worker = os.path.join(REPO_ROOT, "tests", "bench_gen_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="2", UCE_BENCH_FAIL_RANK=str(fail_rank))
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", str(29551 + (fail_rank > 0)), worker, str(tmp_path)],
+                   check=True, env=env, timeout=900)
+    res = [json.load(open(tmp_path / f"gen_w2_r{r}.json")) for r in (0, 1)]
+    for r in res:
+        assert r["n_gpus"] == 2 and r["metric"].startswith("images/sec")
+    if fail_rank < 0:
+        for r in res:
+            assert r["value"] > 0 and r["images_per_rank"] == 2 and r["weight_broadcast_ms"] >= 0
+            assert len(r["per_rank_images_per_s"]) == 2 and all(v > 0 for v in r["per_rank_images_per_s"])
+        assert res[0]["value"] == res[1]["value"]                      # MAX-reduced seconds: one figure for the job
+    else:
+        assert res[0]["value"] is None and res[1]["value"] is None
+        assert "injected failure" in res[1]["error"] and res[0]["error"] == "another rank failed"

@@ -197,7 +197,7 @@ def test_hidream_module_predicate_embeddings_and_cli():
 
 
 def test_even_chunk_respects_cap_and_balances():
-    from uce_amd.edit import even_chunk
+    from uce_amd.sd.conv_dispatch import even_chunk
     for n in range(1, 70):
         for cap in (0, 1, 2, 3, 7, 15, 22, 32, 100):
             step = even_chunk(n, cap)
@@ -223,7 +223,7 @@ def test_edit_slab_rejects_negative_scales_and_nonpositive_lambda():
 def test_conv_dispatch_rule_and_padded_narrow_weights():
     """Host logic of the convolution dispatch: which layers go to the implicit-GEMM kernels (measured rule), and the
     zero-padded copy of a narrow-output weight (VAE conv_out) follows in-place updates of the parameters."""
-    from uce_amd import edit as E
+    from uce_amd.sd import conv_dispatch as E
     from uce_amd.sd import unet as U
     if E.CONV_IGEMM == "auto":
         assert E.conv_prefers_igemm(64, 64, 320, 320, 32)            # U-Net 64 x 64 at the generation batch
@@ -238,6 +238,14 @@ def test_conv_dispatch_rule_and_padded_narrow_weights():
     assert w8.shape == (8, 128, 3, 3) and torch.equal(w8[:3], conv.weight) and not w8[3:].any()
     assert torch.equal(b8[:3], conv.bias) and not b8[3:].any()
     assert U._padded_out_channels(conv)[0] is w8                     # cached
+    # a by-name patch that writes through .data (patch_unet: no version bump) must drop the derived copy
+    from uce_amd.sd import pipeline as sdp
+    holder = type("P", (), {})()
+    holder.unet = torch.nn.Sequential(conv)
+    holder._graphs = {"k": object()}
+    sdp.patch_unet(holder, {"0.weight": torch.ones_like(conv.weight), "0.bias": torch.zeros_like(conv.bias)})
+    assert not hasattr(conv, "_uce_pad8") and not holder._graphs
+    assert bool((U._padded_out_channels(conv)[0][:3] == 1).all())
     with torch.no_grad():
         conv.weight.mul_(2.0)
     w8b, _ = U._padded_out_channels(conv)

@@ -1,0 +1,131 @@
+"""GPU stress of the cross-workgroup hand-offs (SURVEY.md section 5 "race detection": no sanitizer exists for the ticket /
+stage-word recipes, so they are exercised instead): random edits back to back on two handles and two streams, the same
+edit replayed from a captured hipGraph, and random convolution shapes through the LDS-DMA ring - every result against an
+independent fp64 / fp32 evaluation, every repeat bit-identical.  (The long forms: tools/stress_edit.py, stress_conv.py.)"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import uce_oracle as O
+from uce_amd import edit as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _exact(C, G, s, W64, n_e, d):
+    C64, s64 = C.double(), s.double()
+    A = 0.5 * torch.eye(d, dtype=torch.float64, device="cuda") + C64.T @ (s64[:, None] * C64)
+    Delta = torch.linalg.solve(A, (s64[:n_e, None] * C64[:n_e]).T @ (G - C[:n_e]).double()).T
+    return W64 + W64 @ Delta
+
+
+def _random_job(rng, d, big):
+    n_e = int(rng.integers(1, 200 if big else 129))
+    n_p = int(rng.integers(0, max(1, 129 - n_e))) if n_e < 128 else 0
+    N = n_e + n_p
+    Call = O.clip_like_embeddings(N + 1, d, seed=int(rng.integers(1 << 30)))
+    return _dev(Call[:N]), _dev(np.repeat(Call[N:N + 1], n_e, axis=0)), _dev((0.5 + rng.random(N)).astype(np.float32)), n_e
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_edits_back_to_back_on_two_handles_and_streams(seed):
+    """24 random concept sets (1..199 edit concepts: one- and two-block rider systems, the launch chain beyond 128), issued
+    alternately on the cached handle / torch's current stream and on a second handle / a side stream WITHOUT any
+    synchronisation in between (each handle owns its ticket, stage and counter words), then all checked against fp64."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, rows = 768, 4096
+    H1, H2 = E.UceHandle.get("cuda:0"), E.UceHandle("cuda:0")
+    side = torch.cuda.Stream()
+    W = _dev(O.linear_default_weight(rows, d, rng))
+    W64 = W.double()
+    jobs, outs = [], []
+    torch.cuda.synchronize()
+    try:
+        for it in range(24):
+            C, G, s, n_e = _random_job(rng, d, big=(it % 6 == 0))
+            jobs.append((C, G, s, n_e))
+            if it % 2 == 0:
+                outs.append(H1.edit(C, G, s, 0.5, W))
+            else:
+                side.wait_stream(torch.cuda.current_stream())          # the inputs were produced on the current stream
+                with torch.cuda.stream(side):
+                    outs.append(H2.edit(C, G, s, 0.5, W))
+        torch.cuda.synchronize()
+        H1.status()
+        H2.status()
+        worst = 0.0
+        for (C, G, s, n_e), out in zip(jobs, outs):
+            want = _exact(C, G, s, W64, n_e, d)
+            err = float((out.double() - want).norm() / want.norm())
+            worst = max(worst, err)
+            assert err < 1e-5, (n_e, C.shape[0], err)
+        assert worst > 0
+    finally:
+        H2.close()
+
+
+@pytest.mark.parametrize("n_e,n_p", [(50, 0), (100, 20)])
+def test_edit_replays_from_a_captured_graph(n_e, n_p):
+    """The rider hand-off keeps no launch-specific value in the kernel arguments (the stage word and its reset live on the
+    device), so a captured uce_edit can be replayed: three replays on changed weights, each against fp64."""
+    d, rows = 768, 2048
+    rng = np.random.Generator(np.random.PCG64(n_e))
+    H = E.UceHandle.get("cuda:0")
+    N = n_e + n_p
+    Call = O.clip_like_embeddings(N + 1, d, seed=7)
+    C, G = _dev(Call[:N]), _dev(np.repeat(Call[N:N + 1], n_e, axis=0))
+    s = _dev((0.5 + rng.random(N)).astype(np.float32))
+    W = _dev(O.linear_default_weight(rows, d, rng))
+    out = torch.empty_like(W)
+    H.edit(C, G, s, 0.5, W, out=out, check=True)                      # warm-up: workspace, function attributes
+    first = out.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        H.edit(C, G, s, 0.5, W, out=out)
+    for rep in range(3):
+        if rep:
+            W.copy_(_dev(O.linear_default_weight(rows, d, rng)))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        H.status()
+        want = _exact(C, G, s, W.double(), n_e, d)
+        assert float((out.double() - want).norm() / want.norm()) < 1e-5, rep
+        if rep == 0:
+            assert torch.equal(out, first)                            # bit-identical to the eager launch
+    H.edit(C, G, s, 0.5, W, out=out, check=True)                      # and the handle still works eagerly afterwards
+
+
+def test_random_convolution_shapes_repeat_bit_identically():
+    """uce_conv3x3_nhwc_fwd on random shapes (ragged pixel counts, tiles straddling images, every output-tile width, fused
+    upsample, both element types), four launches each: the direct-to-LDS ring must never read a stage before its loads
+    have landed - against F.conv2d in fp32."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    H = E.UceHandle.get("cuda:0")
+    for it in range(14):
+        Cin = int(rng.choice([64, 128, 192, 320, 640]))
+        Cout = int(rng.choice([64, 128, 256, 320, 384, 512, 640]))
+        up = bool(rng.integers(0, 2))
+        N = int(rng.integers(1, 4))
+        Hh, Ww = int(rng.integers(40, 150)), int(rng.integers(40, 150))
+        if up:
+            Hh, Ww = Hh & ~1, Ww & ~1
+        dtype = torch.float16 if rng.integers(0, 4) == 0 else torch.bfloat16
+        gen = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        hs, ws = (Hh // 2, Ww // 2) if up else (Hh, Ww)
+        x = torch.randn(N, Cin, hs, ws, generator=gen).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to("cuda", dtype).to(memory_format=torch.channels_last)
+        with torch.no_grad():
+            xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+            ref = F.conv2d(xin, conv.weight.float(), conv.bias.float(), padding=1)
+            outs = [H.conv3x3_igemm(x, conv.weight, conv.bias, upsample=up) for _ in range(4)]
+            torch.cuda.synchronize()
+        for y in outs:
+            err = float((y.float() - ref).norm() / ref.norm())
+            assert err < (6e-3 if dtype == torch.bfloat16 else 1e-3), (it, N, Cin, Cout, Hh, Ww, up, dtype, err)
+            assert torch.equal(y, outs[0]), (it, "not bit-repeatable")

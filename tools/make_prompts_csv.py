@@ -4,7 +4,8 @@
 
     python tools/make_prompts_csv.py data/coco_30k_synth.csv 30000
 
-The real COCO-30k captions are a dataset and not on these machines; the rows are caption-like prompts from a small
+The real table is data/coco_30k.csv of the reference repository (it does not travel to the GPU box; 71 of its records are
+the fixture tests/golden/coco30k_rows.csv); this tool writes tables of any length: caption-like prompts from a small
 grammar with deterministic 5-digit seeds (uce_amd.synth.coco_like_rows).  data/coco_1k_synth.csv (committed) is the
 first 1000 rows; BASELINE config 5 = the full 30 000."""
 import os

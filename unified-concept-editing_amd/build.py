@@ -8,6 +8,7 @@ header is newer than the object) and the objects are linked into lib/libuce_hip.
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -16,8 +17,6 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-OBJ_DIR = os.path.join(LIB_DIR, "obj")
-LIB_PATH = os.path.join(LIB_DIR, "libuce_hip.so")
 PUBLIC_HEADER = os.path.normpath(os.path.join(PKG, "..", "include", "uce_hip.h"))
 
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950 reads/writes them there directly).  Left to
@@ -27,6 +26,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-faile
 if os.environ.get("UCE_CHAIN_DEBUG"):          # phase stamps of the rider chain (tools/dbg_chain.py); never in the product build
     FLAGS.append("-DUCE_CHAIN_DEBUG")
 FLAGS += os.environ.get("UCE_DEFINES", "").split()            # experiment switches (-DNAME=VALUE ...), empty in the product build
+
+# Objects are only as fresh as the FLAGS they were compiled with: every flag set gets its own object directory, and a
+# build with debug / experiment flags links its own library file - the product libuce_hip.so is only ever made of
+# product objects (an mtime check alone would re-link a stale -DUCE_CHAIN_DEBUG object into it).
+_EXTRA = [f for f in FLAGS if f.startswith("-D")]
+VARIANT = "" if not _EXTRA else hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:10]
+OBJ_DIR = os.path.join(LIB_DIR, "obj", VARIANT or "product")
+LIB_PATH = os.path.join(LIB_DIR, "libuce_hip.so" if not VARIANT else f"libuce_hip.{VARIANT}.so")
 
 
 def sources() -> list[str]:
@@ -64,6 +71,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
+    flags_file = os.path.join(OBJ_DIR, ".flags")
+    flag_line = " ".join(FLAGS)
+    if not os.path.exists(flags_file) or open(flags_file).read() != flag_line:     # objects of another flag set: all stale
+        force = True
+        with open(flags_file, "w") as fh:
+            fh.write(flag_line)
     cc, hdrs = _hipcc(), headers()
     todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
 

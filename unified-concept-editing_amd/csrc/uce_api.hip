@@ -126,9 +126,14 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
   return UCE_OK;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
 extern "C" {
 
-int uce_version(void) { return 108; }
+int uce_version(void) { return 109; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -153,11 +158,17 @@ int uce_create(uce_handle_t* out, int device) {
   if (!h) return UCE_ENOMEM;
   *h = uce_ctx{};
   h->device = device;
+  {
+    const int cap = lr_rider_cap();
+    const int want = env_int("UCE_RIDER_MAX_N", cap);
+    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 1), env_int("UCE_TRISOLVE_VARIANT", 1),
+                        want < cap ? want : cap, env_int("UCE_CONV_DMA", 1)};
+  }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->status, 0, sizeof(int));
-  if (hipMalloc((void**)&h->ticket, 2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
-  (void)hipMemset(h->ticket, 0, 2 * sizeof(unsigned));
+  if (hipMalloc((void**)&h->ticket, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
+  (void)hipMemset(h->ticket, 0, 4 * sizeof(unsigned));
   *out = h;
   return UCE_OK;
 }
@@ -179,17 +190,20 @@ int uce_destroy(uce_handle_t h) {
 
 int uce_reserve(uce_handle_t h, int d_max, int n_max) {
   if (!h || d_max <= 0 || n_max <= 0 || d_max % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   return uce_ensure(h, d_max, round_up(n_max, 64));
 }
 
 int uce_reserve_rows(uce_handle_t h, long rows_max, int n_edit_max) {
   if (!h || rows_max <= 0 || n_edit_max <= 0) return UCE_EINVAL;
+  UCE_ENTER(h);
   return uce_ensure_T(h, rows_max, n_edit_max);
 }
 
 int uce_lowrank_project(uce_handle_t h, const float* W_old, const float* Dm, float* T, long rows, int d,
                         int N_edit, uce_stream_t stream) {
   if (!h || !W_old || !Dm || !T || rows < 0 || N_edit <= 0 || !lowrank_split_supported(d, N_edit)) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (rows == 0) return UCE_OK;
   return launch_lr_project(W_old, Dm, nullptr, T, rows, d, N_edit, (hipStream_t)stream);
 }
@@ -199,6 +213,7 @@ int uce_lowrank_update(uce_handle_t h, const float* W_old, const float* T, const
   if (!h || !W_old || !T || !R || !W_new || rows < 0 || N_edit <= 0 || W_old == W_new ||
       !lowrank_split_supported(d, N_edit))
     return UCE_EINVAL;
+  UCE_ENTER(h);
   if (rows == 0) return UCE_OK;
   return launch_lr_update(W_old, T, R, W_new, rows, d, N_edit, (hipStream_t)stream);
 }
@@ -206,6 +221,7 @@ int uce_lowrank_update(uce_handle_t h, const float* W_old, const float* T, const
 int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
              float lamb, double* A, double* Bt, uce_stream_t stream) {
   if (!h || !C || !s || !A || !Bt || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (N_edit > 0 && !G) return UCE_EINVAL;
   int rc = uce_ensure(h, d, d);
   if (rc) return rc;
@@ -215,6 +231,7 @@ int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int
 
 int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* DeltaT, uce_stream_t stream) {
   if (!h || !A || !Bt || !DeltaT || d <= 0 || d % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   int rc = uce_ensure(h, d, d);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -230,11 +247,11 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
 int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,
               uce_stream_t stream) {
   if (!h || !W_old || !DeltaT || !W_new || rows < 0 || d <= 0 || d % 64 || W_old == W_new) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (rows == 0) return UCE_OK;
   // default: bf16 matrix cores with a three-way split of both operands (fp32-equivalent products, 2.7x the
-  // f32-MFMA rate); UCE_APPLY_VARIANT=0 selects the exact-f32 MFMA kernel
-  static const int variant = getenv("UCE_APPLY_VARIANT") ? atoi(getenv("UCE_APPLY_VARIANT")) : 1;
-  if (variant == 0) {
+  // f32-MFMA rate); UCE_APPLY_VARIANT=0 (read at uce_create) selects the exact-f32 MFMA kernel
+  if (h->sw.apply_variant == 0) {
     UceProfScope ps(h, "k_apply", (hipStream_t)stream);
     return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
   }
@@ -246,6 +263,7 @@ int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_
 int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,
                      int d, float lamb, float* Dm, float* R, uce_stream_t stream) {
   if (!h || !C || !s || !Dm || !R || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (N_edit > 0 && !G) return UCE_EINVAL;
   const int n_pad = round_up(N, 64);
   int rc = uce_ensure(h, d, n_pad);
@@ -272,6 +290,7 @@ int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float
 int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int N_edit, int d,
                            float* DeltaT, uce_stream_t stream) {
   if (!h || !DeltaT || N_edit < 0 || d <= 0 || d % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (N_edit > 0 && (!Dm || !R)) return UCE_EINVAL;
   UceProfScope ps(h, "k_delta_factors", (hipStream_t)stream);
   return launch_delta_from_factors(Dm, R, N_edit, d, DeltaT, (hipStream_t)stream);
@@ -281,6 +300,7 @@ int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const
                       long rows, int d, int N_edit, uce_stream_t stream) {
   if (!h || !W_old || !W_new || rows < 0 || d <= 0 || d % 64 || N_edit < 0 || N_edit > 256 || W_old == W_new)
     return UCE_EINVAL;
+  UCE_ENTER(h);
   if (N_edit > 0 && (!Dm || !R)) return UCE_EINVAL;
   if (rows == 0) return UCE_OK;
   if (N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
@@ -304,6 +324,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   if (!h || !C || !s || !W_old || !W_new || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64 ||
       rows < 0 || W_old == W_new)
     return UCE_EINVAL;
+  UCE_ENTER(h);
   if (N_edit > 0 && !G) return UCE_EINVAL;
   if (algo == UCE_ALGO_AUTO) algo = (round_up(N, 64) < d) ? UCE_ALGO_DUAL : UCE_ALGO_PRIMAL;
   int rc;
@@ -331,7 +352,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     rc = uce_ensure_T(h, rows, N_edit);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const bool riders = n_pad <= lr_rider_max_n();
+    const bool riders = n_pad <= h->sw.rider_max_n;
     if (riders) {
       // TWO launches: projection || (Gram -> Cholesky -> triangular solves, all in rider blocks of the same launch),
       // then the update
@@ -382,6 +403,7 @@ int uce_profile_begin(uce_handle_t h) {
 
 int uce_profile_end(uce_handle_t h, uce_stream_t stream, char* report, size_t cap) {
   if (!h || !h->prof || !report || cap == 0) return UCE_EINVAL;
+  UCE_ENTER(h);
   UCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   struct Agg { const char* name; double ms; int n; };
   std::vector<Agg> agg;
@@ -408,6 +430,7 @@ int uce_profile_end(uce_handle_t h, uce_stream_t stream, char* report, size_t ca
 
 int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {
   if (!h || !info) return UCE_EINVAL;
+  UCE_ENTER(h);
   int v = 0;
   UCE_HIP_TRY(hipMemcpyAsync(&v, h->status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   UCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

@@ -208,8 +208,9 @@ __global__ void k_cast_bf16(const float* __restrict__ src, unsigned short* __res
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st) {
   const size_t smem = (size_t)2 * (BM + BN) * TLD * sizeof(float);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   const long row_tiles = (rows + BM - 1) / BM;
   const int col_tiles = (d + BN - 1) / BN;
@@ -230,6 +231,7 @@ int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d
 
 extern "C" int uce_cast_bf16(uce_handle_t h, const float* src, void* dst_bf16, long n, uce_stream_t stream) {
   if (!h || !src || !dst_bf16 || n < 0) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (n == 0) return UCE_OK;
   const long n4 = (n + 3) / 4;
   hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
@@ -436,9 +438,10 @@ int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, fl
   const size_t smem = ((size_t)LR_BM * (d + 8) + (size_t)5 * LR_BM * (NEP + 2)) * sizeof(float);
   if (smem > 160 * 1024) return UCE_EINVAL;
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_lowrank_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
+    attr_once.commit(tok);
   }
   const long nwg = (rows + LR_BM - 1) / LR_BM;
   if (nwg > 0x7fffffffL) return UCE_EINVAL;
@@ -452,6 +455,7 @@ extern "C" int uce_debias_targets(uce_handle_t h, const float* C_edit, const flo
                                   const double* Dsum, int N_edit, int N_debias, int d, float* G,
                                   uce_stream_t stream) {
   if (!h || !C_edit || !G || N_edit <= 0 || N_debias < 0 || d <= 0 || d % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (N_debias > 0 && (!C_debias || !Dsum)) return UCE_EINVAL;
   const long n = (long)N_edit * (d / 4);
   hipLaunchKernelGGL(k_debias_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -9,11 +9,14 @@
 // accumulation); the dropped terms (x_m y_l, x_l y_m, x_l y_l) are below 2^-23 relative - one fp32 rounding.
 // Six bf16 MFMAs replace the 16 "bf16-MFMA-equivalents" an f32 MFMA product costs: 2.7x the f32-MFMA rate.
 //
-//   k_split3      Delta^T [d, d] f32 -> three bf16 planes (once per edit, 590 k elements at d = 768)
+//   k_split3      (I + Delta)^T [d, d] f32 -> three bf16 planes (once per edit, 590 k elements at d = 768)
 //   k_apply_b3    NT GEMM, 128 x 128 tile per workgroup, 4 waves x (2 x 2) v_mfma_f32_32x32x16_bf16 tiles,
 //                 K step 16, double-buffered LDS with register prefetch; the W_old operand is split on the fly
-//                 while it is staged (each element is staged once per column tile), the residual is the
-//                 accumulator init (fp32, exact), XCD-aware tile order as in k_apply.
+//                 while it is staged (each element is staged once per column tile), XCD-aware tile order as in k_apply.
+// The residual rides in the product:  W_new = W_old (I + Delta), with the identity added to Delta^T before the split
+// (fp32 add: the diagonal entry 1 + delta_ii keeps delta_ii to 2^-24 absolute = one fp32 rounding of the result; the three
+// planes then hold 1 + delta_ii exactly).  Reading the residual tile separately (accumulator init, the round-2 form) cost
+// a second fetch of W_old with 4-byte lane strides: PMC 294 MB per launch for 155.7 MB algorithmic.
 #include "uce_common.h"
 #include <cstdlib>
 
@@ -49,11 +52,14 @@ __device__ __forceinline__ void split4(const float4_t x, uint2_t& h, uint2_t& m,
 }
 
 __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ src, unsigned short* __restrict__ planes,
-                                                long n) {
+                                                long n, int d) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;                                   // n is a multiple of 4 (d % 64 == 0)
   uint2_t h, m, l;
-  split4(*(const float4_t*)(src + i), h, m, l);
+  float4_t x = *(const float4_t*)(src + i);
+  const int row = (int)(i / d), c0 = (int)(i - (long)row * d);   // four consecutive columns of one row
+  if (row >= c0 && row < c0 + 4) x[row - c0] += 1.0f;             // + I
+  split4(x, h, m, l);
   *(uint2_t*)(planes + i) = h;
   *(uint2_t*)(planes + n + i) = m;
   *(uint2_t*)(planes + 2 * n + i) = l;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_b3(const float* __restrict__ W
   if (gj > d - 1) gj = d - 1;
   const unsigned short* bptr = Bp + (size_t)gj * d + bc8;
 
-  // accumulators start at the residual W_old tile (D layout of the 32x32 MFMA)
+  // (the residual is part of the product: the planes hold (I + Delta)^T)
   float16_t acc[2][2];
   const int ccol = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -110,11 +116,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_b3(const float* __restrict__ W
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long gr = r0 + wm + mt * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        const int gc = j0 + wn + nt * 32 + ccol;
-        acc[mt][nt][r] = (gr < rows && gc < d) ? W_old[gr * d + gc] : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   float4_t ra[2];
   uint4_t rb[3];
@@ -196,13 +198,14 @@ int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* pla
   const long n = (long)d * d;
   {
     UceProfScope ps(h, "k_split3", st);
-    hipLaunchKernelGGL(k_split3, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, DeltaT, planes, n);
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, DeltaT, planes, n, d);
   }
   UCE_LAUNCH_CHECK();
   const size_t smem = (size_t)2 * 6 * PLANE * sizeof(unsigned short);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_b3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   const long row_tiles = (rows + BM - 1) / BM;
   const int col_tiles = (d + BN - 1) / BN;

@@ -23,25 +23,56 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef short short8_t __attribute__((ext_vector_type(8)));
 
 // Function attributes (the > 64 KB dynamic-LDS opt-in) are per DEVICE: a launcher sets them the first time it runs
-// on each device of the process, not once per process.
+// on each device of the process, not once per process.  first() returns 0 when the current device is done, else a
+// token (device ordinal + 1) that the launcher hands to commit() AFTER every hipFuncSetAttribute call succeeded - a
+// failed call is retried by the next launch instead of being remembered as done.  (The entry points of uce_api.hip
+// make the handle's device current before any launcher runs, so "current device" = the device of the launch.)
 struct PerDeviceOnce {
   unsigned long long seen[4] = {0, 0, 0, 0};      // up to 256 device ordinals
-  bool first() {
+  int first() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return true;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (seen[dev >> 6] & bit) return false;
-    seen[dev >> 6] |= bit;
-    return true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return -1;     // unknown: set the attributes, remember nothing
+    return (__atomic_load_n(&seen[dev >> 6], __ATOMIC_ACQUIRE) & (1ull << (dev & 63))) ? 0 : dev + 1;
+  }
+  void commit(int token) {
+    if (token > 0) __atomic_fetch_or(&seen[(token - 1) >> 6], 1ull << ((token - 1) & 63), __ATOMIC_RELEASE);
   }
 };
 
+// Every launching entry point runs with the HANDLE's device current (function attributes, allocations and launches
+// then all refer to the device the handle was created on, whatever the caller's current device is); restored on exit.
+struct UceDeviceGuard {
+  int prev = -1;
+  explicit UceDeviceGuard(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+  }
+  ~UceDeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  UceDeviceGuard(const UceDeviceGuard&) = delete;
+  UceDeviceGuard& operator=(const UceDeviceGuard&) = delete;
+};
+#define UCE_ENTER(h) UceDeviceGuard uce_guard_((h)->device)
+
 constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solves
+
+// A/B switches for measurements (defaults = the measured best), read from the environment ONCE, when the handle is created:
+//   UCE_XATTN_VARIANT   1 (default): column-group kernel at generation-batch sizes | 0: always k_xattn | 2: the group kernel
+//                       at every size | 3: its 8-wave dh = 40 form
+//   UCE_APPLY_VARIANT   1: bf16 x 3 dense apply | 0: the f32-MFMA kernel
+//   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
+//   UCE_RIDER_MAX_N     largest dual system (64 or 128) factored by rider blocks of the projection launch; 0: never
+//   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
+struct UceSwitches {
+  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma;
+};
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
 // width and the largest SPD system (primal: n = d, dual: n = roundup(N, 64)) seen so far.
 struct uce_ctx {
   int device;
+  UceSwitches sw;
   int d_cap;      // embedding width capacity
   int n_cap;      // SPD system capacity (multiple of 64)
   double* M;      // [n_cap, n_cap]  system matrix, trailing tiles updated in place
@@ -57,8 +88,8 @@ struct uce_ctx {
   float* Dm;      // [n_cap, d_cap]
   float* R;       // [n_cap, d_cap]
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
-  unsigned* ticket;  // [0] arrival counter of the rider blocks (zero between launches), [1] "factorisation done" sequence word
-  unsigned seq;      // launches with riders so far (the value the solve riders wait for)
+  unsigned* ticket;  // hand-off words of the rider blocks (uce_lowrank2.hip), all zero between launches: [0] arrival counter
+                     // of the Gram riders, [1] stage word of the factorising block, [2] completion counter of the solve riders
   float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply
   size_t T_elems;
   void* Vt;       // V^T scratch of uce_sattn_fwd ([B, H, DVP, LkP] 16-bit elements)
@@ -80,6 +111,7 @@ struct UceProfScope {
 // ---- internal launchers (defined across the .hip files) -------------------------------------
 int uce_ensure(uce_ctx* h, int d, int n);
 // uce_conv_dma.hip: 1 = launched (*rc = status), 0 = shape not taken by the direct-to-LDS form
+// (the caller decides by UceSwitches::conv_dma whether to ask)
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
                     int dtype, hipStream_t st, int* rc);
 
@@ -112,7 +144,7 @@ int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d
                               hipStream_t st);
 int launch_sub_rows(const float* G, const float* C, float* Dm, long n, hipStream_t st);
 bool lowrank_split_supported(int d, int N_edit);
-int lr_rider_max_n();   // largest dual system (rows, multiple of 64) the projection launch's riders factor
+int lr_rider_cap();     // largest dual system (rows, multiple of 64) the projection launch's riders can factor
 // With `h`: the launch also carries the whole small-system chain (Gram + Cholesky riders, then the solve riders
 // that write R [N_edit, d] = rows of K^-1 C) - the caller needs no separate triangular-solve launch.
 int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
@@ -126,7 +158,7 @@ size_t sattn_vt_elems(int B, int H, int Lk, int dh);
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
                  float scale, int dtype, hipStream_t st);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
-                 int dh, float scale, int dtype, hipStream_t st);
+                 int dh, float scale, int dtype, hipStream_t st, int variant = 1);
 
 static __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_im2col3x3_flat(const uint4_t* __restric
 extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
                                   uce_stream_t stream) {
   if (!h || !x || !cols || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (upsample != 0 && upsample != 1) return UCE_EINVAL;
   if (upsample && ((H | W) & 1)) return UCE_EINVAL;
   const int up = upsample;

@@ -221,9 +221,10 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
   const size_t smem = cd_smem<BN>();
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,

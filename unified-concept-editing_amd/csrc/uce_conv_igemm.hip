@@ -217,9 +217,10 @@ int launch_igemm(const void* x, const void* w, const void* bias, void* y, long M
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
   const size_t smem = cg_smem<WM, WN>();
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_igemm<WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_igemm<WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_conv3x3_igemm<WM, WN, true>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x,
@@ -238,6 +239,7 @@ int launch_igemm(const void* x, const void* w, const void* bias, void* y, long M
 extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const void* bias, void* y, int N, int H,
                                     int W, int Cin, int Cout, int upsample, int dtype, uce_stream_t stream) {
   if (!h || !x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (Cin % CG_BK || Cout % 8) return UCE_EINVAL;
   if (upsample && ((H | W) & 1)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
@@ -251,9 +253,8 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
   // 256 x 64 form); 256 x 64 only where a 128-wide tile would be at least half empty (Cout <= 64)
   {
     // wide outputs (multiples of 256 / 320 channels) with enough pixel tiles: the direct-to-LDS 256-pixel form
-    const char* e = getenv("UCE_CONV_DMA");                  // 0: always the 128 x 128 kernel (A/B measurements); read per call
-    int rc;
-    if (!(e && atoi(e) == 0) && M >= 256 * 64 &&          // (fewer than 64 pixel tiles leave most of the 256 CUs idle)
+    int rc;                                                  // UCE_CONV_DMA=0 (read at uce_create): always the 128 x 128 kernel
+    if (h->sw.conv_dma != 0 && M >= 256 * 64 &&          // (fewer than 64 pixel tiles leave most of the 256 CUs idle)
         launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc))
       return rc;
   }

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_gather_last(const void* __restrict__ hi
 extern "C" int uce_gather_last_token(uce_handle_t h, const void* hidden, const int* idx, float* out, int B, int L, int d,
                                      int dtype, uce_stream_t stream) {
   if (!h || !hidden || !idx || !out || B < 0 || L <= 0 || d <= 0 || (d & 7)) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (B == 0) return UCE_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == UCE_DTYPE_F32) hipLaunchKernelGGL(k_gather_last<UCE_DTYPE_F32>, dim3(B), dim3(256), 0, st, hidden, idx, out, L, d);

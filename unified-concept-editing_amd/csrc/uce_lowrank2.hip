@@ -13,13 +13,12 @@
 // footprint is tiny, so several workgroups per CU stream W with their phases naturally interleaved.
 #include "uce_common.h"
 #include "uce_potrf64.h"
-#include <cstdlib>
 
 // -DUCE_CHAIN_DEBUG: wall-clock stamps (100 MHz) of the rider chain's phases, read back with uce_debug_read
 // (tools/dbg_chain.py); compiled out of the product library.
 #ifdef UCE_CHAIN_DEBUG
-__device__ unsigned long long g_dbg[64][16];
-#define DBG(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) { g_dbg[blockIdx.x][slot] = wall_clock64(); g_dbg[blockIdx.x][8 + slot] = clock64(); } } while (0)
+__device__ unsigned long long g_dbg[64][32];   // per block: 16 wall-clock stamps (slots 0-7 Gram / factor / projection role, 8-15 solve role) + 16 shader-clock stamps
+#define DBG(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) { g_dbg[blockIdx.x][slot] = wall_clock64(); g_dbg[blockIdx.x][16 + slot] = clock64(); } } while (0)
 extern "C" int uce_debug_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
 }
@@ -33,17 +32,34 @@ constexpr int PJ_KC = 64;    // floats per W k-chunk
 constexpr int PJ_LD = 72;    // LDS row stride of the chunk (floats): conflict-free b128 fragment reads
 
 // ---------------------------------------------------------------------------------------------
-// projection: 8 waves, wave = (concept tile class c4 = w & 3, M half = w >> 2); the W k-chunk of the
-// MT*16-row super-tile and the D_e k-chunk (64 concepts) are staged once in LDS and shared by the waves;
-// each D_e fragment read from LDS feeds NMT MFMAs.
+// projection: 8 waves, wave = (concept tile class c4 = w & 3, M half = w >> 2); the W k-chunk of the MT*16-row
+// super-tile and the D_e k-chunk (64 * CT concepts, formed on the fly from G and C_e) are staged once in LDS and shared
+// by the waves; each W fragment read from LDS feeds 4 * CT MFMAs, each D_e fragment NMT.
+// CT = 2 (64 < N_edit): wave c4 owns the 16-concept tiles c4 and c4 + 4 of a 128-concept batch, so the weights are
+// streamed ONCE per 128 concepts (round 2 walked W once per 64 concepts: two passes at the north-star's "100
+// concepts", 2.08x the step's algorithmic traffic, 0.144 ms; this form 0.104 ms).
+//  * ONE register set per operand stream: chunk c + 1 is loaded during iteration c - 1, parked into the free LDS buffer
+//    at the start of iteration c, and the set is reloaded with chunk c + 2 right away (a chunk is 1.5 - 3 us of MFMA
+//    work; the two-set form of round 2 needed ~350 VGPRs at CT = 2);
+//  * fragments of ONE 16-k group ahead (two named sets) instead of a whole chunk's;
+//  * buffer addressing: one 32-bit lane offset per load, the chunk displacement folded into the scalar resource base,
+//    num_records doing the bounds work (weight rows >= rows and concept rows >= N_edit read as zeros: no clamps, no mask);
+//  * the parks and the next loads sit BETWEEN the MFMA groups of the chunk, so the matrix pipe keeps draining while
+//    this wave moves data (round 2: all waves parked right after the barrier, the pipe idle: GEMM alone at 50
+//    concepts 33.3 -> 30.7 us, 0.47 -> 0.51 of the f32 MFMA peak on the issued tile; 128-wide: 0.57).
 // ---------------------------------------------------------------------------------------------
-template <int D, int MT, int NMT>
-__device__ __forceinline__ void project_body(const float* __restrict__ W_old, const float* __restrict__ Dm,
-                                             const float* __restrict__ Csub, float* __restrict__ T,
-                                             long rows, int Ne, int NEP, float* Wc, int mbase, int blk_off) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pj_rsrc(const float* base, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0 ? (bytes < 0x7fffffffL ? (int)bytes : 0x7fffffff) : 0, 0x00020000);
+}
+
+template <int D, int MT, int NMT, int CT = 2>
+__device__ __forceinline__ void project_body_w(const float* __restrict__ W_old, const float* __restrict__ Dm,
+                                               const float* __restrict__ Csub, float* __restrict__ T,
+                                               long rows, int Ne, int NEP, float* Wc, int mbase, int blk_off) {
   constexpr int d = D;
   constexpr int SR = MT * 16;
-  float* Dc = Wc + 2 * SR * PJ_LD;                    // [2][64][PJ_LD]  D_e k-chunk of the current batch
+  constexpr int NCB = 64 * CT;                        // concepts per batch
+  float* Dc = Wc + 2 * SR * PJ_LD;                    // [2][NCB][PJ_LD]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c4 = w & 3;
   const int li = lane & 15, lk = lane >> 4;
@@ -52,121 +68,163 @@ __device__ __forceinline__ void project_body(const float* __restrict__ W_old, co
   constexpr int NC = D / PJ_KC;                       // k-chunks (12 / 16 / 32), even
   constexpr int F4 = SR * (PJ_KC / 4);                // float4 per W chunk
   constexpr int NLD = (F4 + 511) / 512;               // per thread
-  struct Stage { float4_t w[NLD]; float4_t x[2]; float4_t y[2]; };
+  constexpr int NDL = NCB * (PJ_KC / 4) / 512;        // 2 * CT
   const float cscale = Csub ? 1.f : 0.f;              // D_e = X - cscale * Y (X = G, Y = C_e) or X = Dm
   const float* Ysrc = Csub ? Csub : Dm;
-  const int nbatch = NEP >> 6;
+  const long w_valid = ((rows - R0) < SR ? (rows - R0) : SR) * (long)d * 4;   // bytes of this super-tile that exist
+  const float* Wb = W_old + R0 * d;
+  // lane offsets (bytes): element e = tid + 512 p -> row e >> 4, float4 column e & 15
+  unsigned vo_w[NLD], vo_d[NDL];
+#pragma unroll
+  for (int p = 0; p < NLD; ++p) {
+    const int e = tid + 512 * p;
+    vo_w[p] = (unsigned)(((e >> 4) * d + ((e & 15) << 2)) * 4);      // rows >= SR: beyond w_valid or never parked
+  }
+#pragma unroll
+  for (int p = 0; p < NDL; ++p) {
+    const int e = tid + 512 * p;
+    vo_d[p] = (unsigned)(((e >> 4) * d + ((e & 15) << 2)) * 4);
+  }
+  const int nbatch = (NEP + NCB - 1) / NCB;
 #pragma unroll 1
   for (int bt = 0; bt < nbatch; ++bt) {
-    // both operands come in as full 256-byte row segments (16 lanes x 16 B) and go through LDS: the
-    // W rows of the super-tile and the 64 concept rows of this batch (masked beyond N_edit)
-    auto load_stage = [&](int kc, Stage& st) {
+    const int nct = (NEP - bt * NCB) >= NCB ? CT : 1; // NEP is a multiple of 64: the last batch may hold one half
+    const long d_valid = (long)(Ne - bt * NCB) * d * 4;               // concept rows of this batch that exist (may be <= 0)
+    const float* Xb = Dm + (size_t)bt * NCB * d;
+    const float* Yb = Ysrc + (size_t)bt * NCB * d;
+    float4_t sw[NLD], sx[NDL], sy[NDL];
+    auto issue = [&](int kc) {
+      const __amdgpu_buffer_rsrc_t rw = pj_rsrc(Wb + kc * PJ_KC, w_valid - (long)kc * PJ_KC * 4);
+      const __amdgpu_buffer_rsrc_t rx = pj_rsrc(Xb + kc * PJ_KC, d_valid - (long)kc * PJ_KC * 4);
+      const __amdgpu_buffer_rsrc_t ry = pj_rsrc(Yb + kc * PJ_KC, d_valid - (long)kc * PJ_KC * 4);
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) sw[p] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rw, vo_w[p], 0, 0));
+#pragma unroll
+      for (int p = 0; p < NDL; ++p) {
+        sx[p] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, vo_d[p], 0, 0));
+        sy[p] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(ry, vo_d[p], 0, 0));
+      }
+    };
+    auto park_w = [&](int buf) {
 #pragma unroll
       for (int p = 0; p < NLD; ++p) {
         const int e = tid + 512 * p;
-        const int r = (e >> 4) < SR ? (e >> 4) : SR - 1, cc = (e & 15) << 2;
-        long gr = R0 + r;
-        gr = gr < rows ? gr : rows - 1;
-        st.w[p] = *(const float4_t*)(W_old + gr * d + kc * PJ_KC + cc);
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int e = tid + 512 * p;                  // 64 rows x 16 float4
-        const int er = bt * 64 + (e >> 4), cc = (e & 15) << 2;
-        const size_t off = (size_t)(er < Ne ? er : Ne - 1) * d + kc * PJ_KC + cc;
-        st.x[p] = *(const float4_t*)(Dm + off);
-        st.y[p] = *(const float4_t*)(Ysrc + off);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto park_stage = [&](int buf, const Stage& st) {
-#pragma unroll
-      for (int p = 0; p < NLD; ++p) {
-        const int e = tid + 512 * p;
-        if (e < F4) *(float4_t*)&Wc[(buf * SR + (e >> 4)) * PJ_LD + ((e & 15) << 2)] = st.w[p];
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int e = tid + 512 * p;
-        const float m = (bt * 64 + (e >> 4) < Ne) ? 1.f : 0.f;
-        *(float4_t*)&Dc[(buf * 64 + (e >> 4)) * PJ_LD + ((e & 15) << 2)] = (st.x[p] - cscale * st.y[p]) * m;
+        if (e < F4) *(float4_t*)&Wc[(buf * SR + (e >> 4)) * PJ_LD + ((e & 15) << 2)] = sw[p];
       }
     };
-    float4_t acc[NMT];
+    auto park_d = [&](int buf) {
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) acc[m] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int buf) {
-      // k permutation: MFMA q of 16-k group g uses k = 16g + 4*(lane>>4) + q on both operands
+      for (int p = 0; p < NDL; ++p) {
+        const int e = tid + 512 * p;
+        *(float4_t*)&Dc[(buf * NCB + (e >> 4)) * PJ_LD + ((e & 15) << 2)] = sx[p] - cscale * sy[p];
+      }
+    };
+    float4_t acc[CT][NMT];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4_t a[NMT];
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) acc[c][m] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    struct Frag { float4_t a[NMT]; float4_t b[CT]; };
+    // k permutation: MFMA q of 16-k group g uses k = 16g + 4*(lane>>4) + q on both operands
+    auto rd = [&](int buf, int g, Frag& f) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+        f.a[m] = *(const float4_t*)&Wc[(buf * SR + (mbase + m) * 16 + li) * PJ_LD + g * 16 + 4 * lk];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        f.b[c] = *(const float4_t*)&Dc[(buf * NCB + (c * 4 + c4) * 16 + li) * PJ_LD + g * 16 + 4 * lk];
+    };
+    auto mm = [&](const Frag& f) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
-          a[m] = *(const float4_t*)&Wc[(buf * SR + (mbase + m) * 16 + li) * PJ_LD + g * 16 + 4 * lk];
-        const float4_t bb = *(const float4_t*)&Dc[(buf * 64 + c4 * 16 + li) * PJ_LD + g * 16 + 4 * lk];
+          acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m][q], f.b[0][q], acc[0][m], 0, 0, 0);
+        if constexpr (CT > 1) {
+          if (nct > 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int m = 0; m < NMT; ++m)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], bb[q], acc[m], 0, 0, 0);
+            for (int m = 0; m < NMT; ++m)
+              acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m][q], f.b[1][q], acc[1][m], 0, 0, 0);
+          }
+        }
       }
     };
-    // chunk c: loaded during iteration c-2 into register set c&1, parked in LDS buffer c&1 during
-    // iteration c-1, consumed in iteration c.
-    Stage sA, sB;
+    // one chunk: buffer `buf` holds chunk kc; the registers hold chunk kc + 1 (parked into buf ^ 1 on the way) and are
+    // reloaded with chunk kc + 2
+    auto chunk = [&](int kc, int buf) {
+      Frag fA, fB;
+      rd(buf, 0, fA);
+      if (kc + 1 < NC) park_w(buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(buf, 1, fB);
+      mm(fA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kc + 1 < NC) park_d(buf ^ 1);
+      if (kc + 2 < NC) issue(kc + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(buf, 2, fA);
+      mm(fB);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(buf, 3, fB);
+      mm(fA);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fB);
+      __syncthreads();
+    };
     __syncthreads();                                  // previous batch is done with the LDS buffers
-    load_stage(0, sA);
-    load_stage(1, sB);
-    park_stage(0, sA);
-    load_stage(2 < NC ? 2 : 0, sA);
+    issue(0);
+    park_w(0);
+    park_d(0);
+    issue(1);
     __syncthreads();
 #pragma unroll 1
     for (int kc = 0; kc < NC; kc += 2) {
-      park_stage(1, sB);                              // chunk kc + 1
-      load_stage(kc + 3 < NC ? kc + 3 : kc, sB);
-      compute(0);                                     // chunk kc
-      __syncthreads();
-      if (kc + 2 < NC) park_stage(0, sA);             // chunk kc + 2
-      load_stage(kc + 4 < NC ? kc + 4 : kc, sA);
-      compute(1);                                     // chunk kc + 1
-      __syncthreads();
+      chunk(kc, 0);
+      chunk(kc + 1, 1);
     }
     // D layout: col = lane & 15 (concept), row = 4*(lane>>4) + r
 #pragma unroll
-    for (int m = 0; m < NMT; ++m)
+    for (int c = 0; c < CT; ++c) {
+      if (c < nct) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long gr = R0 + (mbase + m) * 16 + 4 * lk + r;
-        if (gr < rows) T[gr * NEP + (bt * 4 + c4) * 16 + li] = acc[m][r];
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long gr = R0 + (mbase + m) * 16 + 4 * lk + r;
+            if (gr < rows) T[gr * NEP + bt * NCB + (c * 4 + c4) * 16 + li] = acc[c][m][r];
+          }
       }
+    }
   }
 }
 
-// Optional riders of the projection launch (blocks 0..GP_NB-1): the whole small-system factorisation
-// of the dual form when it is a single 64-block (N <= 64):  K = lambda S^-1 + C C^T  (f64 MFMA over
-// the d features, split over GP_NB blocks x 2 wave quads), then the 64x64 Cholesky + inverse by the
-// rider block that finishes its slab LAST.  Riders need nothing from the projection and vice versa,
-// so riding along costs no launch and no event, and - being shorter than the GEMM beside them - no
-// time.  The slab hand-off between rider blocks is the split-K reduction of the CDNA guide (G16) in its write-through
+// Optional riders of the projection launch (blocks 0..gp_riders(nb)-1): the whole small-system factorisation
+// of the dual form (N <= 128):  K = lambda S^-1 + C C^T  (f64 MFMA over the d features, GP_NB feature slices per
+// 64 x 64 tile of the system x 2 wave quads), then the Cholesky + block inverses by the rider block that finishes
+// its slab LAST.  Riders need nothing from the projection and vice versa, so riding along costs no launch and no
+// event.  The slab hand-off between rider blocks is the split-K reduction of the CDNA guide (G16) in its write-through
 // form: sc1 slab stores -> per-wave vmcnt(0) -> barrier -> one lane draws a relaxed agent-scope ticket; the block
 // drawing the last ticket reads all slabs with sc1 loads (summed in slab order: bit-repeatable) - no release / acquire
-// fence on either side (st_sc1 below).  Correct for any placement of the rider blocks; the ticket word is zero at
-// creation and reset by its last taker.
+// fence on either side (st_sc1 below).  Correct for any placement of the rider blocks.
+//
+// Hand-off words (h->ticket, all zero between launches - nothing of the protocol lives in the kernel arguments, so a
+// launch can be captured into a hipGraph and replayed):
+//   [0] arrival counter of the Gram riders       (reset by the block that draws the last ticket)
+//   [1] stage word of the factorising block:  1 = L_00^-1 is in memory (two-block systems), 2 = every factor block is
+//   [2] completion counter of the solve riders   (the last one to finish resets [1] and [2])
 struct GramPotrfJob {
   const float* C;       // [N, d]; null = no riders
   const float* s;       // [N]
   int N;
   float lamb;
   double* slabs;        // [tiles * GP_NB][64][64] partial Grams
-  unsigned* ticket;     // one word, zero between launches
-  double* Lmat;         // [n, n], n = 64 * nb
+  unsigned* ticket;     // the three hand-off words
+  double* Lmat;         // [n, n], n = 64 * nb (only block (1, 0) is written: L_10 of a two-block system)
   double* Linv;         // [nb][64][64]
   int* status;
-  double* M;            // [n, n] assembled system (nb > 1 only)
   int nb;               // 64-blocks of the dual system handled by the riders: 1 or 2
-  float* R;             // [N_edit, d] rows of K^-1 C, written by the solve riders (null: no solve riders)
+  float* R;             // [N_edit, d] rows of K^-1 C, written by the solve riders
   int N_edit;
-  unsigned seq;         // value of ticket[1] that announces THIS launch's factorisation
 };
 
 constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of the system (split over the feature axis)
@@ -187,36 +245,65 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
 __device__ __forceinline__ double ld_sc1(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same accesses 16 bytes wide (buffer_load/store_dwordx4 ... sc1; cache-policy bit 4 = sc1 on gfx950).  A CU
+// sustains only ~10 KB/us of 8-byte L1-bypassing loads (70 KB of slabs: 6.5 us of the chain): the wide form halves the
+// requests per byte.  Out-of-range offsets read as zero without touching memory - that is the mask.
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned SC1_OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sc1_rsrc(const double* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double2_t ld_sc1_x2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ void st_sc1_x2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double2_t v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), r, byte_off, 0, 16 /* sc1 */);
+}
 
-// The factorising block tells the solve riders that L / L^-1 of this launch are in memory: all its stores drained,
-// one agent-scope release, then the sequence word (the hand-off recipe of the CDNA guide, Guideline 16).
-// `fence`: the payload was written with plain stores (the 128 x 128 path shares its tile bodies with the launch chain)
-// and needs the agent-scope release; the single-tile path stores L / L^-1 write-through and skips it.
-__device__ __forceinline__ void announce_factor(const GramPotrfJob& j, bool fence) {
+// The factorising block tells the solve riders how far the factorisation of THIS launch has come: all its
+// (write-through) stores drained, a barrier, then the stage word.
+__device__ __forceinline__ void publish_stage(const GramPotrfJob& j, unsigned stage) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(j.ticket + 1, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane polls the stage word (relaxed, with s_sleep); the block passes a barrier afterwards and reads the payload
+// with sc1 loads.  A factorising block that never ran cannot happen with in-order dispatch: reported, not hung on.
+__device__ __forceinline__ void wait_stage(const GramPotrfJob& j, unsigned stage) {
   if (threadIdx.x == 0) {
-    if (fence) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned spins = 0;
+    while (__hip_atomic_load(j.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stage) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 24)) {                          // ~ seconds
+        atomicCAS(j.status, 0, -1);
+        break;
+      }
     }
-    __hip_atomic_store(j.ticket + 1, j.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Solve riders (blocks after the Gram riders, one per SV_COLS = 32 columns of R): wait for the factorisation of THIS launch,
-// then  R[:, cols] = rows 0..N_edit-1 of  L^-T L^-1 C[:, cols]  with the inverted diagonal blocks - the triangular
-// solves that used to be a launch of their own between the projection and the update.  f64 tiles in LDS (stride SV_LD),
-// 8 waves x one 16 x 16 MFMA tile, contraction over the non-zero part of the triangular operand (sv_prod).
+// Solve riders (one per SV_COLS = 32 columns of R: the Gram riders that did NOT draw the last ticket take the first
+// column blocks, dedicated blocks behind them the rest): wait for the factorisation of THIS launch, then
+//   R[:, cols] = rows 0..N_edit-1 of  L^-T L^-1 C[:, cols]
+// with the inverted diagonal blocks - the triangular solves that used to be a launch of their own between the projection
+// and the update.  f64 tiles in LDS (matrices: stride SV_LD, the 32-column vectors: stride SV_VLD), 8 waves x one
+// 16 x 16 MFMA tile, contraction over the non-zero part of the triangular operand (sv_prod).  A two-block system keeps
+// all three factor blocks (L_00^-1, L_10, L_11^-1) resident, so its six products run back to back; the first of them
+// (Y_0 = L_00^-1 C_0) already starts at stage 1, while block 1 is still being factored.
 // ---------------------------------------------------------------------------------------------
 constexpr int SV_LD = 66;
-constexpr int SV_COLS = 32;     // columns of R per solve rider: 8 waves x one 16 x 16 tile, twice as many riders as 64 would give
+constexpr int SV_VLD = 34;
+constexpr int SV_COLS = 32;     // columns of R per solve rider: 8 waves x one 16 x 16 tile
 constexpr size_t SV_TILE = (size_t)64 * SV_LD * sizeof(double);
-__host__ __device__ constexpr size_t sv_smem(int nb) { return (nb <= 1 ? 3 : 4) * SV_TILE; }
+constexpr size_t SV_VTILE = (size_t)64 * SV_VLD * sizeof(double);
+__host__ __device__ constexpr size_t sv_smem(int nb) { return nb <= 1 ? SV_TILE + 2 * SV_VTILE : 3 * SV_TILE + 3 * SV_VTILE; }
 
-// dst = base - / + op(A) * B :  A [64][64], B / dst / base [64][SV_COLS] are LDS tiles of stride SV_LD; TA: op(A)[i][k] =
-// A[k][i].  B is read as [k][col].  base == nullptr: dst = op(A) B.  (dst may alias base, never A or B.)
+// dst = base - / + op(A) * B :  A [64][64] (stride SV_LD), B / dst / base [64][SV_COLS] (stride SV_VLD) are LDS tiles; TA:
+// op(A)[i][k] = A[k][i].  B is read as [k][col].  base == nullptr: dst = op(A) B.  (dst may alias base, never A or B.)
 // TRI: A is LOWER triangular (an inverted diagonal block) - the 16-row block rb of op(A) B only contracts over
 // k < 16 (rb + 1) (TA: k >= 16 rb).  One 16 x 16 tile per wave; the waves of a SIMD (w, w + 4) take row blocks rb and
 // 3 - rb, so every SIMD issues 20 of the 32 MFMAs a full contraction would.  (A 64 x 64 x 64 f64 product is MFMA-bound
@@ -235,7 +322,7 @@ __device__ __forceinline__ void sv_prod(double* dst, const double* A, const doub
   for (int kb = 0; kb < 16; ++kb) {
     const int t = 4 * kb + kk;
     fa[kb] = TA ? A[t * SV_LD + row0 + r] : A[(row0 + r) * SV_LD + t];
-    fb[kb] = B[t * SV_LD + col0 + r];
+    fb[kb] = B[t * SV_VLD + col0 + r];
   }
 #pragma unroll
   for (int kb = 0; kb < 16; ++kb)
@@ -243,125 +330,129 @@ __device__ __forceinline__ void sv_prod(double* dst, const double* A, const doub
   // D layout: row = kk + 4q, col = r
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int o = (row0 + kk + 4 * q) * SV_LD + col0 + r;
+    const int o = (row0 + kk + 4 * q) * SV_VLD + col0 + r;
     dst[o] = (base ? base[o] : 0.0) + sign * acc[q];
   }
 }
 
 template <int D>
 __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char* smem_raw, int colblk) {
-  double* Ms = (double*)smem_raw;                       // the matrix operand of the current product
-  double* W0 = Ms + 64 * SV_LD;
-  double* W1 = W0 + 64 * SV_LD;
-  double* W2 = W1 + 64 * SV_LD;                         // (nb == 2 only)
+  double* M0 = (double*)smem_raw;                         // L_00^-1
+  double* M1 = M0 + 64 * SV_LD;                           // L_10      (two-block systems)
+  double* M2 = M1 + 64 * SV_LD;                           // L_11^-1
+  double* V0 = j.nb == 1 ? M1 : M2 + 64 * SV_LD;          // three 64 x 32 vector tiles (one-block systems use two)
+  double* V1 = V0 + 64 * SV_VLD;
+  double* V2 = V1 + 64 * SV_VLD;
   const int tid = threadIdx.x;
   const int n = 64 * j.nb;
-  // 64 concepts x this block's 64 columns of C (rows >= N are zero) -> LDS, widened to f64.  Needs nothing from the
+  // 64 concepts x this block's 32 columns of C (rows >= N are zero) -> LDS, widened to f64.  Needs nothing from the
   // factorisation: loaded before the wait.
-  auto load_c = [&](double* Wt, int kblk) {
-    for (int e = tid; e < 64 * (SV_COLS / 4); e += 512) {
-      const int r = e / (SV_COLS / 4), c4 = (e % (SV_COLS / 4)) << 2;
-      const int row = kblk * 64 + r;
-      float4_t v = {0.f, 0.f, 0.f, 0.f};
-      if (row < j.N) v = *(const float4_t*)(j.C + (size_t)row * D + colblk * SV_COLS + c4);
-      Wt[r * SV_LD + c4] = (double)v[0];
-      Wt[r * SV_LD + c4 + 1] = (double)v[1];
-      Wt[r * SV_LD + c4 + 2] = (double)v[2];
-      Wt[r * SV_LD + c4 + 3] = (double)v[3];
-    }
+  auto load_c = [&](double* Vt, int kblk) {
+    const int r = tid >> 3, c4 = (tid & 7) << 2;          // 64 rows x 8 float4: exactly one per thread
+    const int row = kblk * 64 + r;
+    float4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (row < j.N) v = *(const float4_t*)(j.C + (size_t)row * D + colblk * SV_COLS + c4);
+    Vt[r * SV_VLD + c4] = (double)v[0];
+    Vt[r * SV_VLD + c4 + 1] = (double)v[1];
+    Vt[r * SV_VLD + c4 + 2] = (double)v[2];
+    Vt[r * SV_VLD + c4 + 3] = (double)v[3];
   };
-  auto load_m = [&](const double* G, int ld) {            // a 64 x 64 block of a row-major f64 matrix -> Ms
-    if (j.nb == 1) {                                      // published write-through: read it past the L1
-      double v[8];
+  // a 64 x 64 block of a row-major f64 matrix, published write-through: read it past the L1, 16 bytes per lane, all
+  // loads in flight at once
+  auto fetch_m = [&](const double* G, int ld, double2_t (&v)[4]) {
+    const __amdgpu_buffer_rsrc_t r = sc1_rsrc(G, (unsigned)(64 * ld * sizeof(double)));
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int e = tid + 512 * p;
-        v[p] = ld_sc1(G + (size_t)(e >> 6) * ld + (e & 63));
-      }
+    for (int p = 0; p < 4; ++p) {
+      const int e = 2 * (tid + 512 * p);
+      v[p] = ld_sc1_x2(r, (unsigned)(((e >> 6) * ld + (e & 63)) * sizeof(double)));
+    }
+  };
+  auto park_m = [&](double* Ms, const double2_t (&v)[4]) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int e = tid + 512 * p;
-        Ms[(e >> 6) * SV_LD + (e & 63)] = v[p];
-      }
-      return;
-    }
-    for (int e = tid; e < 64 * 32; e += 512) {
-      const int r = e >> 5, c2 = (e & 31) << 1;
-      typedef double double2_t __attribute__((ext_vector_type(2)));
-      const double2_t v = *(const double2_t*)(G + (size_t)r * ld + c2);
-      Ms[r * SV_LD + c2] = v[0];
-      Ms[r * SV_LD + c2 + 1] = v[1];
+    for (int p = 0; p < 4; ++p) {
+      const int e = 2 * (tid + 512 * p);
+      *(double2_t*)&Ms[(e >> 6) * SV_LD + (e & 63)] = v[p];
     }
   };
-  auto store_r = [&](const double* Wt, int kblk) {        // rows of X -> R (fp32), rows < N_edit only
-    for (int e = tid; e < 64 * (SV_COLS / 4); e += 512) {
-      const int r = e / (SV_COLS / 4), c4 = (e % (SV_COLS / 4)) << 2;
-      const int row = kblk * 64 + r;
-      if (row < j.N_edit)
-        *(float4_t*)(j.R + (size_t)row * D + colblk * SV_COLS + c4) =
-            (float4_t){(float)Wt[r * SV_LD + c4], (float)Wt[r * SV_LD + c4 + 1], (float)Wt[r * SV_LD + c4 + 2],
-                       (float)Wt[r * SV_LD + c4 + 3]};
-    }
+  auto store_r = [&](const double* Vt, int kblk) {        // rows of X -> R (fp32), rows < N_edit only
+    const int r = tid >> 3, c4 = (tid & 7) << 2;
+    const int row = kblk * 64 + r;
+    if (row < j.N_edit)
+      *(float4_t*)(j.R + (size_t)row * D + colblk * SV_COLS + c4) =
+          (float4_t){(float)Vt[r * SV_VLD + c4], (float)Vt[r * SV_VLD + c4 + 1], (float)Vt[r * SV_VLD + c4 + 2],
+                     (float)Vt[r * SV_VLD + c4 + 3]};
   };
-  DBG(0);
-  load_c(W0, 0);
-  DBG(1);
-  // ---- wait for this launch's factorisation: one lane polls (relaxed, with s_sleep), one acquire, then plain loads
-  if (tid == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(j.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != j.seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 24)) {                          // ~ seconds: the factorising block never ran (cannot happen
-        atomicCAS(j.status, 0, -1);                        //   with in-order dispatch); report instead of hanging
-        break;
+  auto finish = [&]() {
+    // every rider counts itself out; the last one re-arms the stage word and the counter for the next launch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(j.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)(D / SV_COLS) - 1) {
+        __hip_atomic_store(j.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(j.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (j.nb != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  DBG(2);
-  const double* Linv0 = j.Linv;
+  };
+  DBG(8);
+  load_c(V0, 0);
+  if (j.nb == 2) load_c(V1, 1);
+  DBG(9);
+  double2_t mv[4];
   if (j.nb == 1) {
-    load_m(Linv0, 64);
+    wait_stage(j, 2);
+    DBG(10);
+    fetch_m(j.Linv, 64, mv);
+    park_m(M0, mv);
     __syncthreads();
-    DBG(3);
-    sv_prod<false, true>(W1, Ms, W0, nullptr, 1.0);       // Y = L^-1 C
+    DBG(11);
+    sv_prod<false, true>(V1, M0, V0, nullptr, 1.0);       // Y = L^-1 C
     __syncthreads();
-    sv_prod<true, true>(W0, Ms, W1, nullptr, 1.0);        // X = L^-T Y
+    sv_prod<true, true>(V0, M0, V1, nullptr, 1.0);        // X = L^-T Y
     __syncthreads();
-    DBG(4);
-    store_r(W0, 0);
-    DBG(5);
+    DBG(12);
+    store_r(V0, 0);
+    DBG(13);
+    finish();
     return;
   }
-  const double* Linv1 = j.Linv + 4096;
-  const double* L10 = j.Lmat + (size_t)64 * n;            // block (1, 0) of L
-  load_m(Linv0, 64);
+  // ---- two-block system:  Y0 = A C0 | Y1 = Dg (C1 - L10 Y0) | X1 = Dg^T Y1 | X0 = A^T (Y0 - L10^T X1),  A = L_00^-1, Dg = L_11^-1
+  wait_stage(j, 1);
+  fetch_m(j.Linv, 64, mv);
+  park_m(M0, mv);
   __syncthreads();
-  sv_prod<false, true>(W1, Ms, W0, nullptr, 1.0);         // Y0 = L00^-1 C0
+  sv_prod<false, true>(V2, M0, V0, nullptr, 1.0);         // Y0 -> V2
+  DBG(10);
+  wait_stage(j, 2);                                       // (its barrier also closes the product above)
+  {
+    double2_t mw[4];
+    fetch_m(j.Lmat + (size_t)64 * n, n, mv);              // block (1, 0) of L
+    fetch_m(j.Linv + 4096, 64, mw);
+    park_m(M1, mv);
+    park_m(M2, mw);
+  }
   __syncthreads();
-  load_c(W0, 1);
-  load_m(L10, n);
+  DBG(11);
+  sv_prod<false, false>(V1, M1, V2, V1, -1.0);            // C1 - L10 Y0 -> V1
   __syncthreads();
-  sv_prod<false, false>(W0, Ms, W1, W0, -1.0);            // C1 - L10 Y0
+  sv_prod<false, true>(V0, M2, V1, nullptr, 1.0);         // Y1 -> V0 (C0 is dead)
   __syncthreads();
-  load_m(Linv1, 64);
+  sv_prod<true, true>(V1, M2, V0, nullptr, 1.0);          // X1 -> V1
   __syncthreads();
-  sv_prod<false, true>(W2, Ms, W0, nullptr, 1.0);         // Y1
+  store_r(V1, 1);
+  sv_prod<true, false>(V2, M1, V1, V2, -1.0);             // Y0 - L10^T X1 -> V2
   __syncthreads();
-  sv_prod<true, true>(W0, Ms, W2, nullptr, 1.0);          // X1 = L11^-T Y1
+  sv_prod<true, true>(V0, M0, V2, nullptr, 1.0);          // X0 -> V0
   __syncthreads();
-  store_r(W0, 1);
-  load_m(L10, n);
-  __syncthreads();
-  sv_prod<true, false>(W1, Ms, W0, W1, -1.0);             // Y0 - L10^T X1
-  __syncthreads();
-  load_m(Linv0, 64);
-  __syncthreads();
-  sv_prod<true, true>(W2, Ms, W1, nullptr, 1.0);          // X0
-  __syncthreads();
-  store_r(W2, 0);
+  DBG(12);
+  store_r(V0, 0);
+  DBG(13);
+  finish();
 }
+
+// LDS of the block that factors a two-block system: the elimination scratch (the K_00 staging tile aliases it, and
+// later the K_11 tile), the K_10 -> L_10 tile and the L_00^-1 -> Schur complement tile
+constexpr size_t GP_F2_SMEM = sizeof(Potrf64Scratch) + 2 * 64 * LD * sizeof(double);
 
 template <int D>
 __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned char* smem_raw) {
@@ -371,11 +462,11 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   constexpr size_t AB_BYTES = (size_t)4 * 64 * GP_LD * sizeof(float);
   double* P1 = (double*)(smem_raw + AB_BYTES);                    // [64][GP_TLD]
   // the factorisation scratch ALIASES the Gram staging (As, Bs, P1 are dead once the slab is published), so a
-  // single-tile rider needs 74 KB and two workgroups of the launch fit a CU
+  // single-tile rider needs 74 KB
   Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
   static_assert(sizeof(Potrf64Scratch) <= AB_BYTES + 64 * GP_TLD * sizeof(double), "scratch must fit the Gram staging");
   // (all LDS in the dynamic region: a static __shared__ would shift its 16-byte alignment)
-  unsigned* s_last_p = (unsigned*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double));
+  unsigned* s_tick_p = (unsigned*)(smem_raw + AB_BYTES + 64 * GP_TLD * sizeof(double));
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = w >> 2, wq = w & 3;
   const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
@@ -460,7 +551,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   if (tid == 0) {
     // (slabs went out write-through and are read back past the L1: no release / acquire fence - see st_sc1)
     const unsigned t = __hip_atomic_fetch_add(j.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_last_p = (t == (unsigned)nriders - 1) ? 1u : 0u;
+    *s_tick_p = t;
     if (t == (unsigned)nriders - 1) {
       __hip_atomic_store(j.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       *j.status = 0;
@@ -468,37 +559,66 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   }
   __syncthreads();
   DBG(2);
-  if (!*s_last_p) return;
+  const unsigned my_ticket = *s_tick_p;
+  __syncthreads();                                                // everybody has read the ticket: the LDS is free
+  if (my_ticket != (unsigned)nriders - 1) {
+    // not the last arriver: this block's Gram duty is over - it becomes the solve rider of column block `ticket`
+    solve_rider<D>(j, smem_raw, (int)my_ticket);
+    return;
+  }
   auto diag_term = [&](int row) -> double {
     const float sv = (row < j.N) ? j.s[row] : 1.f;
     return (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
   };
-  if (j.nb == 1) {
-    // last arriver: all 8 waves factor - waves 0-3 carry the matrix tiles, waves 4-7 the tiles of L^-1.
-    // The GP_NB slabs are summed by ALL 512 threads (8 elements each, every load independent and in flight at
-    // once, fixed slab order: bit-repeatable) into the LDS tile the matrix waves then pick their 4x4 tiles from.
-    double* Ksum = (double*)smem_raw;                             // [64][GP_TLD] (the Gram staging is dead)
-    {
-      // only what the factorisation reads: the 4 x 4 tiles of the lower triangle, rows of real concepts (the padding
-      // rows are identity) - a 50-concept system moves 35 % of the slab bytes
-      const int n4 = (j.N + 3) & ~3;
-      double v[GP_NB][8];
+  // Last arriver: all 8 waves factor.  The GP_NB slabs of a tile are summed by ALL 512 threads (8 elements each, every
+  // load independent and in flight at once, fixed slab order: bit-repeatable).  Only what the factorisation reads is
+  // fetched: rows of real concepts (the padding rows are the identity) and, for the diagonal tiles, the 4 x 4 tiles
+  // of the lower triangle.
+  const __amdgpu_buffer_rsrc_t slab_r = sc1_rsrc(j.slabs, (unsigned)(nriders * 4096 * sizeof(double)));
+  const __amdgpu_buffer_rsrc_t linv_r = sc1_rsrc(j.Linv, (unsigned)(j.nb * 4096 * sizeof(double)));
+  // thread -> element pairs e, e + 1 with e = 2 (tid + 512 p): row e >> 6, columns e & 63 (even) and the next
+  auto fetch_tile = [&](int t, int nrow4, bool lower, double2_t (&v)[GP_NB][4]) {
 #pragma unroll
-      for (int b = 0; b < GP_NB; ++b)
+    for (int b = 0; b < GP_NB; ++b)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          const int e = tid + 512 * p, row = e >> 6, col = e & 63;
-          v[b][p] = (row < n4 && col <= (row | 3)) ? ld_sc1(&j.slabs[(size_t)b * 4096 + e]) : 0.0;
-        }
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int e = tid + 512 * p, row = e >> 6, col = e & 63;
-        double acc = v[0][p];
-#pragma unroll
-        for (int b = 1; b < GP_NB; ++b) acc += v[b][p];
-        if (row == col) acc = (row < n4 ? acc : 0.0) + diag_term(row);
-        Ksum[row * GP_TLD + col] = acc;
+      for (int p = 0; p < 4; ++p) {
+        const int e = 2 * (tid + 512 * p), row = e >> 6, col = e & 63;
+        const bool live = row < nrow4 && (!lower || col <= (row | 3));       // (col even, row | 3 odd: both elements alike)
+        v[b][p] = ld_sc1_x2(slab_r, live ? (unsigned)(((t * GP_NB + b) * 4096 + e) * sizeof(double)) : SC1_OOB);
       }
+  };
+  auto reduce_tile = [&](const double2_t (&v)[GP_NB][4], int nrow4, int row_base, bool diag, double2_t (&out)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int e = 2 * (tid + 512 * p), row = e >> 6, col = e & 63;
+      double2_t a = v[0][p];
+#pragma unroll
+      for (int b = 1; b < GP_NB; ++b) a += v[b][p];                          // fixed slab order: bit-repeatable
+      if (diag && row == col) a[0] = (row < nrow4 ? a[0] : 0.0) + diag_term(row_base + row);
+      if (diag && row == col + 1) a[1] = (row < nrow4 ? a[1] : 0.0) + diag_term(row_base + row);
+      out[p] = a;
+    }
+  };
+  auto park_tile = [&](double* tile, const double2_t (&o)[4]) {            // -> a [64][GP_TLD] LDS tile
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int e = 2 * (tid + 512 * p);
+      *(double2_t*)&tile[(e >> 6) * GP_TLD + (e & 63)] = o[p];
+    }
+  };
+  auto store_linv = [&](int blk, int row, int col, const double (&v)[4]) {   // 4 consecutive columns of a row of L_blk^-1
+    const unsigned off = (unsigned)((blk * 4096 + row * 64 + col) * sizeof(double));
+    st_sc1_x2(linv_r, off, (double2_t){v[0], v[1]});
+    st_sc1_x2(linv_r, off + 16, (double2_t){v[2], v[3]});
+  };
+  double* Ksum = (double*)smem_raw;                               // [64][GP_TLD] (the Gram staging is dead)
+  if (j.nb == 1) {
+    {
+      const int n4 = (j.N + 3) & ~3;
+      double2_t v[GP_NB][4], o[4];
+      fetch_tile(0, n4, true, v);
+      reduce_tile(v, n4, 0, true, o);
+      park_tile(Ksum, o);
     }
     __syncthreads();
     DBG(3);
@@ -506,69 +626,144 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
                   const pk_d2 a = *(const pk_d2*)&Ksum[row * GP_TLD + col], b = *(const pk_d2*)&Ksum[row * GP_TLD + col + 2];
                   v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
                 },
-                [&](int row, int col, const double (&v)[4]) {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) st_sc1(&j.Linv[row * 64 + col + e], v[e]);
-                },
+                [&](int row, int col, const double (&v)[4]) { store_linv(0, row, col, v); },
                 sc, tid, j.status, 0, j.N);
     DBG(4);
-    announce_factor(j, false);
+    publish_stage(j, 2);
     DBG(5);
     return;
   }
-  // nb == 2: the last arriver assembles the 128 x 128 system and runs the blocked factorisation that
-  // uce_solve.hip spreads over a chain of launches (same tile bodies), alone, under the projection GEMM:
-  // factor (0,0) -> tile (1,1) of step 0 (forms L_10, updates and factors block 1).
-  const int n = 64 * j.nb;
-  for (int t = 0; t < 3; ++t) {
-    const int gi = t == 0 ? 0 : 1, gk = t == 2 ? 1 : 0;
-    for (int e = tid; e < 64 * 64; e += 512) {
-      const int r = e >> 6, cc = e & 63;
-      double v = ld_sc1(&j.slabs[(size_t)(t * GP_NB) * 4096 + e]);
-#pragma unroll
-      for (int b = 1; b < GP_NB; ++b) v += ld_sc1(&j.slabs[(size_t)(t * GP_NB + b) * 4096 + e]);        // fixed order
-      const int grow = gi * 64 + r, gcol = gk * 64 + cc;
-      if (grow == gcol) v += diag_term(grow);
-      j.M[(size_t)grow * n + gcol] = v;
-    }
+  // ---- nb == 2: the blocked factorisation of the 128 x 128 system, alone, under the projection GEMM, entirely in
+  // LDS / registers (the launch-chain form of uce_solve.hip goes through memory between its steps):
+  //   K_00 -> L_00^-1 (stage 1) | L_10 = K_10 L_00^-T | S = K_11 - L_10 L_10^T -> L_11^-1 (stage 2)
+  static_assert(GP_TLD == LD, "the staging tile and the step tiles share one stride");
+  double (*Mi)[LD] = (double (*)[LD])(smem_raw + sizeof(Potrf64Scratch));                           // K_10 -> L_10
+  double (*Li)[LD] = (double (*)[LD])(smem_raw + sizeof(Potrf64Scratch) + 64 * LD * sizeof(double));  // L_00^-1 -> S
+  const int n = 128, n2 = j.N - 64;                               // real concepts of block 1 (1..64)
+  const int n4b = (n2 + 3) & ~3;
+  // K_00 is reduced and factored while the slab loads of K_10 land (64 VGPRs of them ride through the elimination), the
+  // loads of K_11 are issued behind the factor and land under the L_10 product - one CU sustains only ~10 KB/us of
+  // L1-bypassing loads: summed before the factor, as the first form of this block did, they were 6 us of the chain
+  double2_t vb[GP_NB][4], vc[GP_NB][4];
+  {
+    double2_t va[GP_NB][4], o[4];
+    fetch_tile(0, 64, true, va);                                  // K_00
+    fetch_tile(1, n4b, false, vb);                                // K_10: lands during the first factor (64 VGPRs pinned)
+    reduce_tile(va, 64, 0, true, o);
+    park_tile(Ksum, o);
   }
-  __syncthreads();                                    // the block's own global writes -> visible to the block
-  potrf_first_body8(j.M, n, 1, 0, j.Lmat, j.Linv, j.status, (Potrf64Scratch*)smem_raw, j.N);
   __syncthreads();
-  potrf_step_tile(j.M, n, 0, 1, 1, j.Lmat, j.Linv, j.status, smem_raw, j.N);
-  announce_factor(j, true);
+  DBG(3);
+  UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+                const pk_d2 a = *(const pk_d2*)&Ksum[row * GP_TLD + col], b = *(const pk_d2*)&Ksum[row * GP_TLD + col + 2];
+                v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+              },
+              [&](int row, int col, const double (&v)[4]) {
+                store_linv(0, row, col, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Li[row][col + e] = v[e];
+              },
+              sc, tid, j.status, 0, 64);
+  fetch_tile(2, n4b, true, vc);                                   // K_11: lands during the L_10 product below
+  {
+    double2_t o[4];
+    reduce_tile(vb, n4b, 64, false, o);
+    park_tile(&Mi[0][0], o);
+  }
+  publish_stage(j, 1);                                            // (its barrier: L_00^-1 is in LDS, the scratch is dead)
+  DBG(4);
+  {
+    // both 64 x 64 x 64 products on all 8 waves: wave (wq, half) owns rows wr .. wr+31 x columns wc + 16 half .. +15
+    const int wc8 = wc + 16 * half;
+    auto prod = [&](double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign) {
+      const int r = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+      for (int kb = 0; kb < 16; ++kb) {
+        const int t = kb * 4 + kk;
+        const double b0 = Q[wc8 + r][t];
+        a2[0] = mfma_f64(sign * P[wr + r][t], b0, a2[0]);
+        a2[1] = mfma_f64(sign * P[wr + 16 + r][t], b0, a2[1]);
+      }
+    };
+    // D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4r, col = lane&15
+    const int oc = wc8 + (lane & 15), orq = lane >> 4;
+    double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
+    prod(pp, Mi, Li, 1.0);                                        // L_10 = K_10 L_00^-T
+    double (*S)[LD] = (double (*)[LD])smem_raw;                   // K_11 -> the (dead) scratch region
+    {
+      double2_t k11[4];
+      reduce_tile(vc, n4b, 64, true, k11);
+      park_tile(&S[0][0], k11);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Mi[wr + m * 16 + orq + 4 * r][oc] = pp[m][r];
+    __syncthreads();
+    {
+      const __amdgpu_buffer_rsrc_t l10_r = sc1_rsrc(j.Lmat + (size_t)64 * n, (unsigned)(64 * n * sizeof(double)));
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int e = 2 * (tid + 512 * p);
+        st_sc1_x2(l10_r, (unsigned)(((e >> 6) * n + (e & 63)) * sizeof(double)), *(const double2_t*)&Mi[e >> 6][e & 63]);
+      }
+    }
+    double4_t sacc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[m][r] = S[wr + m * 16 + orq + 4 * r][oc];
+    prod(sacc, Mi, Mi, -1.0);                                     // S = K_11 - L_10 L_10^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Li[wr + m * 16 + orq + 4 * r][oc] = sacc[m][r];
+    __syncthreads();
+  }
+  UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+                const pk_d2 a = *(const pk_d2*)&Li[row][col], b = *(const pk_d2*)&Li[row][col + 2];
+                v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+              },
+              [&](int row, int col, const double (&v)[4]) { store_linv(1, row, col, v); },
+              sc, tid, j.status, 64, n2);
+  publish_stage(j, 2);
+  DBG(5);
 }
 
 constexpr size_t GP_SMEM1 = (size_t)4 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + 16;   // one system tile
-constexpr size_t GP_SMEM = GP_SMEM1 > POTRF_STEP_SMEM + 16 ? GP_SMEM1 : POTRF_STEP_SMEM + 16;              // 128 x 128 systems
 __host__ __device__ constexpr size_t gp_smem(int nb) {
-  const size_t g = nb <= 1 ? GP_SMEM1 : GP_SMEM;
+  const size_t g = nb <= 1 ? GP_SMEM1 : (GP_SMEM1 > GP_F2_SMEM ? GP_SMEM1 : GP_F2_SMEM);
   return g > sv_smem(nb) ? g : sv_smem(nb);
 }
+// blocks of the launch that do not project: the Gram riders plus the DEDICATED solve riders (the Gram riders that
+// do not factor become solve riders themselves)
+__host__ __device__ constexpr int lr_rider_blocks(int nb, int d) { return gp_riders(nb) + d / SV_COLS - (gp_riders(nb) - 1); }
 
-template <int D, int MT>
+template <int D, int MT, int CT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_project(
     const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ Csub,
     float* __restrict__ T, long rows, int Ne, int NEP, GramPotrfJob job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_gram = job.C ? gp_riders(job.nb) : 0;
-  const int n_solve = (job.C && job.R) ? D / SV_COLS : 0;
-  const int has_rider = n_gram + n_solve;
+  const int has_rider = job.C ? lr_rider_blocks(job.nb, D) : 0;
   if ((int)blockIdx.x < n_gram) {
     gram_potrf_rider<D>(job, smem_raw);
     return;
   }
   if ((int)blockIdx.x < has_rider) {
-    solve_rider<D>(job, smem_raw, (int)blockIdx.x - n_gram);
+    solve_rider<D>(job, smem_raw, (int)blockIdx.x - 1);   // column blocks 0 .. n_gram - 2 belong to the Gram riders
     return;
   }
   DBG(0);
   float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD]
   constexpr int M0 = (MT + 1) / 2;
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
-    project_body<D, MT, M0>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, has_rider);
-  else
-    project_body<D, MT, MT - M0>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, has_rider);
+  {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
+      project_body_w<D, MT, M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, has_rider);
+    else
+      project_body_w<D, MT, MT - M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, has_rider);
+  }
   DBG(1);
 }
 
@@ -685,8 +880,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 //    addressing), no per-row branches.  (The scalar offset operand is not part of the hardware range
 //    check, hence base shifting instead of soffset.)
 // ---------------------------------------------------------------------------------------------
-typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0 ? bytes : 0, 0x00020000);
 }
@@ -795,44 +988,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   }
 }
 
-// rows / 16 tiles over 256 CUs with MT tiles per workgroup: time ~ ceil(workgroups / 256) * MT
-int pick_mt2(long rows) {
+// rows / 16 tiles over 256 CUs with MT tiles per workgroup: time ~ ceil(workgroups / 256) * MT.  `extra`: the rider
+// blocks of the launch - they hold a CU each while the chain runs, so a projection workgroup beyond 256 - extra would
+// start late and stretch the launch.
+int pick_mt2(long rows, int extra) {
   const long t16 = (rows + 15) / 16;
   int best = 8;
   long best_cost = -1;
   for (int mt = 8; mt >= 5; --mt) {
-    const long wgs = (t16 + mt - 1) / mt;
+    const long wgs = (t16 + mt - 1) / mt + extra;
     const long cost = ((wgs + 255) / 256) * mt;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt; }
   }
   return best;
 }
 
-template <int D, int MT>
+template <int D, int MT, int CT>
 int launch_project(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit,
                    int NEP64, const GramPotrfJob& job, hipStream_t st) {
-  size_t smem = (size_t)2 * (MT * 16 + 64) * PJ_LD * sizeof(float);
+  size_t smem = (size_t)2 * (MT * 16 + 64 * CT) * PJ_LD * sizeof(float);
   if (job.C && smem < gp_smem(job.nb)) smem = gp_smem(job.nb);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (const int tok = attr_once.first()) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project<D, MT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
+    attr_once.commit(tok);
   }
-  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? gp_riders(job.nb) + (job.R ? D / SV_COLS : 0) : 0);
-  hipLaunchKernelGGL((k_lr_project<D, MT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + (job.C ? lr_rider_blocks(job.nb, D) : 0);
+  hipLaunchKernelGGL((k_lr_project<D, MT, CT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows,
                      N_edit, NEP64, job);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
-template <int D>
+template <int D, int CT>
 int launch_project_d(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit,
                      int NEP64, const GramPotrfJob& job, hipStream_t st) {
-  switch (pick_mt2(rows)) {
-    case 5: return launch_project<D, 5>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
-    case 6: return launch_project<D, 6>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
-    case 7: return launch_project<D, 7>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
-    default: return launch_project<D, 8>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+  if constexpr (D == 2048) return launch_project<D, 5, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+  else switch (pick_mt2(rows, job.C ? lr_rider_blocks(job.nb, D) : 0)) {
+    case 5: return launch_project<D, 5, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+    case 6: return launch_project<D, 6, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+    case 7: return launch_project<D, 7, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
+    default: return launch_project<D, 8, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, job, st);
   }
 }
 
@@ -841,9 +1038,10 @@ int launch_update_v(const float* W_old, const float* T, const float* R, float* W
                     int NEP64, hipStream_t st) {
   const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_update<D, UP_MT, WPE>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   const long nwg = (rows + UP_MT * 16 - 1) / (UP_MT * 16);
   hipLaunchKernelGGL((k_lr_update<D, UP_MT, WPE>), dim3((unsigned)nwg), dim3(256), smem, st, W_old, T, R, W_new, rows,
@@ -884,30 +1082,35 @@ int launch_update_d(const float* W_old, const float* T, const float* R, float* W
 
 }  // namespace
 
-int lr_rider_max_n() {
-  static const int cap = getenv("UCE_RIDER_MAX_N") ? atoi(getenv("UCE_RIDER_MAX_N")) : 64 * GP_MAXB;
-  return cap < 64 * GP_MAXB ? cap : 64 * GP_MAXB;
-}
+int lr_rider_cap() { return 64 * GP_MAXB; }
 
 bool lowrank_split_supported(int d, int N_edit) {
   return (d == 768 || d == 1024 || d == 2048) && N_edit >= 1 && N_edit <= 256;
 }
 
-// X = Dm with Csub == nullptr, or X = G with Csub = C_e (D_e = G - C_e formed on the fly).  With `h`
-// and a dual system that is a single 64-block (N <= 64) the launch also builds and factors that
-// system (block 0): K = lamb S^-1 + C C^T -> h->Lmat (ld 64), h->Linv, h->status.
+// X = Dm with Csub == nullptr, or X = G with Csub = C_e (D_e = G - C_e formed on the fly).  With `h` (and N <= 128) the
+// launch also builds and factors the dual system in its rider blocks and solves for R = rows of K^-1 C:
+// K = lamb S^-1 + C C^T -> h->Linv (+ block (1, 0) of h->Lmat), h->status, R.  More than 64 edit concepts take the
+// 128-concept batches (one pass over W per 128 concepts).
 int launch_lr_project(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d,
                       int N_edit, hipStream_t st, uce_ctx* h, const float* C, const float* s, int N, float lamb, float* R) {
   const int NEP64 = (N_edit + 63) / 64 * 64;
   GramPotrfJob job{};
   if (h) {
     const int nb = (N + 63) / 64;
-    if (nb < 1 || nb > GP_MAXB) return UCE_EINVAL;
-    job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, h->M, nb, R, N_edit, ++h->seq};
+    if (nb < 1 || nb > GP_MAXB || !R || !C || !s) return UCE_EINVAL;
+    job = GramPotrfJob{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, nb, R, N_edit};
   }
-  if (d == 768) return launch_project_d<768>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
-  if (d == 1024) return launch_project_d<1024>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
-  if (d == 2048) return launch_project<2048, 5>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  const bool wide = NEP64 > 64;
+  if (d == 768)
+    return wide ? launch_project_d<768, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st)
+                : launch_project_d<768, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  if (d == 1024)
+    return wide ? launch_project_d<1024, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st)
+                : launch_project_d<1024, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  if (d == 2048)
+    return wide ? launch_project_d<2048, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st)
+                : launch_project_d<2048, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
   return UCE_EINVAL;
 }
 

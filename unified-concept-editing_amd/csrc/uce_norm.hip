@@ -213,6 +213,7 @@ extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void*
                                       void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
                                       uce_stream_t stream) {
   if (!h || !x || !gamma || !beta || !y || !ws || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (C % 8 || C % G || C > 8 * 256 * MAXO || N > 65535) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const int chunks = uce_groupnorm_chunks(HW);
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void k_geglu(const unsigned short* __restrict_
 
 extern "C" int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, int inner, int dtype, uce_stream_t stream) {
   if (!h || !x || !y || rows <= 0 || inner <= 0 || inner % 8) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const long total = rows * (inner / 8);
   long blocks = (total + 255) / 256;
@@ -360,6 +362,7 @@ extern "C" int uce_cfg_pndm_step(uce_handle_t h, const void* eps, int cfg, float
                                  const void* h3, const float* w, const void* sample, float cs, float ce, void* eps_out,
                                  void* prev_out, long n, int dtype, uce_stream_t stream) {
   if (!h || !eps || !w || !sample || !eps_out || !prev_out || n <= 0 || (n & 7)) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const long n8 = n / 8;
   long blocks = (n8 + 255) / 256;
@@ -379,6 +382,7 @@ extern "C" int uce_cfg_pndm_step(uce_handle_t h, const void* eps, int cfg, float
 extern "C" int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const void* bias, void* y, long pixels,
                                      int C, int dtype, uce_stream_t stream) {
   if (!h || !a || !y || pixels <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const long total = pixels * (C / 8);
   long blocks = (total + 255) / 256;
@@ -505,6 +509,7 @@ void launch_layernorm(const void* x, const void* res, const void* gamma, const v
 extern "C" int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const void* gamma, const void* beta,
                                  void* y, void* sum_out, long rows, int C, float eps, int dtype, uce_stream_t stream) {
   if (!h || !x || !gamma || !beta || !y || rows <= 0 || C <= 0 || C % 8) return UCE_EINVAL;
+  UCE_ENTER(h);
   if ((residual != nullptr) != (sum_out != nullptr)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const int units = C / 8;

@@ -282,9 +282,10 @@ int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_sattn<DHP, true>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
@@ -327,6 +328,7 @@ int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o,
 extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                              int Lk, int dh, float scale, int dtype, uce_stream_t stream) {
   if (!h || !q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (dh <= 0 || dh > 160 || (dh & 7)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   if (B > 65535 || H > 65535 || (long)B * H > 65535) return UCE_EINVAL;

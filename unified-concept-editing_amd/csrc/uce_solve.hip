@@ -220,11 +220,12 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
   const size_t smem_first = sizeof(Potrf64Scratch);
   static_assert(sizeof(Potrf64Scratch) <= POTRF_STEP_SMEM, "scratch must fit the three tile regions");
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_first, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem_first));
+    attr_once.commit(tok);
   }
   hipLaunchKernelGGL(k_potrf_first, dim3(1), dim3(512), smem_first, st, (const double*)M, n, nsplit,
                      slab_stride, h->Lmat, h->Linv, h->status, n_valid);
@@ -245,20 +246,20 @@ int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st, int n_valid) {
 
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
                     float* out, int out_rows, hipStream_t st, double* scratch) {
-  // UCE_TRISOLVE_VARIANT=0 keeps the substitution kernel at every size (A/B measurements)
-  static const int variant = getenv("UCE_TRISOLVE_VARIANT") ? atoi(getenv("UCE_TRISOLVE_VARIANT")) : 1;
-  if (variant && scratch && n >= 192 && m % 64 == 0)
+  // UCE_TRISOLVE_VARIANT=0 (read at uce_create) keeps the substitution kernel at every size (A/B measurements)
+  if (h->sw.trisolve_variant && scratch && n >= 192 && m % 64 == 0)
     return launch_trisolve_inv(h, n, m, rhs64, rhs32, rhs_rows, out, out_rows, scratch, st);
   const bool use_lds = n <= 1024;
   const size_t smem = 64 * 16 * 8 + (use_lds ? (size_t)n * 16 * 8 : 0);
   double* Yg = use_lds ? nullptr : h->Yg;
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     const int cap = 64 * 16 * 8 + 1024 * 16 * 8;
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trisolve<true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trisolve<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_once.commit(tok);
   }
   const dim3 grid(m / 16);
   if (rhs32)

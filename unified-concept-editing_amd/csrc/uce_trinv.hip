@@ -219,12 +219,13 @@ int launch_trisolve_inv(uce_ctx* h, int n, int m, const double* rhs64, const flo
   const int nb = n / 64;
   const size_t smem = TRINV_SMEM;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_merge<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_merge<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_once.commit(tok);
   }
   for (int S = 1; S < nb; S *= 2) {
     // D rows of the level: every block i with (i / S) odd

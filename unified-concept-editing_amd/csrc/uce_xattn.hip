@@ -525,9 +525,10 @@ int launch_group(const void* q, const void* k, const void* v, void* o, int B, in
   const size_t smem = xg_smem<DH, NW>();
   const float sl2 = scale * 1.4426950408889634f;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_xattn_g<DH, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_xattn_g<DH, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_xattn_g<DH, NW, true>), dim3((unsigned)nwg), dim3(NW * 64), smem, st, (const unsigned short*)q,
@@ -576,12 +577,10 @@ int launch_dh(const void* q, const void* k, const void* v, void* o, int B, int H
 }  // namespace
 
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st) {
-  // SD-1.x shapes: the 640-byte column-group kernel (whole lines of Q / O per workgroup); UCE_XATTN_VARIANT=0 keeps
-  // the per-(batch, head) kernel for A/B measurements
-  // (0: always k_xattn; 2: the group kernel at every size; 3: its 8-wave dh = 40 form; read per call - tests flip it)
-  const char* env = getenv("UCE_XATTN_VARIANT");
-  const int variant = env ? atoi(env) : 1;
+                 float scale, int dtype, hipStream_t st, int variant) {
+  // SD-1.x shapes: the 640-byte column-group kernel (whole lines of Q / O per workgroup); `variant` = the handle's
+  // UCE_XATTN_VARIANT (read at uce_create): 0 keeps the per-(batch, head) kernel, 2 = the group kernel at every size,
+  // 3 = its 8-wave dh = 40 form (tests force them through a handle of their own)
   if (variant && Lk <= XG_KEYS && (H * dh) % XG_C == 0 && scale > 0.f) {
     // worth it once a workgroup walks several tiles behind one K / V^T staging (the generation batch); the B = 2
     // launches of row-by-row generation stay on k_xattn (launch-bound either way)
@@ -601,8 +600,9 @@ int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, in
 extern "C" int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B,
                              int H, int Lq, int Lk, int dh, float scale, int dtype, uce_stream_t stream) {
   if (!h || !q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lk > 128) return UCE_EINVAL;
+  UCE_ENTER(h);
   if (dh <= 0 || dh > 160 || (dh & 7)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   if (B > 65535 || H > 65535) return UCE_EINVAL;
-  return launch_xattn(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream);
+  return launch_xattn(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.xattn_variant);
 }

@@ -636,4 +636,16 @@ def patch_unet(pipe, state: Dict[str, torch.Tensor]) -> List[str]:
             handle.cast_bf16(v.to(p.device).contiguous(), p.data)
         else:
             p.data.copy_(v.to(device=p.device, dtype=p.dtype))
+        # both writes above go around the tensor's version counter: drop what was derived from the old values (the
+        # zero-padded copy of a narrow convolution weight, sd/unet.py) - a captured step that holds such a copy's
+        # address is stale too
+        mod_name = k.rsplit(".", 1)[0]
+        try:
+            mod = pipe.unet.get_submodule(mod_name)
+        except AttributeError:
+            mod = None
+        if mod is not None and hasattr(mod, "_uce_pad8"):
+            del mod._uce_pad8
+            if hasattr(pipe, "_graphs"):
+                pipe._graphs.clear()
     return loaded

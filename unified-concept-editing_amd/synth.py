@@ -52,7 +52,10 @@ def linear_default_weight(o: int, d: int, rng: np.random.Generator) -> np.ndarra
     return rng.uniform(-bound, bound, size=(o, d)).astype(np.float32)
 
 
-# ---- prompt tables in the schema of the reference's data/coco_30k.csv (no dataset on these machines) --------------
+# ---- prompt tables in the schema of the reference's data/coco_30k.csv -------------------------------------------------
+# The real table (30 000 COCO captions) ships with the reference repository but does not travel to the GPU box; 71 of its
+# records are committed as the data fixture tests/golden/coco30k_rows.csv (tools/make_coco_fixture.py), which pins the
+# row walk of generate-images-sd.py:21-46 on real rows.  The generator below makes tables of any LENGTH for throughput runs.
 _SUBJECTS = ["a man", "a woman", "a child", "two people", "a dog", "a cat", "a horse", "a bird", "a giraffe", "an elephant",
              "a bicycle", "a motorcycle", "a bus", "a train", "an airplane", "a boat", "a pizza", "a sandwich", "a cake",
              "a laptop", "a clock", "a vase", "a bench", "a kite", "a skateboard", "a surfboard", "a tennis racket",
@@ -69,7 +72,8 @@ _TAILS = ["", " at sunset", " on a cloudy day", " in black and white", " with mo
 def coco_like_rows(n: int, seed: int = 0, first_case: int = 0):
     """`n` rows (case_number, source, prompt, evaluation_seed, coco_id) in the schema of the reference's
     data/coco_30k.csv (read by evalscripts/generate-images-sd.py:21-36): caption-like prompts from a small grammar,
-    5-digit evaluation seeds, deterministic in `seed`.  Stands in for the real table, which is not on these machines."""
+    5-digit evaluation seeds, deterministic in `seed`.  For throughput runs of any length (captions of the same shape as
+    the table's; the real records used for parity are tests/golden/coco30k_rows.csv)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     rows = []
     for i in range(n):
