@@ -505,6 +505,7 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
     MFMA peak (the loop is VALU-bound on the online softmax, not MFMA-bound)."""
     import torch.nn.functional as F
     from uce_amd import edit as E
+    from uce_amd.sd.unet import sattn_prefers_hip
     H = E.UceHandle.get(device)
     traffic = load_traffic().get("sattn", {})
     out = []
@@ -520,6 +521,8 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
         if with_torch:
             sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)  # noqa: E731
             ent["torch_sdpa_us"] = round(time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), iters) * 1e3, 1)
+        # what the U-Net launches at this shape (sd/unet.py: measured rule) - the kernel above or torch's SDPA
+        ent["unet_dispatch"] = "uce_sattn_fwd" if sattn_prefers_hip(L) else "torch_sdpa"
         t = traffic.get(f"B{B}_L{L}_dh{dh}")
         if isinstance(t, dict):
             ent["traffic"] = t.get("total_bytes")

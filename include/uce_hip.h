@@ -71,6 +71,11 @@ int uce_gram(uce_handle_t h, const float* C, const float* G, const float* s, int
  * A is destroyed.  A non-positive pivot is recorded in the handle (see uce_status). */
 int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* DeltaT, uce_stream_t stream);
 
+/* The same solve for a NARROW right-hand side: X [d, m] f32 = A^-1 B, B [d, m] f64, m a multiple of 64 (the bias
+ * direction u = A^-1 sum_i s_i c_i of the biased-Linear variants, trainscripts/uce_flux_edit.py:86-113, rides in one
+ * column).  A is destroyed; pivot failures as uce_solve_delta. */
+int uce_solve_rhs(uce_handle_t h, double* A, const double* B, int d, int m, float* X, uce_stream_t stream);
+
 /* a5 - apply (replaces `mat1 @ inverse` of uce_sd_erase.py:82 for ALL modules in one launch):
  *   W_new [rows,d] = W_old + W_old Delta ; rows = sum of the modules' out_features (the host
  *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  Products carry fp32 accuracy: both operands
@@ -108,7 +113,11 @@ int uce_delta_from_factors(uce_handle_t h, const float* Dm, const float* R, int 
                            float* DeltaT, uce_stream_t stream);
 
 /* The whole of uce_sd_erase.py:45-82 for every module: picks dual/primal and low-rank/full by
- * (N, N_edit, d) when algo == UCE_ALGO_AUTO.  W_new may not alias W_old. */
+ * (N, N_edit, d) when algo == UCE_ALGO_AUTO.  W_new may not alias W_old.
+ * Stream capture: once the workspace is reserved (uce_reserve / uce_reserve_rows, or one eager call of the same shape)
+ * the call allocates nothing and keeps no per-launch value on the host - the hand-off words of its cooperating
+ * workgroups live on the device and are re-armed by the launch itself - so it may be captured into a hipGraph and
+ * replayed (tests/test_stress_gpu.py). */
 int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
              float lamb, const float* W_old, float* W_new, long rows, int algo, uce_stream_t stream);
 

@@ -100,3 +100,43 @@ def test_sattn_rejects_bad_arguments(H):
     q = torch.zeros(1, 8, 8 * 168, dtype=torch.bfloat16, device="cuda:0")     # dh > 160
     with pytest.raises(L.UceError):
         H.sattn(q, q, q, 8)
+
+
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
+    (2, 8, 1024, 1024, 40, torch.bfloat16),     # dh = 40: one / two query tiles per wave, the pipelined kernel
+    (1, 8, 300, 130, 40, torch.bfloat16),       # ragged: a 256-row workgroup with a partial second tile, three key tiles
+    (3, 4, 77, 64, 40, torch.float16),          # exactly one key tile (the pipeline's prologue only)
+    (2, 8, 512, 200, 80, torch.bfloat16),       # dh = 80: k_sattn and k_sattn_p
+    (1, 2, 40, 1, 80, torch.bfloat16),          # a single key
+])
+def test_sattn_every_kernel_form_forced(variant, B, H_, Lq, Lk, dh, dtype):
+    """k_sattn with one (1) and two (2) query tiles per wave and the software-pipelined k_sattn_p (3), each forced through a
+    handle of its own (UCE_SATTN_QT is read at uce_create) at sizes the by-shape rule would not send there."""
+    import os
+    from uce_amd import edit as E
+    old = os.environ.get("UCE_SATTN_QT")
+    os.environ["UCE_SATTN_QT"] = variant
+    try:
+        Hv = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_SATTN_QT"]
+        else:
+            os.environ["UCE_SATTN_QT"] = old
+    g = torch.Generator().manual_seed(Lq * 5 + dh + Lk)
+    C = H_ * dh
+    q = torch.randn(B, Lq, C, generator=g).to(dtype)
+    k = torch.randn(B, Lk, C, generator=g).to(dtype)
+    v = torch.randn(B, Lk, C, generator=g).to(dtype)
+    try:
+        o = Hv.sattn(q.cuda(), k.cuda(), v.cuda(), H_)
+        again = Hv.sattn(q.cuda(), k.cuda(), v.cuda(), H_)
+    finally:
+        torch.cuda.synchronize()
+        Hv.close()
+    ref = _ref_gpu(q.cuda(), k.cuda(), v.cuda(), H_)
+    assert O.rel_fro(o.double().cpu(), ref.cpu()) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
+    assert torch.equal(o, again)
+    if Lk == 1:
+        assert torch.equal(o.cpu(), v.expand(B, Lq, C).contiguous())

@@ -1,79756 +1,84 @@
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-G    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-I    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-'    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-^    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-9    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-;    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-@    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-@    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-<    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-'    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-P    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-<    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-@    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-9    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-R    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-Y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-9    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-9    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-G    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-+    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-<    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-@    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-@    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-9    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-%    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-S    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-/    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-D    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-G    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-+    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-+    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-R    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-I    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-R    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-I    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-R    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-I    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-[    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-X    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-V    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-R    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-I    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-A    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-N    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-]    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-<    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
--    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-G    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-7    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-C    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-5    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-<    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-T    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-O    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-B    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-F    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-j    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-g    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-_    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-*    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-3    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-q    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-2    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-9    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-#    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-m    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-w    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-L    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-U    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-E    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-
-    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-H    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-x    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-n    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-z    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-s    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-(    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-8    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-4    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-y    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-p    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-r    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-h    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-.    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-b    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-f    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-l    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-o    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-t    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-6    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-v    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-i    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-e    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-=    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-c    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-u    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-d    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-a    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-:    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-0    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-"    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-k    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-,    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-1    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
-    from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
-)    # the A/B switches are read when a handle is created: a handle of its own for the forced variant
+"""GPU parity of the cross-attention kernel (through the C ABI) against the oracle and the
+golden outputs of torch's CPU scaled_dot_product_attention."""
+import pytest
+import torch
+
+from oracle import uce_oracle as O
+from tests.golden_io import Case, SDPA_CASES
+
+pytestmark = pytest.mark.gpu
+
+# bf16 output rounding (2^-9 relative per element) dominates; P is rounded to bf16 before P.V
+TOL_BF16 = 8e-3
+TOL_F16 = 1.5e-3
+
+
+@pytest.fixture(scope="module")
+def H():
     from uce_amd import edit as E
-    old = os.environ.get("UCE_XATTN_VARIANT")
-    os.environ["UCE_XATTN_VARIANT"] = variant
-    try:
-        Hv = E.UceHandle("cuda:0")
-    finally:
-        if old is None:
-            del os.environ["UCE_XATTN_VARIANT"]
-        else:
-            os.environ["UCE_XATTN_VARIANT"] = old
-    try:
-        o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
-    finally:
-        Hv.close()
+    return E.UceHandle.get("cuda:0")
+
+
+@pytest.mark.parametrize("name", SDPA_CASES)
+def test_xattn_golden(H, name):
+    c = Case(name)
+    m = c.meta
+    q, k, v = (c.t(x).view(torch.bfloat16).cuda() for x in ("q", "k", "v"))
+    o = H.xattn(q, k, v, m["H"]).cpu()
+    ref64 = O.xattn_ref(q.cpu(), k.cpu(), v.cpu(), m["H"])
+    assert O.rel_fro(o.double(), ref64) < TOL_BF16
+    # and as close to the fp32 SDPA result as torch's own bf16 SDPA is (x1.5)
+    sdpa_bf16 = c.t("o_bf16").view(torch.bfloat16).double()
+    err_ref = O.rel_fro(sdpa_bf16, c.t("o_f32"))
+    assert O.rel_fro(o.double(), c.t("o_f32")) < max(1.5 * err_ref, 4e-3)
 
+
+@pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
+    (2, 8, 4096, 77, 40, torch.bfloat16),     # SD-1.4 full shapes
+    (2, 8, 1024, 77, 80, torch.bfloat16),
+    (2, 8, 256, 77, 160, torch.bfloat16),
+    (2, 8, 64, 77, 160, torch.bfloat16),
+    (16, 8, 4096, 77, 40, torch.bfloat16),    # the batch the generation loop issues: 4 query tiles per workgroup
+    (40, 8, 1000, 77, 40, torch.bfloat16),    # 2 tiles per workgroup, ragged last tile
+    (1, 5, 100, 77, 64, torch.bfloat16),      # ragged Lq (not a multiple of 128 or 32)
+    (3, 2, 33, 1, 40, torch.bfloat16),        # a single key: softmax == 1, O == V
+    (1, 4, 200, 128, 128, torch.bfloat16),    # 4 key tiles
+    (2, 10, 130, 97, 64, torch.float16),      # f16 path, SDXL-like head dim
+    (1, 20, 64, 77, 64, torch.float16),
+])
+def test_xattn_shapes(H, B, H_, Lq, Lk, dh, dtype):
+    g = torch.Generator().manual_seed(Lq * 7 + dh)
+    C = H_ * dh
+    q = torch.randn(B, Lq, C, generator=g).to(dtype)
+    k = torch.randn(B, Lk, C, generator=g).to(dtype)
+    v = torch.randn(B, Lk, C, generator=g).to(dtype)
+    o = H.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
+    ref = O.xattn_ref(q, k, v, H_)
+    assert O.rel_fro(o.double(), ref) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
+    if Lk == 1:
+        assert torch.equal(o, v.expand(B, Lq, C).contiguous())
+
+
+@pytest.mark.parametrize("variant", ["2", "3"])
+@pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
+    (2, 8, 4096, 77, 40, torch.bfloat16),     # one tile per workgroup
+    (8, 8, 1000, 77, 40, torch.bfloat16),     # XCD remap (B % 8 == 0), ragged last tile
+    (3, 16, 333, 77, 40, torch.bfloat16),     # two column groups, ragged, no remap
+    (5, 8, 130, 80, 80, torch.bfloat16),      # 80 keys: the last key row of the LDS image
+    (8, 8, 1024, 77, 80, torch.bfloat16),
+    (2, 8, 256, 77, 160, torch.bfloat16),
+    (16, 4, 70, 33, 160, torch.float16),      # f16, two key tiles only
+    (3, 8, 64, 1, 40, torch.bfloat16),        # a single key: O == V
+])
+def test_xattn_group_kernel_forced(H, variant, B, H_, Lq, Lk, dh, dtype):
+    """The 640-byte column-group kernel (default only at generation-batch sizes) forced at every size: its 16-wave
+    (variant 2) and 8-wave (variant 3) dh = 40 forms, dh = 80 / 160, ragged tiles, the XCD remap, both dtypes."""
+    import os
+    g = torch.Generator().manual_seed(Lq * 11 + dh + B)
+    C = H_ * dh
+    q = torch.randn(B, Lq, C, generator=g).to(dtype)
+    k = torch.randn(B, Lk, C, generator=g).to(dtype)
+    v = torch.randn(B, Lk, C, generator=g).to(dtype)
     # the A/B switches are read when a handle is created: a handle of its own for the forced variant
     from uce_amd import edit as E
     old = os.environ.get("UCE_XATTN_VARIANT")
@@ -79766,3 +94,31 @@ k    # the A/B switches are read when a handle is created: a handle of its own f
         o = Hv.xattn(q.cuda(), k.cuda(), v.cuda(), H_).cpu()
     finally:
         Hv.close()
+    ref = O.xattn_ref(q, k, v, H_)
+    assert O.rel_fro(o.double(), ref) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
+    if Lk == 1:
+        assert torch.equal(o, v.expand(B, Lq, C).contiguous())
+
+
+def test_xattn_peaked_and_scaled(H):
+    """Large logits (one key dominating) and a custom scale: exercises max-subtraction."""
+    g = torch.Generator().manual_seed(3)
+    B, H_, Lq, Lk, dh = 1, 8, 128, 77, 40
+    C = H_ * dh
+    q = (torch.randn(B, Lq, C, generator=g) * 6).to(torch.bfloat16)
+    k = (torch.randn(B, Lk, C, generator=g) * 6).to(torch.bfloat16)
+    v = torch.randn(B, Lk, C, generator=g).to(torch.bfloat16)
+    o = H.xattn(q.cuda(), k.cuda(), v.cuda(), H_, scale=0.5).cpu()
+    ref = O.xattn_ref(q, k, v, H_, scale=0.5)
+    assert torch.isfinite(o.float()).all()
+    assert O.rel_fro(o.double(), ref) < TOL_BF16
+
+
+def test_xattn_rejects_bad_arguments(H):
+    from uce_amd import lib as L
+    q = torch.zeros(1, 8, 8 * 36, dtype=torch.bfloat16, device="cuda:0")   # dh = 36 is not a multiple of 8
+    with pytest.raises(L.UceError):
+        H.xattn(q, q, q, 8)
+    k = torch.zeros(1, 129, 64, dtype=torch.bfloat16, device="cuda:0")     # too many keys
+    with pytest.raises(L.UceError):
+        H.xattn(torch.zeros(1, 8, 64, dtype=torch.bfloat16, device="cuda:0"), k, k, 1)

@@ -133,7 +133,7 @@ static int env_int(const char* name, int dflt) {
 
 extern "C" {
 
-int uce_version(void) { return 109; }
+int uce_version(void) { return 110; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -162,13 +162,16 @@ int uce_create(uce_handle_t* out, int device) {
     const int cap = lr_rider_cap();
     const int want = env_int("UCE_RIDER_MAX_N", cap);
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 1), env_int("UCE_TRISOLVE_VARIANT", 1),
-                        want < cap ? want : cap, env_int("UCE_CONV_DMA", 1)};
+                        want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->status, 0, sizeof(int));
   if (hipMalloc((void**)&h->ticket, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->ticket, 0, 4 * sizeof(unsigned));
+  constexpr size_t LA_FLAGS = 22 * 22 + 2 * 22 + 8;            // k_potrf_la: systems of up to 22 diagonal blocks
+  if (hipMalloc((void**)&h->la_flags, LA_FLAGS * sizeof(unsigned)) == hipSuccess) (void)hipMemset(h->la_flags, 0, LA_FLAGS * sizeof(unsigned));
+  else h->la_flags = nullptr;                                  // (the launch chain is used instead)
   *out = h;
   return UCE_OK;
 }
@@ -183,6 +186,7 @@ int uce_destroy(uce_handle_t h) {
   if (h->Vt) (void)hipFree(h->Vt);
   for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->la_flags) (void)hipFree(h->la_flags);
   prof_clear(h);
   delete h;
   return UCE_OK;
@@ -242,6 +246,21 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
   if (rc) return rc;
   UceProfScope ps(h, "k_trisolve", st);
   return launch_trisolve(h, d, d, Bt, nullptr, d, DeltaT, d, st, A);
+}
+
+int uce_solve_rhs(uce_handle_t h, double* A, const double* B, int d, int m, float* X, uce_stream_t stream) {
+  if (!h || !A || !B || !X || d <= 0 || d % 64 || m <= 0 || m % 64) return UCE_EINVAL;
+  UCE_ENTER(h);
+  int rc = uce_ensure(h, d > m ? d : m, d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    UceProfScope ps(h, "potrf", st);
+    rc = launch_potrf(h, A, d, st);
+  }
+  if (rc) return rc;
+  UceProfScope ps(h, "k_trisolve", st);
+  return launch_trisolve(h, d, m, B, nullptr, d, X, d, st, A);
 }
 
 int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,

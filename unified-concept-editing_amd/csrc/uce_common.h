@@ -64,8 +64,11 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
 //   UCE_RIDER_MAX_N     largest dual system (64 or 128) factored by rider blocks of the projection launch; 0: never
 //   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
+//   UCE_SATTN_QT        0: self-attention kernel by measured rule | 1: k_sattn, one query tile per wave | 2: two query tiles
+//                       wherever dh <= 48 | 3: the software-pipelined k_sattn_p wherever it exists
+//   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..22 diagonal blocks | 0: the launch chain
 struct UceSwitches {
-  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma;
+  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -88,6 +91,7 @@ struct uce_ctx {
   float* Dm;      // [n_cap, d_cap]
   float* R;       // [n_cap, d_cap]
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
+  unsigned* la_flags;   // hand-off flags of the persistent Cholesky (uce_solve.hip: k_potrf_la), zero between launches
   unsigned* ticket;  // hand-off words of the rider blocks (uce_lowrank2.hip), all zero between launches: [0] arrival counter
                      // of the Gram riders, [1] stage word of the factorising block, [2] completion counter of the solve riders
   float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply
@@ -156,7 +160,7 @@ int uce_ensure_T(uce_ctx* h, long rows, int N_edit);
 int uce_ensure_Vt(uce_ctx* h, size_t elems);
 size_t sattn_vt_elems(int B, int H, int Lk, int dh);
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st);
+                 float scale, int dtype, hipStream_t st, int qt_variant = 0);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
                  int dh, float scale, int dtype, hipStream_t st, int variant = 1);
 

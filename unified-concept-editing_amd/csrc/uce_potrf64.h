@@ -120,9 +120,15 @@ __device__ unsigned long long g_pkst[8];
 #define PKS(i) do { } while (0)
 #endif
 
-template <class LoadA, class StoreX>
+struct PotrfNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// `after_load`: called by every thread right after the barrier that follows the tile load (the persistent Cholesky posts a
+// hand-off flag there: the stores it covers were drained by the waves before that barrier, off the critical path).
+template <class LoadA, class StoreX, class Hook = PotrfNoHook>
 __device__ __forceinline__ void potrf64_pk(LoadA loadA, StoreX storeX, Potrf64Scratch* sc, int tid, int* status, int col_base,
-                                           int npiv) {
+                                           int npiv, Hook after_load = Hook()) {
   const int wave = tid >> 6, lane = tid & 63;
   PKS(0);
   // role 0: matrix tile, (i1, i2) = (row block, column block); role 1: X tile, transposed, (i1, i2) = (column block, row block)
@@ -157,6 +163,7 @@ __device__ __forceinline__ void potrf64_pk(LoadA loadA, StoreX storeX, Potrf64Sc
     }
   }
   __syncthreads();                                                      // loadA may have read what the scratch aliases
+  after_load();
   PKS(1);
   const int nkb = npiv >= 64 ? 16 : ((npiv + 3) >> 2), kstop = 4 * nkb;
   char* lds = (char*)sc;

@@ -78,8 +78,11 @@ __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V
   }
 }
 
-// DHP: head dim padded to a multiple of 16
-template <int DHP, bool F16>
+// DHP: head dim padded to a multiple of 16.  QT: 32-row query tiles per wave (1 or 2).  With QT = 2 (dh <= 48: the
+// accumulators of two tiles fit the register file at two waves per SIMD) every K / V^T fragment read from LDS feeds two
+// MFMAs and a key tile's barrier covers twice the flops - the 4096-token layers were bound by LDS fragment traffic and
+// barrier stalls (22 KB of LDS reads per wave and key tile at QT = 1), not by the matrix cores.
+template <int DHP, bool F16, int QT>
 __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                int H, int Lq, int Lk, int LkP, int dh, float scale_log2e) {
@@ -100,17 +103,18 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = H * dh;
   const int lq = lane & 31, lh = lane >> 5;
-  const long q0 = (long)blockIdx.x * 128 + w * 32;
-  const long row = q0 + lq;
+  const long q0 = (long)blockIdx.x * (128 * QT) + w * (32 * QT);
 
-  // ---- this lane's Q fragments (row q0 + lq, dims 16s + 8*lh .. +7)
-  uint4_t qf[NS];
-  {
+  // ---- this lane's Q fragments (rows q0 + 32 t + lq, dims 16s + 8*lh .. +7)
+  uint4_t qf[QT][NS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const long row = q0 + 32 * t + lq;
     const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int dim = 16 * s + 8 * lh;
-      qf[s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
+      qf[t][s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
     }
   }
 
@@ -157,26 +161,226 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   // dh < DVP: row DVP - 1 of V^T is all ones (k_vt), so O^T's last row IS the running softmax denominator - summed
   // by the matrix core, rescaled with the other rows - and the 32 VALU adds per tile go away.
   const bool sum_mfma = dh < DVP;
-  float m = -INFINITY, lsum = 0.f;          // running max (shared by lane and lane^32), this lane's partial sum
-  float16_t oacc[NDV];
+  float m[QT], lsum[QT];                    // running max (shared by lane and lane^32), this lane's partial sum
+  float16_t oacc[QT][NDV];
 #pragma unroll
-  for (int nt = 0; nt < NDV; ++nt)
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY;
+    lsum[t] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.f;
+    for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][nt][r] = 0.f;
+  }
 
   const int ntiles = (Lk + KT - 1) / KT;
   g_load(0);
   s_store(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
     const unsigned short* Ks = smem + cur * BUF;
     const unsigned short* Vs = Ks + KT * KLD;
-    if (t + 1 < ntiles) g_load(t + 1);
+    if (kt + 1 < ntiles) g_load(kt + 1);
 
     // ---- S^T = K Q^T for the 64 keys: register r of sub-tile j = key 32j + (r&3) + 8*(r>>2) + 4*lh
-    float16_t sacc[2];
+    float16_t sacc[QT][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][j][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint4_t kf = *(const uint4_t*)(Ks + (j * 32 + lq) * KLD + 16 * s + 8 * lh);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sacc[t][j] = mfma32<F16>(kf, qf[t][s], sacc[t][j]);
+      }
+    }
+    if ((kt + 1) * KT > Lk) {                 // the last tile may hold padding keys
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * KT + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sacc[t][j][r] = (key < Lk) ? sacc[t][j][r] : -INFINITY;
+          }
+    }
+    // ---- online softmax, per query tile
+    uint4_t pf[QT][2][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      float mt = sacc[t][0][0];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][j][r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float m_new = fmaxf(m[t], mt);                            // finite: every tile holds at least one real key
+      const float alpha = __builtin_amdgcn_exp2f((m[t] - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first tile
+      const float mc = m_new * scale_log2e;
+      m[t] = m_new;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sacc[t][j][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][j][r], scale_log2e, -mc));
+      if (!sum_mfma) {
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ps += sacc[t][j][r];
+        lsum[t] = fmaf(lsum[t], alpha, ps);
+      }
+      if (__any(alpha != 1.0f)) {               // the max rarely moves after the first tiles: skip the rescale
+#pragma unroll
+        for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[t][nt][r] *= alpha;
+      }
+      // ---- P fragments (unnormalised): slot e of step s2 of sub-tile j <- register 8*s2 + e
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pf[t][j][s2][q] = pack2<F16>(sacc[t][j][8 * s2 + 2 * q], sacc[t][j][8 * s2 + 2 * q + 1]);
+    }
+    // ---- O^T += V^T P^T : slot e <-> key 32j + 16*s2 + 4*lh + (e&3) + 8*(e>>2) on both sides
+#pragma unroll
+    for (int nt = 0; nt < NDV; ++nt) {
+      const unsigned short* vrow = Vs + (nt * 32 + lq) * VLD + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint2_t lo = *(const uint2_t*)(vrow + j * 32 + 16 * s2);
+          const uint2_t hi = *(const uint2_t*)(vrow + j * 32 + 16 * s2 + 8);
+          const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+          for (int t = 0; t < QT; ++t) oacc[t][nt] = mfma32<F16>(vf, pf[t][j][s2], oacc[t][nt]);
+        }
+    }
+    if (kt + 1 < ntiles) s_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- 1/sum, convert, store: register r of tile nt = output dim nt*32 + (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const long row = q0 + 32 * t + lq;
+    float denom = lsum[t] + __shfl_xor(lsum[t], 32);
+    if (sum_mfma) {                           // row DVP - 1 = tile NDV - 1, register 15 of the lh = 1 lanes
+      const float l1 = oacc[t][NDV - 1][15];
+      const float l0 = __shfl_xor(l1, 32);
+      denom = lh ? l1 : l0;
+    }
+    const float inv = 1.0f / denom;
+    unsigned short* orow = O + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+#pragma unroll
+    for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = nt * 32 + 8 * g + 4 * lh;
+        if (dv < dh && row < Lq) {
+          const uint2_t o2 = {pack2<F16>(oacc[t][nt][4 * g] * inv, oacc[t][nt][4 * g + 1] * inv),
+                              pack2<F16>(oacc[t][nt][4 * g + 2] * inv, oacc[t][nt][4 * g + 3] * inv)};
+          *(uint2_t*)(orow + dv) = o2;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sattn_p: the same kernel software-pipelined over the key tiles (the att[2] double pipeline of the CDNA guide, T15):
+// iteration t issues the S^T MFMAs of tile t + 1 FIRST, then runs the softmax of tile t on the VALU while they execute,
+// then the P V MFMAs of tile t - inside one wave the MFMA -> VALU -> MFMA dependency chain of a tile (what kept the
+// matrix pipe at a third of its time in k_sattn: neither pipe saturated, the wave waiting on its own previous phase)
+// is broken across two tiles.  K is therefore staged one tile further ahead than V^T: separate double buffers.
+// ---------------------------------------------------------------------------------------------
+template <int DHP, bool F16>
+__global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
+                                                 const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
+                                                 int H, int Lq, int Lk, int LkP, int dh, float scale_log2e) {
+  constexpr int NDV = (DHP + 31) / 32;
+  constexpr int DVP = NDV * 32;
+  constexpr int KLD = DHP + 8;
+  constexpr int VLD = KT + 4;
+  constexpr int NS = DHP / 16;
+  constexpr int KCH = DHP / 8;
+  constexpr int NKL = (KT * KCH + 255) / 256;
+  constexpr int VCH = KT / 8;
+  constexpr int NVL = (DVP * VCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Kbuf = (unsigned short*)smem_raw;                  // [2][KT * KLD]
+  unsigned short* Vbuf = Kbuf + 2 * KT * KLD;                        // [2][DVP * VLD]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * dh;
+  const int lq = lane & 31, lh = lane >> 5;
+  const long row = (long)blockIdx.x * 128 + w * 32 + lq;
+
+  uint4_t qf[NS];
+  {
+    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int dim = 16 * s + 8 * lh;
+      qf[s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
+    }
+  }
+  const unsigned short* kbase = K + (size_t)b * Lk * C + (size_t)h * dh;
+  const unsigned short* vbase = Vt + ((size_t)b * H + h) * DVP * LkP;
+  uint4_t rk[NKL], rv[NVL];
+  auto g_load_k = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int e = tid + 256 * i;
+      const int key = e / KCH, dim = (e - key * KCH) * 8;
+      rk[i] = (uint4_t){0u, 0u, 0u, 0u};
+      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * C + dim);
+    }
+  };
+  auto g_load_v = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int e = tid + 256 * i;
+      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+      if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+    }
+  };
+  auto s_store_k = [&](int buf) {
+    unsigned short* Ks = Kbuf + buf * KT * KLD;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int e = tid + 256 * i;
+      const int key = e / KCH, dim = (e - key * KCH) * 8;
+      if (e < KT * KCH) *(uint4_t*)(Ks + key * KLD + dim) = rk[i];
+    }
+  };
+  auto s_store_v = [&](int buf) {
+    unsigned short* Vs = Vbuf + buf * DVP * VLD;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int e = tid + 256 * i;
+      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+      if (e < DVP * VCH) {
+        *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
+        *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+      }
+    }
+  };
+  // S^T = K Q^T of the tile in K buffer `buf`
+  auto qk = [&](int buf, float16_t (&sacc)[2]) {
+    const unsigned short* Ks = Kbuf + buf * KT * KLD;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -187,54 +391,84 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
         sacc[j] = mfma32<F16>(kf, qf[s], sacc[j]);
       }
     }
-    if ((t + 1) * KT > Lk) {                 // the last tile may hold padding keys
+  };
+
+  const bool sum_mfma = dh < DVP;
+  float m = -INFINITY, lsum = 0.f;
+  float16_t oacc[NDV];
+#pragma unroll
+  for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.f;
+
+  const int ntiles = (Lk + KT - 1) / KT;
+  // prologue: K(0), V^T(0), K(1) staged; S^T(0) computed
+  g_load_k(0);
+  g_load_v(0);
+  s_store_k(0);
+  s_store_v(0);
+  if (ntiles > 1) {
+    g_load_k(1);
+    s_store_k(1);
+  }
+  __syncthreads();
+  float16_t sA[2], sB[2];
+  qk(0, sA);
+  __syncthreads();                              // K(0) is overwritten by iteration 0's store of K(2)
+
+  // one key tile: sc = S^T(t) (computed one iteration earlier), sn <- S^T(t + 1)
+  auto tile = [&](int t, float16_t (&sc)[2], float16_t (&sn)[2]) {
+    const int cur = t & 1;
+    if (t + 2 < ntiles) g_load_k(t + 2);
+    if (t + 1 < ntiles) {
+      g_load_v(t + 1);
+      qk(cur ^ 1, sn);                          // the next tile's scores: in flight under this tile's softmax
+    }
+    if ((t + 1) * KT > Lk) {                    // the last tile may hold padding keys
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = t * KT + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          sacc[j][r] = (key < Lk) ? sacc[j][r] : -INFINITY;
+          sc[j][r] = (key < Lk) ? sc[j][r] : -INFINITY;
         }
     }
-    // ---- online softmax
-    float mt = sacc[0][0];
+    float mt = sc[0][0];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[j][r]);
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[j][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m, mt);                              // finite: every tile holds at least one real key
-    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first tile
+    const float m_new = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_log2e);
     const float mc = m_new * scale_log2e;
     m = m_new;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sacc[j][r] = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale_log2e, -mc));
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(fmaf(sc[j][r], scale_log2e, -mc));
     if (!sum_mfma) {
       float ps = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ps += sacc[j][r];
+        for (int r = 0; r < 16; ++r) ps += sc[j][r];
       lsum = fmaf(lsum, alpha, ps);
     }
-    if (__any(alpha != 1.0f)) {               // the max rarely moves after the first tiles: skip the rescale
+    if (__any(alpha != 1.0f)) {
 #pragma unroll
       for (int nt = 0; nt < NDV; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[nt][r] *= alpha;
     }
-    // ---- P fragments (unnormalised): slot e of step s2 of sub-tile j <- register 8*s2 + e
     uint4_t pf[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pf[j][s2][q] = pack2<F16>(sacc[j][8 * s2 + 2 * q], sacc[j][8 * s2 + 2 * q + 1]);
-    // ---- O^T += V^T P^T : slot e <-> key 32j + 16*s2 + 4*lh + (e&3) + 8*(e>>2) on both sides
+        for (int q = 0; q < 4; ++q) pf[j][s2][q] = pack2<F16>(sc[j][8 * s2 + 2 * q], sc[j][8 * s2 + 2 * q + 1]);
+    const unsigned short* Vs = Vbuf + cur * DVP * VLD;
 #pragma unroll
     for (int nt = 0; nt < NDV; ++nt) {
       const unsigned short* vrow = Vs + (nt * 32 + lq) * VLD + 4 * lh;
@@ -248,13 +482,18 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
           oacc[nt] = mfma32<F16>(vf, pf[j][s2], oacc[nt]);
         }
     }
-    if (t + 1 < ntiles) s_store(cur ^ 1);
+    // K(t + 2) -> the buffer K(t) left one iteration ago; V^T(t + 1) -> the buffer V^T(t - 1) left
+    if (t + 2 < ntiles) s_store_k(cur);
+    if (t + 1 < ntiles) s_store_v(cur ^ 1);
     __syncthreads();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(t, sA, sB);
+    if (t + 1 < ntiles) tile(t + 1, sB, sA);
   }
 
-  // ---- 1/sum, convert, store: register r of tile nt = output dim nt*32 + (r&3) + 8*(r>>2) + 4*lh
   float denom = lsum + __shfl_xor(lsum, 32);
-  if (sum_mfma) {                           // row DVP - 1 = tile NDV - 1, register 15 of the lh = 1 lanes
+  if (sum_mfma) {
     const float l1 = oacc[NDV - 1][15];
     const float l0 = __shfl_xor(l1, 32);
     denom = lh ? l1 : l0;
@@ -275,23 +514,46 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 }
 
 template <int DHP>
+int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
+                 float scale, int dtype, hipStream_t st) {
+  const dim3 grid((Lq + 127) / 128, H, B);
+  const float sl2 = scale * 1.4426950408889634f;
+  constexpr int NDV = (DHP + 31) / 32;
+  const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  static PerDeviceOnce attr_once;
+  if (const int tok = attr_once.first()) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
+  }
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL((k_sattn_p<DHP, true>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+  else
+    hipLaunchKernelGGL((k_sattn_p<DHP, false>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+template <int DHP, int QT>
 int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                float scale, int dtype, hipStream_t st) {
-  const dim3 grid((Lq + 127) / 128, H, B);
+  const dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn<DHP, true>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn<DHP, true, QT>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
   else
-    hipLaunchKernelGGL((k_sattn<DHP, false>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn<DHP, false, QT>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -308,8 +570,10 @@ size_t sattn_vt_elems(int B, int H, int Lk, int dh) {
   return (size_t)B * H * sattn_dvp(dh) * ((Lk + KT - 1) / KT * KT);
 }
 
+// qt_variant (UCE_SATTN_QT, read at uce_create): 0 = measured best by shape, 1 = always k_sattn with one query tile per wave,
+// 2 = two query tiles wherever dh <= 48, 3 = the pipelined kernel wherever it exists (dh <= 48, 64 < dh <= 80)
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st) {
+                 float scale, int dtype, hipStream_t st, int qt_variant) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
@@ -317,12 +581,23 @@ int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o,
   hipLaunchKernelGGL(k_vt, dim3(LkP / 64, (DVP + 63) / 64, B * H), dim3(256), 0, st, (const unsigned short*)v,
                      (unsigned short*)vt, H, Lk, dh, DVP, LkP, ones_row, one);
   UCE_LAUNCH_CHECK();
-  if (dh <= 48) return launch_cfg<48>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 64) return launch_cfg<64>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 80) return launch_cfg<80>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 96) return launch_cfg<96>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 128) return launch_cfg<128>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  return launch_cfg<160>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
+  //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
+  //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
+  if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
+    return launch_cfg_p<80>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 48) {
+    // two query tiles per wave once there are enough 256-row workgroups to fill the chip twice over
+    const long wg2 = (long)((Lq + 255) / 256) * H * B;
+    if (qt_variant != 1 && (qt_variant == 2 || wg2 >= 1024)) return launch_cfg<48, 2>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+    return launch_cfg<48, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  }
+  if (dh <= 64) return launch_cfg<64, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 80) return launch_cfg<80, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 96) return launch_cfg<96, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  if (dh <= 128) return launch_cfg<128, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  return launch_cfg<160, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
 }
 
 extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
@@ -334,5 +609,5 @@ extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const
   if (B > 65535 || H > 65535 || (long)B * H > 65535) return UCE_EINVAL;
   const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, Lk, dh));
   if (rc) return rc;
-  return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream);
+  return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt);
 }

@@ -45,6 +45,253 @@ __global__ __launch_bounds__(512) void k_potrf_step(double* __restrict__ M, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// The same factorisation as ONE persistent launch with look-ahead (systems of >= 3 diagonal blocks whose tiles are all
+// co-resident: the d x d primal system of BASELINE config 3 is 12 blocks = 67 workgroups).  The launch chain above
+// serialises, per 64-block, [kernel boundary | loads | panel product | trailing update | 64 x 64 factor]: 21.8 us, of which
+// only the factor (11.3 us, a latency chain of 32 pivot pairs) is inherently sequential.  Here
+//   * workgroup 0, the WALKER, goes down the diagonal: for block k it takes the tiles M_k,k-1 and M_kk that others have
+//     already brought up to date through column k-2, forms L_k,k-1 = M_k,k-1 L_k-1,k-1^-T with the inverse it still holds
+//     in LDS, publishes it, forms the Schur complement M_kk - L_k,k-1 L_k,k-1^T and factors it - nothing between two
+//     factors but two 64^3 products and one tile load;
+//   * one workgroup per off-diagonal tile (i, k), LEFT-looking: it subtracts L_ij L_kj^T for j = 0 .. k-1 as those panels
+//     appear (all of it while the walker is busy with later... earlier diagonal blocks), then waits for L_kk^-1, forms
+//     L_ik and publishes it.  The tile next to the diagonal, (i, i-1), also accumulates the diagonal tile M_ii (same L_ij
+//     operand) and hands both to the walker instead of finishing itself.
+// Hand-offs: payload with 16-byte write-through stores -> drained -> barrier -> relaxed flag; the reader polls the flag,
+// passes a barrier, runs an agent-scope ACQUIRE (invalidates what its L1 / its XCD's L2 may still hold of the previous
+// launch's tiles at the same addresses) and reads with plain 16-byte loads at full cache bandwidth.  Workgroups are
+// ordered so that nobody but the walker waits for a higher-numbered workgroup (column-major tiles): progress never depends
+// on all workgroups being resident at once.  Every wait is bounded (status -1 instead of a hang).  The flags are zero
+// between launches: the workgroup that finishes last clears them.
+// ------------------------------------------------------------------------------------------
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+
+struct PotrfLaJob {
+  double* M;          // [n, n] system (lower tiles read; the tiles (i, i-1) and (i, i) are overwritten with their updates)
+  int n, nb, n_valid;
+  double* Lmat;       // [n, n]: off-diagonal blocks of L
+  double* Linv;       // [nb][64][64]
+  int* status;
+  unsigned* flags;    // [nb * nb] panel (i, j) published | [nb] L_kk^-1 published | [nb] tiles (k, k-1), (k, k) handed over | [1] exits
+};
+
+__device__ __forceinline__ bool la_wait(const unsigned* flag, int* status) {
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 25)) {                        // ~ seconds: report instead of hanging
+        atomicCAS(status, 0, -1);
+        ok = false;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+__device__ __forceinline__ void la_post(unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 64 x 64 tile at G (row stride ld doubles) <-> LDS tile [64][LD]; 512 threads, 16 bytes per lane
+__device__ __forceinline__ void la_load_tile(double (*T)[LD], const double* G, int ld) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = 2 * (threadIdx.x + 512 * p);
+    *(double2_t*)&T[e >> 6][e & 63] = *(const double2_t*)(G + (size_t)(e >> 6) * ld + (e & 63));
+  }
+}
+__device__ __forceinline__ void la_publish_tile(const double (*T)[LD], double* G, int ld) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)G, 0, (int)(64 * ld * sizeof(double)), 0x00020000);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = 2 * (threadIdx.x + 512 * p);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, *(const double2_t*)&T[e >> 6][e & 63]), r,
+                                           (unsigned)(((e >> 6) * ld + (e & 63)) * sizeof(double)), 0, 16 /* sc1 */);
+  }
+}
+
+// 8 waves: wave (wq = w & 3, half = w >> 2) owns rows wr .. wr + 31 x columns wc8 .. wc8 + 15 of a 64 x 64 product
+// acc += sign * P Q^T (both LDS tiles row-major, contraction index contiguous)
+struct LaWave {
+  int wr, wc8, lane;
+  __device__ __forceinline__ LaWave() {
+    const int w = threadIdx.x >> 6, wq = w & 3;
+    lane = threadIdx.x & 63;
+    wr = (wq >> 1) * 32;
+    wc8 = (wq & 1) * 32 + 16 * (w >> 2);
+  }
+  __device__ __forceinline__ void prod(double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign) const {
+    const int r = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+    for (int kb = 0; kb < 16; ++kb) {
+      const int t = kb * 4 + kk;
+      const double b0 = Q[wc8 + r][t];
+      a2[0] = mfma_f64(sign * P[wr + r][t], b0, a2[0]);
+      a2[1] = mfma_f64(sign * P[wr + 16 + r][t], b0, a2[1]);
+    }
+  }
+  // accumulator <-> tile (D layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 r, col = lane & 15)
+  template <typename F>
+  __device__ __forceinline__ void each(F f) const {
+    const int oc = wc8 + (lane & 15), orq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(m, r, wr + m * 16 + orq + 4 * r, oc);
+  }
+};
+
+constexpr size_t POTRF_LA_SMEM = sizeof(Potrf64Scratch) + 2 * 64 * LD * sizeof(double);
+
+__device__ __forceinline__ void la_tile_of_block(int b, int nb, int& i, int& k) {
+  // workgroups 1 ..: the off-diagonal tiles in column-major order (column k holds nb - 1 - k tiles)
+  int t = b - 1;
+  k = 0;
+  while (t >= nb - 1 - k) { t -= nb - 1 - k; ++k; }
+  i = k + 1 + t;
+}
+
+__global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int n = j.n, nb = j.nb;
+  unsigned* fL = j.flags;                      // [nb * nb]
+  unsigned* fInv = j.flags + nb * nb;          // [nb]
+  unsigned* fSub = fInv + nb;                  // [nb]
+  unsigned* fDone = fSub + nb;                 // [1]
+  const int nflags = nb * nb + 2 * nb + 1;
+  const LaWave lw;
+  auto finish = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned s_last;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(fDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last)
+      for (int e = tid; e < nflags; e += 512) __hip_atomic_store(j.flags + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  if (blockIdx.x == 0) {
+    // ------------------------------------------------------------------ the walker
+    Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
+    double (*S)[LD] = (double (*)[LD])smem_raw;                                              // aliases the scratch
+    double (*A)[LD] = (double (*)[LD])(smem_raw + sizeof(Potrf64Scratch));                    // M_k,k-1 -> L_k,k-1
+    double (*B)[LD] = (double (*)[LD])(smem_raw + sizeof(Potrf64Scratch) + 64 * LD * sizeof(double));   // L_k-1,k-1^-1
+    const __amdgpu_buffer_rsrc_t linv_r =
+        __builtin_amdgcn_make_buffer_rsrc((void*)j.Linv, 0, (int)(nb * 4096 * sizeof(double)), 0x00020000);
+    if (tid == 0) *j.status = 0;
+    la_load_tile(S, j.M, n);                                       // M_00 (written by the launch before this one)
+    __syncthreads();
+    // Nothing the walker publishes is drained on its own critical path: the flag of a payload is posted one phase later,
+    // behind a barrier that every wave reaches with `s_waitcnt vmcnt(0)` long after the stores were issued.
+    unsigned* pending = nullptr;                                   // flag of the L_k,k-1 tile whose stores are in flight
+    auto post_now = [&](unsigned* f) {
+      if (tid == 0 && f) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (int k = 0; k < nb; ++k) {
+      if (k > 0) {
+        la_wait(fSub + k, j.status);                               // (barrier: L_k-1,k-1^-1 is in LDS, the scratch is dead)
+        la_load_tile(A, j.M + (size_t)k * 64 * n + (size_t)(k - 1) * 64, n);
+        la_load_tile(S, j.M + (size_t)k * 64 * n + (size_t)k * 64, n);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile loads - and the stores of L_k-1,k-1^-1
+        __syncthreads();
+        post_now(fInv + (k - 1));
+        double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
+        lw.prod(pp, A, B, 1.0);                                    // L_k,k-1 = M_k,k-1 L_k-1,k-1^-T
+        __syncthreads();
+        lw.each([&](int m, int r, int row, int col) { A[row][col] = pp[m][r]; });
+        __syncthreads();
+        la_publish_tile(A, j.Lmat + (size_t)k * 64 * n + (size_t)(k - 1) * 64, n);
+        pending = fL + k * nb + (k - 1);
+        double4_t sacc[2];
+        lw.each([&](int m, int r, int row, int col) { sacc[m][r] = S[row][col]; });
+        lw.prod(sacc, A, A, -1.0);                                 // Schur complement of the diagonal tile
+        __syncthreads();
+        lw.each([&](int m, int r, int row, int col) { S[row][col] = sacc[m][r]; });
+        __syncthreads();
+      }
+      const int npiv = (j.n_valid - k * 64) < 64 ? (j.n_valid - k * 64) : 64;
+      UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drains the publish of L_k,k-1 before the factor's first barrier
+                    const pk_d2 a = *(const pk_d2*)&S[row][col], b = *(const pk_d2*)&S[row][col + 2];
+                    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+                  },
+                  [&](int row, int col, const double (&v)[4]) {
+                    const unsigned off = (unsigned)((k * 4096 + row * 64 + col) * sizeof(double));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, (double2_t){v[0], v[1]}), linv_r, off, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, (double2_t){v[2], v[3]}), linv_r, off + 16, 0, 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) B[row][col + e] = v[e];
+                  },
+                  sc, tid, j.status, k * 64, npiv, [&]() { post_now(pending); });
+    }
+    la_post(fInv + (nb - 1));                                      // (nobody waits for it; kept for symmetry of the flag set)
+    finish();
+    return;
+  }
+
+  // -------------------------------------------------------------------- an off-diagonal tile (i, k)
+  int ti, tk;
+  la_tile_of_block((int)blockIdx.x, nb, ti, tk);
+  double (*P)[LD] = (double (*)[LD])smem_raw;                      // L_ij, later this tile's accumulator
+  double (*Q)[LD] = P + 64;                                        // L_kj, later L_kk^-1
+  const bool sub = (ti == tk + 1);                                 // next to the diagonal: also carries M_ii
+  double4_t acc[2], dacc[2];
+  {
+    const double* Mik = j.M + (size_t)ti * 64 * n + (size_t)tk * 64;
+    lw.each([&](int m, int r, int row, int col) { acc[m][r] = Mik[(size_t)row * n + col]; });
+    if (sub) {
+      const double* Mii = j.M + (size_t)ti * 64 * n + (size_t)ti * 64;
+      lw.each([&](int m, int r, int row, int col) { dacc[m][r] = Mii[(size_t)row * n + col]; });
+    }
+  }
+  for (int jj = 0; jj < tk; ++jj) {
+    la_wait(fL + ti * nb + jj, j.status);
+    la_wait(fL + tk * nb + jj, j.status);
+    la_load_tile(P, j.Lmat + (size_t)ti * 64 * n + (size_t)jj * 64, n);
+    la_load_tile(Q, j.Lmat + (size_t)tk * 64 * n + (size_t)jj * 64, n);
+    __syncthreads();
+    lw.prod(acc, P, Q, -1.0);
+    if (sub) lw.prod(dacc, P, P, -1.0);
+    __syncthreads();
+  }
+  if (sub) {
+    // hand both tiles, up to date through column k - 1, to the walker (it owns the last update and the factor)
+    double* Mik = j.M + (size_t)ti * 64 * n + (size_t)tk * 64;
+    double* Mii = j.M + (size_t)ti * 64 * n + (size_t)ti * 64;
+    if (tk > 0) {                                                  // (column 0: the tiles in memory are already final)
+      lw.each([&](int m, int r, int row, int col) { P[row][col] = acc[m][r]; Q[row][col] = dacc[m][r]; });
+      __syncthreads();
+      la_publish_tile(P, Mik, n);
+      la_publish_tile(Q, Mii, n);
+    }
+    la_post(fSub + ti);
+    finish();
+    return;
+  }
+  la_wait(fInv + tk, j.status);
+  la_load_tile(Q, j.Linv + (size_t)tk * 4096, 64);
+  lw.each([&](int m, int r, int row, int col) { P[row][col] = acc[m][r]; });
+  __syncthreads();
+  double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
+  lw.prod(pp, P, Q, 1.0);                                          // L_ik = M_ik L_kk^-T
+  __syncthreads();
+  lw.each([&](int m, int r, int row, int col) { P[row][col] = pp[m][r]; });
+  __syncthreads();
+  la_publish_tile(P, j.Lmat + (size_t)ti * 64 * n + (size_t)tk * 64, n);
+  la_post(fL + ti * nb + tk);
+  finish();
+}
+
+// ------------------------------------------------------------------------------------------
 // triangular solves: X = L^-T L^-1 RHS for 16 columns per workgroup
 // ------------------------------------------------------------------------------------------
 template <bool RHS32>
@@ -213,9 +460,23 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
 
 }  // namespace
 
+constexpr int POTRF_LA_MAX_NB = 22;        // 1 + nb (nb - 1) / 2 workgroups <= 232: all tiles resident on a 256-CU chip
+
 int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid) {
   if (n_valid <= 0 || n_valid > n) n_valid = n;
   const int nb = n / 64;
+  if (nsplit == 1 && nb >= 3 && nb <= POTRF_LA_MAX_NB && h->sw.potrf_variant != 0 && h->la_flags) {
+    // one persistent launch with look-ahead (k_potrf_la)
+    static PerDeviceOnce la_once;
+    if (const int tok = la_once.first()) {
+      UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LA_SMEM));
+      la_once.commit(tok);
+    }
+    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags};
+    hipLaunchKernelGGL(k_potrf_la, dim3(1 + nb * (nb - 1) / 2), dim3(512), POTRF_LA_SMEM, st, job);
+    UCE_LAUNCH_CHECK();
+    return UCE_OK;
+  }
   const size_t smem = 3 * 64 * LD * sizeof(double);
   const size_t smem_first = sizeof(Potrf64Scratch);
   static_assert(sizeof(Potrf64Scratch) <= POTRF_STEP_SMEM, "scratch must fit the three tile regions");

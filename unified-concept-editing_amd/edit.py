@@ -101,6 +101,13 @@ class UceHandle:
                    "uce_solve_delta")
         return DeltaT
 
+    def solve_rhs(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """X [d, m] f32 = A^-1 B for an SPD f64 A [d, d] (destroyed) and an f64 B [d, m], m % 64 == 0."""
+        d, m = B.shape
+        X = torch.empty(d, m, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_solve_rhs(self._h, _ptr(A), _ptr(B), d, m, _ptr(X), _stream_ptr(self.device)), "uce_solve_rhs")
+        return X
+
     def apply(self, W_old: torch.Tensor, DeltaT: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         rows, d = W_old.shape
         out = torch.empty_like(W_old) if out is None else out
@@ -472,14 +479,23 @@ def drop_zero_scale_rows(C, G, s, n_edit: int):
 # the drop-in entry points
 # --------------------------------------------------------------------------------------------
 
-def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor,
-              lamb: float, algo: int = _lib.ALGO_AUTO) -> WeightSlab:
-    n_edit = 0 if G is None else G.shape[0]
-    if bool((s < 0).any()) or not (lamb > 0):
-        # the solver is Cholesky-only (SPD system); the reference's general LU inverse would accept these
+def check_spd_inputs(scales, lamb: float) -> None:
+    """The solver is Cholesky-only (SPD system); the reference's general LU inverse (torch.inverse, uce_sd_erase.py:82) would
+    accept negative scales / lamb <= 0.  Host-side check of the few scalars a job is built from - callers that build
+    `s` themselves run it ONCE (no device read-back per edit; the device-side pivot check reports through uce_status)."""
+    vals = [float(v) for v in (scales.tolist() if isinstance(scales, torch.Tensor) else scales)]
+    if any(v < 0 for v in vals) or not (lamb > 0):
         raise ValueError("erase/edit/preserve scales must be >= 0 and lamb > 0: the closed-form system "
                          "lamb*I + sum_i s_i c_i c_i^T is solved by a Cholesky factorisation (SPD only)")
-    C, G, s, n_edit = drop_zero_scale_rows(C, G, s, n_edit)
+
+
+def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor,
+              lamb: float, algo: int = _lib.ALGO_AUTO, validated: bool = False) -> WeightSlab:
+    n_edit = 0 if G is None else G.shape[0]
+    if not validated:
+        check_spd_inputs(s, lamb)
+    if not validated:                                  # (validated callers have already dropped zero-scale rows)
+        C, G, s, n_edit = drop_zero_scale_rows(C, G, s, n_edit)
     if C.shape[0] == 0 or n_edit == 0:
         # nothing pulls the weights anywhere: W_new = W_old exactly (Delta = 0)
         return slab.like(slab.data.clone())
@@ -522,14 +538,20 @@ class DebiasState:
         self.C_edit, self.C_debias = C_edit, C_debias
         n_e = C_edit.shape[0]
         n_p = 0 if C_pres is None else C_pres.shape[0]
+        if float(preserve_scale) == 0.0:                         # zero-scale rows contribute nothing: dropped here, once
+            n_p = 0
+        self.no_edit = float(edit_scale) == 0.0                  # nothing pulls the weights anywhere
         self.C = torch.cat([C_edit] + ([C_pres] if n_p else [])).contiguous()
         self.s = torch.tensor([float(edit_scale)] * n_e + [float(preserve_scale)] * n_p, dtype=torch.float32,
                               device=handle.device)
+        check_spd_inputs([edit_scale, preserve_scale], lamb)     # once: the per-iteration edits skip the read-back of `s`
         self.Dsum = torch.zeros(n_e, C_debias.shape[0], dtype=torch.float64, device=handle.device)
         self.current = slab.like(slab.data.clone())
 
     def step(self, direction_scale: np.ndarray) -> WeightSlab:
         self.Dsum += torch.as_tensor(np.asarray(direction_scale, dtype=np.float64), device=self.handle.device)
+        if self.no_edit:
+            return self.current
         G = self.handle.debias_targets(self.C_edit, self.C_debias, self.Dsum)
-        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb, self.algo)
+        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb, self.algo, validated=True)
         return self.current

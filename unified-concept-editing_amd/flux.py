@@ -59,12 +59,12 @@ def bias_direction(handle: E.UceHandle, C: torch.Tensor, s: torch.Tensor, lamb: 
     if (N + 63) // 64 * 64 < d:
         _, R = handle.dual_factors(C, C, s, lamb)              # every row as an "edit" row: R = K^-1 C, all N rows
         return R.double().sum(dim=0).float()
-    # N >= d: the primal system through the library's own Cholesky + triangular solves (uce_solve_delta solves A X = B for
-    # a [d, d] right-hand side: the vector rides in column 0)
+    # N >= d: the primal system through the library's own Cholesky + triangular solves with a NARROW right-hand side
+    # (uce_solve_rhs: 64 columns, the vector rides in column 0 - not a dense d x d solve for one column)
     A, _ = handle.gram(C, None, s, lamb)                       # f64 [d, d]
-    Bt = torch.zeros(d, d, dtype=torch.float64, device=handle.device)
-    Bt[:, 0] = (C.double() * s.double()[:, None]).sum(dim=0)
-    u = handle.solve_delta(A, Bt)[:, 0].contiguous()
+    B = torch.zeros(d, 64, dtype=torch.float64, device=handle.device)
+    B[:, 0] = (C.double() * s.double()[:, None]).sum(dim=0)
+    u = handle.solve_rhs(A, B)[:, 0].contiguous()
     handle.status()
     return u
 

@@ -287,6 +287,14 @@ USE_HIP_SELF_ATTENTION = True     # attn1 through uce_sattn_fwd on a GPU in bf16
 USE_HIP_CROSS_ATTENTION = True    # attn2 through uce_xattn_fwd (False: torch SDPA; comparison runs only)
 
 
+def sattn_prefers_hip(Lk: int) -> bool:
+    """Measured rule (bench.py's `sattn` rows, MI355X, generation batch): uce_sattn_fwd streams key tiles behind a V^T
+    pre-pass - ahead of torch's SDPA from 1024 keys up (the 4096- and 1024-token layers: 97 % of the attn1 time), 10 %
+    behind it at the 256- and 64-token layers, where the pre-pass and the prologue are a fifth of the launch.  SDPA on the
+    [B, L, H, dh] views returns that layout, so the hand-back to [B, L, C] is a view either way."""
+    return Lk > 256
+
+
 def _attention_core(q, k, v, heads: int, is_cross: bool):
     """[B, L, C] in / out.  On a GPU in bf16/f16: cross-attention -> uce_xattn_fwd, self-attention -> uce_sattn_fwd;
     otherwise torch SDPA."""
@@ -297,7 +305,7 @@ def _attention_core(q, k, v, heads: int, is_cross: bool):
         handle = _edit.UceHandle.get(q.device)
         if is_cross and k.shape[1] <= 128 and USE_HIP_CROSS_ATTENTION:
             return handle.xattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
-        if USE_HIP_SELF_ATTENTION and (USE_HIP_CROSS_ATTENTION or not is_cross):
+        if USE_HIP_SELF_ATTENTION and (USE_HIP_CROSS_ATTENTION or not is_cross) and sattn_prefers_hip(k.shape[1]):
             return handle.sattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
     B, Lq, C = q.shape
     dh = C // heads
