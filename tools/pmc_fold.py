@@ -19,11 +19,11 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")
-EDIT_KERNELS = ["k_lr_project", "k_lr_update_s", "k_lr_update", "k_lr_fused", "k_trisolve", "k_potrf_first", "k_potrf_step",
+EDIT_KERNELS = ["k_lr_project", "k_lr_update_s", "k_lr_update", "k_lr_fused", "k_trisolve", "k_potrf_la", "k_potrf_first", "k_potrf_step",
                 "k_potrf_panel", "k_potrf_diag", "k_trsm", "k_gram_primal", "k_gram_dual", "k_apply_b3", "k_split3", "k_apply",
                 "k_delta_factors", "k_apply_lowrank_generic", "k_reduce_slabs", "k_trinv_merge", "k_trinv_fwd", "k_trinv_bwd"]
 # bench.py's launch-chain scopes: per-step bytes = all launches of the members / launches of the FIRST member
-CHAINS = {"potrf": ["k_potrf_first", "k_potrf_step", "k_potrf_panel", "k_potrf_diag"],
+CHAINS = {"potrf": ["k_potrf_la", "k_potrf_first", "k_potrf_step", "k_potrf_panel", "k_potrf_diag"],
           "k_trisolve": ["k_trinv_fwd", "k_trinv_merge", "k_trinv_bwd"]}
 XATTN_SHAPES = ((4096, 40), (1024, 80), (256, 160), (64, 160))
 LAUNCHES_PER_SHAPE = 5          # bench.py --only xattn / sattn: one warm launch + 4 timed
@@ -88,7 +88,7 @@ def by_kernel(path, wanted):
     return g
 
 
-ALIASES = {"k_xattn_g": "k_xattn"}       # the column-group form and the per-head form serve the same call
+ALIASES = {"k_xattn_g": "k_xattn", "k_sattn_p": "k_sattn"}       # forms of one kernel that serve the same call
 
 
 def by_order(path, kernel_names, keys):
@@ -135,7 +135,7 @@ def main():
         for chain, members in CHAINS.items():
             have = [m for m in members if m in ent and "total_bytes" in ent[m]]
             if have and chain not in ent:
-                firsts = ent[members[0]]["launches"] if members[0] in ent else 1
+                firsts = ent[have[0]]["launches"]
                 tot = sum(ent[m]["total_bytes"] * ent[m]["launches"] for m in have) / max(firsts, 1)
                 ent[chain] = {"total_bytes": tot, "launches": firsts, "members": have}
         for e in ent.values():

@@ -126,9 +126,15 @@ struct PotrfNoHook {
 
 // `after_load`: called by every thread right after the barrier that follows the tile load (the persistent Cholesky posts a
 // hand-off flag there: the stores it covers were drained by the waves before that barrier, off the critical path).
-template <class LoadA, class StoreX, class Hook = PotrfNoHook>
+struct PotrfNoSide {
+  __device__ __forceinline__ void operator()(int, int) const {}
+};
+
+// `side(kb, nkb)`: called once per elimination iteration by waves 4-7 - they carry no tile and otherwise only meet the
+// barriers - so a caller can have them fetch what comes after the factor while waves 0-3 eliminate.
+template <class LoadA, class StoreX, class Hook = PotrfNoHook, class Side = PotrfNoSide>
 __device__ __forceinline__ void potrf64_pk(LoadA loadA, StoreX storeX, Potrf64Scratch* sc, int tid, int* status, int col_base,
-                                           int npiv, Hook after_load = Hook()) {
+                                           int npiv, Hook after_load = Hook(), Side side = Side()) {
   const int wave = tid >> 6, lane = tid & 63;
   PKS(0);
   // role 0: matrix tile, (i1, i2) = (row block, column block); role 1: X tile, transposed, (i1, i2) = (column block, row block)
@@ -204,6 +210,7 @@ __device__ __forceinline__ void potrf64_pk(LoadA loadA, StoreX storeX, Potrf64Sc
 #pragma unroll 1
     for (int kb = kb0; kb < kbe; ++kb) {
       if (wave < 4) pk_step<0>(w, lds, foff, soff, i2, kb, kstop);
+      else side(kb, nkb);
       __syncthreads();
       if (wave < 4) pk_step<2>(w, lds, foff, soff, i2, kb, kstop);
       __syncthreads();

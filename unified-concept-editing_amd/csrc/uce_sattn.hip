@@ -46,6 +46,26 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 
 constexpr int KT = 64;            // keys per tile
 
+// (query tile, head, batch) of a workgroup.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
+// its own L2: with the natural order the query tiles of one (batch, head) land on all 8 XCDs and every XCD streams every
+// K / V^T from HBM (PMC: 2.1 GB per launch at L = 4096, B = 32 for 0.34 GB of Q + K + V + O).  Remapped, the workgroups
+// an XCD receives walk the query tiles of ONE (batch, head) after another, whose K / V^T (0.65 MB) then stay in that L2.
+__device__ __forceinline__ void sattn_block(int& qx, int& h, int& b) {
+  const unsigned gx = gridDim.x, gy = gridDim.y, nbh = gridDim.y * gridDim.z;
+  if ((nbh & 7u) == 0u) {
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, slot = lin >> 3;
+    const unsigned bh = (slot / gx) * 8u + xcd;
+    qx = (int)(slot % gx);
+    h = (int)(bh % gy);
+    b = (int)(bh / gy);
+  } else {
+    qx = (int)blockIdx.x;
+    h = (int)blockIdx.y;
+    b = (int)blockIdx.z;
+  }
+}
+
 // V [B, Lk, C] -> Vt [B, H, DVP, LkP]; 64 keys x 64 dims per workgroup through LDS
 // ones_row >= 0: that (padding) row of V^T is set to 1.0 (`one`, in the element type) for the real keys, so the P V
 // product accumulates the softmax denominator in that output row for free (k_sattn's sum_mfma path).
@@ -100,10 +120,11 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   unsigned short* smem = (unsigned short*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int qx, h, b;
+  sattn_block(qx, h, b);
   const int C = H * dh;
   const int lq = lane & 31, lh = lane >> 5;
-  const long q0 = (long)blockIdx.x * (128 * QT) + w * (32 * QT);
+  const long q0 = (long)qx * (128 * QT) + w * (32 * QT);
 
   // ---- this lane's Q fragments (rows q0 + 32 t + lq, dims 16s + 8*lh .. +7)
   uint4_t qf[QT][NS];
@@ -321,10 +342,11 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
   unsigned short* Vbuf = Kbuf + 2 * KT * KLD;                        // [2][DVP * VLD]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int qx, h, b;
+  sattn_block(qx, h, b);
   const int C = H * dh;
   const int lq = lane & 31, lh = lane >> 5;
-  const long row = (long)blockIdx.x * 128 + w * 32 + lq;
+  const long row = (long)qx * 128 + w * 32 + lq;
 
   uint4_t qf[NS];
   {

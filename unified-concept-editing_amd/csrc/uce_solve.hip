@@ -67,6 +67,20 @@ __global__ __launch_bounds__(512) void k_potrf_step(double* __restrict__ M, int 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
+// -DUCE_CHAIN_DEBUG: wall-clock stamps (100 MHz) of the walker's phases per diagonal block, read back with
+// uce_debug_read_la (tools/dbg_potrf.py); compiled out of the product library.
+#ifdef UCE_CHAIN_DEBUG
+__device__ unsigned long long g_la_dbg[32][8];
+#define LADBG(k, slot) do { if ((threadIdx.x == 0 || threadIdx.x == 256) && (k) < 32) g_la_dbg[k][slot] = wall_clock64(); } while (0)
+__device__ __forceinline__ void g_la_stamp(int k) { g_la_dbg[k][6] = wall_clock64(); }
+extern "C" int uce_debug_read_la(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_la_dbg), sizeof(g_la_dbg));
+}
+#else
+#define LADBG(k, slot) do { } while (0)
+__device__ __forceinline__ void g_la_stamp(int) {}
+#endif
+
 struct PotrfLaJob {
   double* M;          // [n, n] system (lower tiles read; the tiles (i, i-1) and (i, i) are overwritten with their updates)
   int n, nb, n_valid;
@@ -128,16 +142,27 @@ struct LaWave {
     wr = (wq >> 1) * 32;
     wc8 = (wq & 1) * 32 + 16 * (w >> 2);
   }
-  __device__ __forceinline__ void prod(double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign) const {
+  // kb_end < 16: Q is lower triangular (an inverted diagonal block) - column block c of P Q^T only contracts over
+  // t < 16 (c + 1).  A 64^3 f64 product is MFMA-bound on one CU (2 us of the walker's critical path per product).
+  __device__ __forceinline__ void prod(double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign,
+                                       int kb_end = 16) const {
     const int r = lane & 15, kk = lane >> 4;
 #pragma unroll 4
-    for (int kb = 0; kb < 16; ++kb) {
+    for (int kb = 0; kb < kb_end; ++kb) {
       const int t = kb * 4 + kk;
       const double b0 = Q[wc8 + r][t];
       a2[0] = mfma_f64(sign * P[wr + r][t], b0, a2[0]);
       a2[1] = mfma_f64(sign * P[wr + 16 + r][t], b0, a2[1]);
     }
   }
+  // the triangular product's own tile map: the two waves of a SIMD (w, w + 4) take column blocks (0, 3) or (1, 2), so every
+  // SIMD issues 20 of the 32 k-steps a full contraction would
+  __device__ __forceinline__ void use_tri_map() {
+    const int w = threadIdx.x >> 6, hf = w >> 2;
+    wr = (w & 2) ? 32 : 0;
+    wc8 = 16 * ((w & 1) ? (hf ? 2 : 1) : (hf ? 3 : 0));
+  }
+  __device__ __forceinline__ int tri_kb_end() const { return (wc8 + 16) / 4; }
   // accumulator <-> tile (D layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 r, col = lane & 15)
   template <typename F>
   __device__ __forceinline__ void each(F f) const {
@@ -169,6 +194,8 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
   unsigned* fDone = fSub + nb;                 // [1]
   const int nflags = nb * nb + 2 * nb + 1;
   const LaWave lw;
+  LaWave lwt;
+  lwt.use_tri_map();
   auto finish = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -191,23 +218,35 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     la_load_tile(S, j.M, n);                                       // M_00 (written by the launch before this one)
     __syncthreads();
     // Nothing the walker publishes is drained on its own critical path: the flag of a payload is posted one phase later,
-    // behind a barrier that every wave reaches with `s_waitcnt vmcnt(0)` long after the stores were issued.
+    // behind a barrier that every wave reaches with `s_waitcnt vmcnt(0)` long after the stores were issued.  And nothing it
+    // consumes is fetched on it: waves 4-7, idle while waves 0-3 eliminate, poll for the next block's two tiles during
+    // the last iterations of the factor and pull them in (one into the free A tile, one into 32 VGPRs).
     unsigned* pending = nullptr;                                   // flag of the L_k,k-1 tile whose stores are in flight
     auto post_now = [&](unsigned* f) {
       if (tid == 0 && f) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    double2_t ps[8];                                               // waves 4-7: pieces of M_k+1,k+1 (M_k+1,k goes straight into A)
+    const int st = tid - 256;                                      // index among the 256 side threads
     for (int k = 0; k < nb; ++k) {
+      LADBG(k, 0);
       if (k > 0) {
-        la_wait(fSub + k, j.status);                               // (barrier: L_k-1,k-1^-1 is in LDS, the scratch is dead)
-        la_load_tile(A, j.M + (size_t)k * 64 * n + (size_t)(k - 1) * 64, n);
-        la_load_tile(S, j.M + (size_t)k * 64 * n + (size_t)k * 64, n);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile loads - and the stores of L_k-1,k-1^-1
+        __syncthreads();                                           // the factor is over: L_k-1,k-1^-1 is in LDS, the scratch is dead
+        if (st >= 0) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            const int e = 2 * (st + 256 * p);
+            *(double2_t*)&S[e >> 6][e & 63] = ps[p];
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores of L_k-1,k-1^-1
         __syncthreads();
         post_now(fInv + (k - 1));
+        LADBG(k, 1);
         double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
-        lw.prod(pp, A, B, 1.0);                                    // L_k,k-1 = M_k,k-1 L_k-1,k-1^-T
+        lwt.prod(pp, A, B, 1.0, lwt.tri_kb_end());                 // L_k,k-1 = M_k,k-1 L_k-1,k-1^-T (L^-1 is lower triangular)
         __syncthreads();
-        lw.each([&](int m, int r, int row, int col) { A[row][col] = pp[m][r]; });
+        LADBG(k, 2);
+        lwt.each([&](int m, int r, int row, int col) { A[row][col] = pp[m][r]; });
         __syncthreads();
         la_publish_tile(A, j.Lmat + (size_t)k * 64 * n + (size_t)(k - 1) * 64, n);
         pending = fL + k * nb + (k - 1);
@@ -218,7 +257,10 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
         lw.each([&](int m, int r, int row, int col) { S[row][col] = sacc[m][r]; });
         __syncthreads();
       }
+      LADBG(k, 3);
       const int npiv = (j.n_valid - k * 64) < 64 ? (j.n_valid - k * 64) : 64;
+      const double* nextA = j.M + (size_t)(k + 1) * 64 * n + (size_t)k * 64;
+      const double* nextS = j.M + (size_t)(k + 1) * 64 * n + (size_t)(k + 1) * 64;
       UCE_POTRF64([&](int row, int col, double (&v)[4]) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drains the publish of L_k,k-1 before the factor's first barrier
                     const pk_d2 a = *(const pk_d2*)&S[row][col], b = *(const pk_d2*)&S[row][col + 2];
@@ -231,7 +273,44 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) B[row][col + e] = v[e];
                   },
-                  sc, tid, j.status, k * 64, npiv, [&]() { post_now(pending); });
+                  sc, tid, j.status, k * 64, npiv, [&]() { post_now(pending); },
+                  [&](int kb, int nkb) {
+                    // waves 4-7, three iterations before the end of the factor (or at once for a short one): the tiles the
+                    // sub-diagonal workgroup (k+1, k) has handed over
+                    if (k + 1 >= nb || kb != (nkb > 3 ? nkb - 3 : 0)) return;
+                    LADBG(k, 5);
+                    if ((tid & 63) == 0) {
+                      unsigned spins = 0;
+                      while (__hip_atomic_load(fSub + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 25)) {
+                          atomicCAS(j.status, 0, -1);
+                          break;
+                        }
+                      }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    // M_k+1,k -> the A tile (L_k,k-1 left it when its publish was issued, before this factor began);
+                    // M_k+1,k+1 stays in registers until the scratch it belongs in is dead
+                    double2_t pa[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                      const int e = 2 * (st + 256 * p);
+                      pa[p] = *(const double2_t*)(nextA + (size_t)(e >> 6) * n + (e & 63));
+                    }
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                      const int e = 2 * (st + 256 * p);
+                      ps[p] = *(const double2_t*)(nextS + (size_t)(e >> 6) * n + (e & 63));
+                    }
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                      const int e = 2 * (st + 256 * p);
+                      *(double2_t*)&A[e >> 6][e & 63] = pa[p];
+                    }
+                    if (tid == 256 && k < 32) g_la_stamp(k);
+                  });
+      LADBG(k, 4);
     }
     la_post(fInv + (nb - 1));                                      // (nobody waits for it; kept for symmetry of the flag set)
     finish();
@@ -282,9 +361,9 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
   lw.each([&](int m, int r, int row, int col) { P[row][col] = acc[m][r]; });
   __syncthreads();
   double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
-  lw.prod(pp, P, Q, 1.0);                                          // L_ik = M_ik L_kk^-T
+  lwt.prod(pp, P, Q, 1.0, lwt.tri_kb_end());                       // L_ik = M_ik L_kk^-T
   __syncthreads();
-  lw.each([&](int m, int r, int row, int col) { P[row][col] = pp[m][r]; });
+  lwt.each([&](int m, int r, int row, int col) { P[row][col] = pp[m][r]; });
   __syncthreads();
   la_publish_tile(P, j.Lmat + (size_t)ti * 64 * n + (size_t)tk * 64, n);
   la_post(fL + ti * nb + tk);

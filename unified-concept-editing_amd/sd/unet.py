@@ -14,6 +14,8 @@ the C ABI when the module lives on a GPU in bf16/f16; everything else is stock t
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -292,7 +294,10 @@ def sattn_prefers_hip(Lk: int) -> bool:
     pre-pass - ahead of torch's SDPA from 1024 keys up (the 4096- and 1024-token layers: 97 % of the attn1 time), 10 %
     behind it at the 256- and 64-token layers, where the pre-pass and the prologue are a fifth of the launch.  SDPA on the
     [B, L, H, dh] views returns that layout, so the hand-back to [B, L, C] is a view either way."""
-    return Lk > 256
+    return Lk > SATTN_HIP_MIN_KEYS
+
+
+SATTN_HIP_MIN_KEYS = int(os.environ.get("UCE_SATTN_MIN_KEYS", "256"))     # (A/B runs only)
 
 
 def _attention_core(q, k, v, heads: int, is_cross: bool):
