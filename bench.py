@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak
 F64_MFMA_PEAK_TF = 78.6      # dense f64 MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak (no sparsity)
-CPU_BASELINE_THREADS = 4     # fixed (measured fastest for the reference's many small ops on the GPU box's EPYC host)
+CPU_BASELINE_THREADS = 4     # first point of the thread sweep (the fastest count on the GPU box's EPYC host so far)
 
 WORKLOADS = {
     # name: (N_edit, N_preserve, d, module table, BASELINE.json config index)
@@ -116,15 +116,27 @@ def cpu_baseline(inp, repeats: int = 5):
     guide = [G[i:i + 1] for i in range(n_e)]
     pres = [C[n_e + i:n_e + i + 1] for i in range(n_p)]
     ncpu = os.cpu_count() or 1
-    threads = min(CPU_BASELINE_THREADS, ncpu)
-    torch.set_num_threads(threads)
 
     def whole():
         t = time.perf_counter()
         O.uce_edit_ref(ws, edit, guide, pres, 1.0, 1.0, 0.5)
         return time.perf_counter() - t
 
+    # thread sweep, one whole edit each after one untimed run (the reference's op order is ~10^4 small torch ops per edit:
+    # it does not scale with cores; SURVEY 8d asks for the count to be stated): the fastest count runs the timed sample
+    torch.set_num_threads(min(CPU_BASELINE_THREADS, ncpu))
     whole()
+    sweep = {}
+    if repeats >= 5:
+        for th in sorted({min(CPU_BASELINE_THREADS, ncpu), min(16, ncpu), min(64, ncpu), ncpu}):
+            torch.set_num_threads(th)
+            sweep[str(th)] = round(whole(), 4)
+            if sweep[str(th)] > 4.0 * min(sweep.values()):
+                break                                        # far slower already: do not spend the budget on larger counts
+        threads = int(min(sweep, key=sweep.get))
+    else:
+        threads = min(CPU_BASELINE_THREADS, ncpu)
+    torch.set_num_threads(threads)
     times = []
     t0 = time.perf_counter()
     for _ in range(repeats):
@@ -136,6 +148,7 @@ def cpu_baseline(inp, repeats: int = 5):
     return dict(value=round(n / med, 2), unit="concepts/s", cores=threads, kind="port",
                 cpu=cpu_model(), physical_cores=physical_cores(), logical_cpus=ncpu,
                 seconds_per_edit=dict(median=round(med, 4), min=round(min(times), 4), max=round(max(times), 4)),
+                thread_sweep_seconds_per_edit=sweep,
                 sample=f"{len(times)} whole edits (all {len(ws)} modules, {n} concepts) after one untimed run, median "
                        f"{med:.3f} s, on {threads} torch threads of {ncpu} logical CPUs")
 
@@ -199,6 +212,17 @@ def kernel_model(name: str, path: str, N: int, n_e: int, d: int, rows: int):
     return "hbm", 0.0, HBM_PEAK_GBS, "GB/s", "unmodelled"
 
 
+def _source_hash():
+    try:
+        from uce_amd import build
+        return build.source_hash()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+SOURCE_HASH = _source_hash()       # state of csrc/ this run was built from (profiles/traffic.json entries carry theirs)
+
+
 def load_traffic():
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -227,6 +251,10 @@ def kernel_breakdown(H, inp, algo: int, step, iters: int = 30):
         ent["traffic"] = t.get("total_bytes") if isinstance(t, dict) else None
         if isinstance(t, dict) and t.get("mfma_util") is not None:
             ent["mfma_util"] = t["mfma_util"]
+        if isinstance(t, dict):
+            # the counters are folded from separate rocprofv3 passes (profiles/traffic.json): say which library they saw
+            ent["traffic_src"] = t.get("src")
+            ent["traffic_stale"] = bool(t.get("src") is not None and t.get("src") != SOURCE_HASH)
         rows_out.append(ent)
     rows_out.sort(key=lambda e: -e["share"])
     if path == "dual_lowrank" and N <= 128:
@@ -491,6 +519,7 @@ def xattn_leg(device, batches=(2, 16), iters: int = 100):
             t = traffic.get(f"B{B}_Lq{Lq}_dh{dh}")
             if isinstance(t, dict):
                 ent["traffic"] = t.get("total_bytes")
+                ent["traffic_stale"] = bool(t.get("src") is not None and t.get("src") != SOURCE_HASH)
                 if t.get("mfma_util") is not None:
                     ent["mfma_util"] = t["mfma_util"]
             out.append(ent)
@@ -505,7 +534,7 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
     MFMA peak (the loop is VALU-bound on the online softmax, not MFMA-bound)."""
     import torch.nn.functional as F
     from uce_amd import edit as E
-    from uce_amd.sd.unet import sattn_prefers_hip
+    from uce_amd.sd import unet as sd_unet
     H = E.UceHandle.get(device)
     traffic = load_traffic().get("sattn", {})
     out = []
@@ -522,10 +551,11 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
             sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)  # noqa: E731
             ent["torch_sdpa_us"] = round(time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), iters) * 1e3, 1)
         # what the U-Net launches at this shape (sd/unet.py: measured rule) - the kernel above or torch's SDPA
-        ent["unet_dispatch"] = "uce_sattn_fwd" if sattn_prefers_hip(L) else "torch_sdpa"
+        ent["unet_dispatch"] = "uce_sattn_fwd" if sd_unet.sattn_prefers_hip(L) else "torch_sdpa"
         t = traffic.get(f"B{B}_L{L}_dh{dh}")
         if isinstance(t, dict):
             ent["traffic"] = t.get("total_bytes")
+            ent["traffic_stale"] = bool(t.get("src") is not None and t.get("src") != SOURCE_HASH)
             if t.get("mfma_util") is not None:
                 ent["mfma_util"] = t["mfma_util"]
         out.append(ent)

@@ -113,6 +113,16 @@ def load():
     return json.load(open(TRAFFIC)) if os.path.exists(TRAFFIC) else {}
 
 
+def lib_abi():
+    """Hash of the kernel sources in the tree (the state the passes were run on, when folded right after them)."""
+    try:
+        sys.path.insert(0, ROOT)
+        from uce_amd import build
+        return build.source_hash()
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def save(data):
     data["_comment"] = ("HBM bytes per launch and MFMA utilisation from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE / SQ passes, "
                         "tools/prof_round.sh -> tools/pmc_fold.py); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide "
@@ -140,6 +150,7 @@ def main():
                 ent[chain] = {"total_bytes": tot, "launches": firsts, "members": have}
         for e in ent.values():
             e["source"] = os.path.basename(os.path.normpath(d))
+            e["src"] = lib_abi()
         data[workload] = ent
         for k, e in sorted(ent.items()):
             print(f"{workload} {k}: " + (f"{e['total_bytes'] / 1e6:.2f} MB/launch " if "total_bytes" in e else "")
@@ -165,6 +176,7 @@ def main():
             if "mfma_util" in main_k:
                 m["mfma_util"] = main_k["mfma_util"]
             m["source"] = os.path.basename(os.path.normpath(d))
+            m["src"] = lib_abi()
             print(f"{mode} {key}: {m['total_bytes'] / 1e6:.2f} MB/launch mfma_util {m.get('mfma_util')}")
         data[mode] = merged
     else:

@@ -62,6 +62,16 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def source_hash() -> str:
+    """Short hash of every kernel source and header: which state of csrc/ a measurement belongs to (profiles/traffic.json
+    stamps it next to the folded counters; bench.py flags entries collected on another state as stale)."""
+    h = hashlib.sha256()
+    for path in sources() + headers():
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build() -> bool:
     """True when the library is missing or older than ANY csrc/*.hip, csrc/*.h or the public header."""
     return _stale(LIB_PATH, sources() + headers())
