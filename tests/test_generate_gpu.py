@@ -76,3 +76,33 @@ def test_rccl_broadcast_of_the_edited_weights_single_rank(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RCCL_BCAST_OK nccl 3" in r.stdout
+
+
+def test_real_coco30k_rows_at_sd14_size(tmp_path):
+    """Rows of the reference's REAL prompt table (the committed fixture: tests/golden/coco30k_rows.csv, incl. a caption with a
+    quoted newline) through generate_images at SD-1.4 size: the PNG names the reference wrote for that window, and each image
+    = what pipe(prompt, generator=CPU generator seeded with the row's evaluation_seed) gives for the prompt and seed the
+    reference passed (coco30k_rows.json)."""
+    import json
+    from uce_amd import generate
+    from uce_amd.sd import pipeline as sdp
+    csv_path = os.path.join(REPO_ROOT, "tests", "golden", "coco30k_rows.csv")
+    meta = json.load(open(os.path.join(REPO_ROOT, "tests", "golden", "coco30k_rows.json")))
+    win = meta["windows"][1]                                           # from_case 85 ... till_case 2539, 2 images per prompt
+    calls = [c for c in win["calls"]][:4]                              # the first four rows of that window
+    assert "\n" in calls[0]["prompt"]                                  # case 85: the multi-line caption
+    cases = sorted({int(f.split("_")[0]) for f in win["files"]})[:4]
+    pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.bfloat16, "cuda:0", synthetic=True, vae=True)
+    kw = dict(model_id="CompVis/stable-diffusion-v1-4", uce_model_path=None, prompts_path=csv_path, save_path=str(tmp_path),
+              device="cuda:0", torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=8, num_images_per_prompt=2,
+              synthetic=True, pipe=pipe)
+    stats = generate.generate_images(exp_name="png", from_case=cases[0], till_case=cases[-1], batch_prompts=3, **kw)
+    want_files = [f for f in win["files"] if int(f.split("_")[0]) in cases]
+    assert sorted(os.listdir(tmp_path / "png")) == sorted(want_files) and stats["images"] == len(want_files) == 8
+    generate.generate_images(exp_name="lat", from_case=cases[0], till_case=cases[-1], batch_prompts=3, latents_only=True, **kw)
+    for case, call in zip(cases, calls):
+        got = torch.load(tmp_path / "lat" / f"{case}.pt").float()
+        alone = pipe(call["prompt"], num_inference_steps=8, guidance_scale=7.5, num_images_per_prompt=2,
+                     generator=torch.Generator().manual_seed(call["seed"]), output_type="latent").latents.float().cpu()
+        assert got.shape == alone.shape == (2, 4, 64, 64)
+        assert float((got - alone).norm() / alone.norm()) < 3e-2, case   # batched vs alone: different GEMM shapes, same draw

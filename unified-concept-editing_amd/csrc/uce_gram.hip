@@ -56,20 +56,27 @@ __device__ __forceinline__ void store_quadrant(double* out, int ld, int row0, in
 // ------------------------------------------------------------------------------------------
 // primal: tiles [0, nA) are the lower-triangular tiles of A, tiles [nA, nA + nb*nb) those of Bt
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gram_primal(const float* __restrict__ C,
+// 8 waves: two quads of 4 waves, each quad a full 64 x 64 tile over ALTERNATE 32-concept chunks (its own LDS staging);
+// quad 1's accumulators are added to quad 0's through LDS at the end (fixed order: bit-repeatable).  With one wave per
+// SIMD (round 2: 4 waves) the f64 MFMA pipe sat idle through every staging write, barrier and fragment read of its only
+// wave: 0.33 of the f64 peak; two waves per SIMD cover each other's stalls.
+__global__ __launch_bounds__(512) void k_gram_primal(const float* __restrict__ C,
                                                      const float* __restrict__ G,
                                                      const float* __restrict__ s, int N, int N_edit,
                                                      int d, float lamb, double* __restrict__ outA,
                                                      double* __restrict__ outBt, int kchunk,
                                                      size_t slab_stride) {
-  __shared__ __attribute__((aligned(16))) float Xs[KC][64];
-  __shared__ __attribute__((aligned(16))) float Ys[KC][64];
-  __shared__ float Ss[KC];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_raw[2 * 2 * KC * 64 * sizeof(float)];   // 32 KB
+  __shared__ float Ss[2][KC];
+  float (*Xs)[KC][64] = (float (*)[KC][64])stage_raw;                         // [2][KC][64]
+  float (*Ys)[KC][64] = (float (*)[KC][64])(stage_raw + 2 * KC * 64 * sizeof(float));
+  double (*Red)[64] = (double (*)[64])stage_raw;   // [64][64]: quad 1's tile on its way to quad 0 (the staging is dead by then)
 
   const int nb = d / 64;
   const int nA = nb * (nb + 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 1, wc = w & 1;
+  const int half = w >> 2, wq = w & 3, ht = tid & 255;
+  const int wr = wq >> 1, wc = wq & 1;
   int ti, tj;
   bool isA = (int)blockIdx.x < nA;
   if (isA) tri_decode(blockIdx.x, ti, tj);
@@ -85,10 +92,9 @@ __global__ __launch_bounds__(256) void k_gram_primal(const float* __restrict__ C
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const int lrow = tid >> 4;          // 0..15
-  const int lc4 = (tid & 15) * 4;     // 0..60
-  // register prefetch of the next 32-concept chunk: the global loads of chunk k+1 are in flight while chunk k is
-  // multiplied (single-buffered LDS: load -> barrier -> MFMA -> barrier left the f64 MFMA pipe idle half the time)
+  const int lrow = ht >> 4;           // 0..15
+  const int lc4 = (ht & 15) * 4;      // 0..60
+  // register prefetch of this quad's next 32-concept chunk: its global loads are in flight while the current one is multiplied
   float4_t px[KC / 16], py[KC / 16];
   float ps = 0.f;
   auto g_load = [&](int k0) {
@@ -105,32 +111,55 @@ __global__ __launch_bounds__(256) void k_gram_primal(const float* __restrict__ C
         else py[p] = *(const float4_t*)(G + (size_t)n * d + tj * 64 + lc4) - cy;
       }
     }
-    if (tid < KC) ps = (k0 + tid < k_end) ? s[k0 + tid] : 0.f;
+    if (ht < KC) ps = (k0 + ht < k_end) ? s[k0 + ht] : 0.f;
   };
-  if (k_begin < k_end) g_load(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += KC) {
+  // quad `half` owns chunks half, half + 2, ...; the loop count is the same for both quads (barriers are workgroup-wide):
+  // a quad whose chunk lies beyond k_end stages zeros
+  const int kq = k_begin + half * KC;
+  if (k_begin < k_end) g_load(kq);
+  for (int k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
 #pragma unroll
     for (int p = 0; p < KC / 16; ++p) {
-      *(float4_t*)&Xs[p * 16 + lrow][lc4] = px[p];
-      *(float4_t*)&Ys[p * 16 + lrow][lc4] = py[p];
+      *(float4_t*)&Xs[half][p * 16 + lrow][lc4] = px[p];
+      *(float4_t*)&Ys[half][p * 16 + lrow][lc4] = py[p];
     }
-    if (tid < KC) Ss[tid] = ps;
+    if (ht < KC) Ss[half][ht] = ps;
     __syncthreads();
-    if (k0 + KC < k_end) g_load(k0 + KC);
+    if (k0 + 2 * KC < k_end) g_load(k0 + 2 * KC + half * KC);
 #pragma unroll
     for (int kb = 0; kb < KC / 4; ++kb) {
       const int kk = kb * 4 + (lane >> 4);
-      const double sc = (double)Ss[kk];
-      const double a0 = (double)Xs[kk][wr * 32 + (lane & 15)] * sc;
-      const double a1 = (double)Xs[kk][wr * 32 + 16 + (lane & 15)] * sc;
-      const double b0 = (double)Ys[kk][wc * 32 + (lane & 15)];
-      const double b1 = (double)Ys[kk][wc * 32 + 16 + (lane & 15)];
+      const double sc = (double)Ss[half][kk];
+      const double a0 = (double)Xs[half][kk][wr * 32 + (lane & 15)] * sc;
+      const double a1 = (double)Xs[half][kk][wr * 32 + 16 + (lane & 15)] * sc;
+      const double b0 = (double)Ys[half][kk][wc * 32 + (lane & 15)];
+      const double b1 = (double)Ys[half][kk][wc * 32 + 16 + (lane & 15)];
       acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
       acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
       acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
       acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
     }
     __syncthreads();
+  }
+  // quad 1 -> LDS -> quad 0 (D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15)
+  {
+    const int c = lane & 15, rq = lane >> 4;
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Red[wr * 32 + m * 16 + rq + 4 * r][wc * 32 + n * 16 + c] = acc[m][n][r];
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] += Red[wr * 32 + m * 16 + rq + 4 * r][wc * 32 + n * 16 + c];
   }
   double* out = (isA ? outA : outBt) + (size_t)split * slab_stride;
   store_quadrant(out, d, ti * 64 + wr * 32, tj * 64 + wc * 32, acc, lane, isA && ti != tj,
@@ -254,7 +283,7 @@ int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* 
   nsplit = (N + kchunk - 1) / kchunk;
   const size_t mat = (size_t)d * d;
   if (nsplit == 1) {
-    hipLaunchKernelGGL(k_gram_primal, dim3(tiles, 1), dim3(256), 0, st, C, G, s, N, N_edit, d, lamb, A, Bt,
+    hipLaunchKernelGGL(k_gram_primal, dim3(tiles, 1), dim3(512), 0, st, C, G, s, N, N_edit, d, lamb, A, Bt,
                        kchunk, (size_t)0);
     UCE_LAUNCH_CHECK();
     return UCE_OK;
@@ -264,7 +293,7 @@ int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* 
   if (need > h->slabs_bytes) return UCE_ENOMEM;
   double* sA = h->slabs;
   double* sB = h->slabs + mat;
-  hipLaunchKernelGGL(k_gram_primal, dim3(tiles, nsplit), dim3(256), 0, st, C, G, s, N, N_edit, d, lamb, sA,
+  hipLaunchKernelGGL(k_gram_primal, dim3(tiles, nsplit), dim3(512), 0, st, C, G, s, N, N_edit, d, lamb, sA,
                      sB, kchunk, 2 * mat);
   UCE_LAUNCH_CHECK();
   // a split whose k-range is beyond N_edit still writes zeros to its Bt slab, so both reduce fully
