@@ -1077,7 +1077,8 @@ int launch_update_d(const float* W_old, const float* T, const float* R, float* W
                     int NEP64, hipStream_t st) {
   // 16-row tiles, 2 waves per SIMD: measured best at N_edit 16..128 on MI355X (32-row tiles: +4-9 %)
   // (3 / 4 waves per SIMD measured in round 3: SDXL slab 564 -> 610 / 537 us, 100 concepts 45 -> 45 / 78 us (spills): kept at 2)
-  // (32-row tiles for the SDXL slab measured in round 3: 520-570 us either way, inside the run-to-run spread)
+  // (measured in round 3 on the SDXL slab and without effect beyond the 520-570 us run-to-run spread: 32-row tiles; weight
+  // rows of two column groups in flight instead of one)
   if (N_edit <= 128) return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
   return launch_update_v<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);   // 129 <= N_edit <= 256: ring-buffered form
 }
