@@ -169,7 +169,7 @@ int uce_create(uce_handle_t* out, int device) {
   (void)hipMemset(h->status, 0, sizeof(int));
   if (hipMalloc((void**)&h->ticket, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->ticket, 0, 4 * sizeof(unsigned));
-  constexpr size_t LA_FLAGS = 22 * 22 + 2 * 22 + 8;            // k_potrf_la: systems of up to 22 diagonal blocks
+  constexpr size_t LA_FLAGS = 2 * 22 * 22 + 2 * 22 + 8;        // k_potrf_la: systems of up to 22 diagonal blocks
   if (hipMalloc((void**)&h->la_flags, LA_FLAGS * sizeof(unsigned)) == hipSuccess) (void)hipMemset(h->la_flags, 0, LA_FLAGS * sizeof(unsigned));
   else h->la_flags = nullptr;                                  // (the launch chain is used instead)
   *out = h;

@@ -66,7 +66,8 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
 //   UCE_SATTN_QT        0: self-attention kernel by measured rule | 1: k_sattn, one query tile per wave | 2: two query tiles
 //                       wherever dh <= 48 | 3: the software-pipelined k_sattn_p wherever it exists
-//   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..22 diagonal blocks | 0: the launch chain
+//   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..22 diagonal blocks that also forms L^-1 |
+//                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt;
 };
@@ -86,6 +87,7 @@ struct uce_ctx {
   double* Bt;     // [d_cap, d_cap] right-hand side of the primal solve
   double* Yg;     // [n_cap, d_cap] intermediate of the triangular solves (Y = L^-1 RHS)
   double* Wi;     // [n_cap, n_cap] explicit L^-1 of the GEMM-shaped triangular solves (uce_trinv.hip)
+  bool wi_valid;  // the last factorisation on this handle already formed the off-diagonal blocks of L^-1 in Wi (k_potrf_la)
   float* DeltaT;  // [d_cap, d_cap]
   unsigned short* DeltaP;  // [3][d_cap, d_cap] bf16 planes of Delta^T (uce_apply_b3.hip)
   float* Dm;      // [n_cap, d_cap]

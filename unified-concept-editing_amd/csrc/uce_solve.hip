@@ -58,8 +58,9 @@ __global__ __launch_bounds__(512) void k_potrf_step(double* __restrict__ M, int 
 //     L_ik and publishes it.  The tile next to the diagonal, (i, i-1), also accumulates the diagonal tile M_ii (same L_ij
 //     operand) and hands both to the walker instead of finishing itself.
 // Hand-offs: payload with 16-byte write-through stores -> drained -> barrier -> relaxed flag; the reader polls the flag,
-// passes a barrier, runs an agent-scope ACQUIRE (invalidates what its L1 / its XCD's L2 may still hold of the previous
-// launch's tiles at the same addresses) and reads with plain 16-byte loads at full cache bandwidth.  Workgroups are
+// passes a barrier and reads the payload with 16-byte L1-bypassing (sc1) buffer loads - no acquire: an agent-scope acquire
+// invalidates the XCD's L2 under every workgroup on it, and with a few hundred hand-offs per launch those invalidates
+// cost the factorisation more than the bypassing loads do (measured: +29 us on the walker's chain).  Workgroups are
 // ordered so that nobody but the walker waits for a higher-numbered workgroup (column-major tiles): progress never depends
 // on all workgroups being resident at once.  Every wait is bounded (status -1 instead of a hang).  The flags are zero
 // between launches: the workgroup that finishes last clears them.
@@ -88,8 +89,12 @@ struct PotrfLaJob {
   double* Linv;       // [nb][64][64]
   int* status;
   unsigned* flags;    // [nb * nb] panel (i, j) published | [nb] L_kk^-1 published | [nb] tiles (k, k-1), (k, k) handed over | [1] exits
+                      // | [nb * nb] block (i, k) of L^-1 published
+  double* Wi;         // [n, n]: off-diagonal blocks of L^-1 (null: not wanted)
 };
 
+// `acquire` = false: the caller reads the payload with L1-bypassing (sc1) loads and needs no cache invalidate
+template <bool ACQUIRE = true>
 __device__ __forceinline__ bool la_wait(const unsigned* flag, int* status) {
   bool ok = true;
   if (threadIdx.x == 0) {
@@ -104,7 +109,7 @@ __device__ __forceinline__ bool la_wait(const unsigned* flag, int* status) {
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return ok;
 }
 
@@ -120,6 +125,31 @@ __device__ __forceinline__ void la_load_tile(double (*T)[LD], const double* G, i
   for (int p = 0; p < 4; ++p) {
     const int e = 2 * (threadIdx.x + 512 * p);
     *(double2_t*)&T[e >> 6][e & 63] = *(const double2_t*)(G + (size_t)(e >> 6) * ld + (e & 63));
+  }
+}
+// L1-bypassing forms (16-byte buffer loads with sc1): a reader that uses them needs no acquire - an agent-scope acquire
+// invalidates the XCD's L2 for every workgroup on it, and the W workgroups below would issue hundreds of them beside the
+// factorisation they ride along with
+__device__ __forceinline__ double2_t la_ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ void la_load_tile_sc1(double (*T)[LD], const double* G, int ld, bool transpose) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)G, 0, (int)(64 * ld * sizeof(double)), 0x00020000);
+  double2_t v[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = 2 * (threadIdx.x + 512 * p);
+    v[p] = la_ld_sc1(r, (unsigned)(((e >> 6) * ld + (e & 63)) * sizeof(double)));
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = 2 * (threadIdx.x + 512 * p);
+    if (transpose) {
+      T[e & 63][e >> 6] = v[p][0];
+      T[(e & 63) + 1][e >> 6] = v[p][1];
+    } else {
+      *(double2_t*)&T[e >> 6][e & 63] = v[p];
+    }
   }
 }
 __device__ __forceinline__ void la_publish_tile(const double (*T)[LD], double* G, int ld) {
@@ -192,7 +222,9 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
   unsigned* fInv = j.flags + nb * nb;          // [nb]
   unsigned* fSub = fInv + nb;                  // [nb]
   unsigned* fDone = fSub + nb;                 // [1]
-  const int nflags = nb * nb + 2 * nb + 1;
+  unsigned* fW = fDone + 1;                    // [nb * nb]
+  const int nflags = 2 * nb * nb + 2 * nb + 1;
+  const int ntiles = nb * (nb - 1) / 2;
   const LaWave lw;
   LaWave lwt;
   lwt.use_tri_map();
@@ -289,19 +321,20 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
                         }
                       }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     // M_k+1,k -> the A tile (L_k,k-1 left it when its publish was issued, before this factor began);
-                    // M_k+1,k+1 stays in registers until the scratch it belongs in is dead
+                    // M_k+1,k+1 stays in registers until the scratch it belongs in is dead.  L1-bypassing loads: no acquire
+                    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)nextA, 0, (int)(64 * n * sizeof(double)), 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)nextS, 0, (int)(64 * n * sizeof(double)), 0x00020000);
                     double2_t pa[8];
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
                       const int e = 2 * (st + 256 * p);
-                      pa[p] = *(const double2_t*)(nextA + (size_t)(e >> 6) * n + (e & 63));
+                      pa[p] = la_ld_sc1(ra, (unsigned)(((e >> 6) * n + (e & 63)) * sizeof(double)));
                     }
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
                       const int e = 2 * (st + 256 * p);
-                      ps[p] = *(const double2_t*)(nextS + (size_t)(e >> 6) * n + (e & 63));
+                      ps[p] = la_ld_sc1(rs, (unsigned)(((e >> 6) * n + (e & 63)) * sizeof(double)));
                     }
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
@@ -313,6 +346,43 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
       LADBG(k, 4);
     }
     la_post(fInv + (nb - 1));                                      // (nobody waits for it; kept for symmetry of the flag set)
+    finish();
+    return;
+  }
+
+  if ((int)blockIdx.x > ntiles) {
+    // ------------------------------------------------------------------ a block (i, k) of L^-1, i > k
+    //   W_ik = -L_ii^-1 sum_{j = k .. i-1} L_ij W_jk ,  W_kk = L_kk^-1
+    // - what the GEMM-shaped solve (uce_trinv.hip) otherwise builds by recursive doubling in 2 log2(nb) launches AFTER
+    // the factorisation.  These workgroups come last in the grid (each waits only for lower-numbered ones: the L tiles,
+    // the walker, the W blocks above it in its column) and run beside the factorisation: block (i, k) is complete ~3 us
+    // after the walker hands out L_ii^-1, the whole inverse a few microseconds after the last factor.
+    int ti, tk;
+    la_tile_of_block((int)blockIdx.x - ntiles, nb, ti, tk);
+    double (*P)[LD] = (double (*)[LD])smem_raw;
+    double (*Q)[LD] = P + 64;
+    double4_t acc[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
+    for (int jj = tk; jj < ti; ++jj) {
+      la_wait<false>(fL + ti * nb + jj, j.status);
+      la_wait<false>(jj == tk ? fInv + tk : fW + jj * nb + tk, j.status);
+      la_load_tile_sc1(P, j.Lmat + (size_t)ti * 64 * n + (size_t)jj * 64, n, false);
+      if (jj == tk) la_load_tile_sc1(Q, j.Linv + (size_t)tk * 4096, 64, true);
+      else la_load_tile_sc1(Q, j.Wi + (size_t)jj * 64 * n + (size_t)tk * 64, n, true);
+      __syncthreads();
+      lw.prod(acc, P, Q, 1.0);
+      __syncthreads();
+    }
+    la_wait<false>(fInv + ti, j.status);
+    la_load_tile_sc1(P, j.Linv + (size_t)ti * 4096, 64, false);
+    lw.each([&](int m, int r, int row, int col) { Q[col][row] = acc[m][r]; });       // transposed: the right operand again
+    __syncthreads();
+    double4_t out[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
+    lw.prod(out, P, Q, -1.0, (lw.wr + 32) / 4);                   // L_ii^-1 is lower triangular: rows wr .. wr+31 contract over t < wr + 32
+    __syncthreads();
+    lw.each([&](int m, int r, int row, int col) { P[row][col] = out[m][r]; });
+    __syncthreads();
+    la_publish_tile(P, j.Wi + (size_t)ti * 64 * n + (size_t)tk * 64, n);
+    la_post(fW + ti * nb + tk);
     finish();
     return;
   }
@@ -333,10 +403,10 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     }
   }
   for (int jj = 0; jj < tk; ++jj) {
-    la_wait(fL + ti * nb + jj, j.status);
-    la_wait(fL + tk * nb + jj, j.status);
-    la_load_tile(P, j.Lmat + (size_t)ti * 64 * n + (size_t)jj * 64, n);
-    la_load_tile(Q, j.Lmat + (size_t)tk * 64 * n + (size_t)jj * 64, n);
+    la_wait<false>(fL + ti * nb + jj, j.status);
+    la_wait<false>(fL + tk * nb + jj, j.status);
+    la_load_tile_sc1(P, j.Lmat + (size_t)ti * 64 * n + (size_t)jj * 64, n, false);
+    la_load_tile_sc1(Q, j.Lmat + (size_t)tk * 64 * n + (size_t)jj * 64, n, false);
     __syncthreads();
     lw.prod(acc, P, Q, -1.0);
     if (sub) lw.prod(dacc, P, P, -1.0);
@@ -356,8 +426,8 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     finish();
     return;
   }
-  la_wait(fInv + tk, j.status);
-  la_load_tile(Q, j.Linv + (size_t)tk * 4096, 64);
+  la_wait<false>(fInv + tk, j.status);
+  la_load_tile_sc1(Q, j.Linv + (size_t)tk * 4096, 64, false);
   lw.each([&](int m, int r, int row, int col) { P[row][col] = acc[m][r]; });
   __syncthreads();
   double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
@@ -551,11 +621,17 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
       UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_potrf_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LA_SMEM));
       la_once.commit(tok);
     }
-    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags};
-    hipLaunchKernelGGL(k_potrf_la, dim3(1 + nb * (nb - 1) / 2), dim3(512), POTRF_LA_SMEM, st, job);
+    // variant 1 (default): the launch also forms the off-diagonal blocks of L^-1 (h->Wi) for the GEMM-shaped solve that
+    // follows (uce_trinv.hip skips its merge launches); variant 2: factor only
+    const bool with_inverse = h->sw.potrf_variant == 1 && h->Wi != nullptr;
+    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags, with_inverse ? h->Wi : nullptr};
+    const int tiles = nb * (nb - 1) / 2;
+    hipLaunchKernelGGL(k_potrf_la, dim3(1 + tiles * (with_inverse ? 2 : 1)), dim3(512), POTRF_LA_SMEM, st, job);
     UCE_LAUNCH_CHECK();
+    h->wi_valid = with_inverse;
     return UCE_OK;
   }
+  h->wi_valid = false;
   const size_t smem = 3 * 64 * LD * sizeof(double);
   const size_t smem_first = sizeof(Potrf64Scratch);
   static_assert(sizeof(Potrf64Scratch) <= POTRF_STEP_SMEM, "scratch must fit the three tile regions");

@@ -227,7 +227,8 @@ int launch_trisolve_inv(uce_ctx* h, int n, int m, const double* rhs64, const flo
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_trinv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_once.commit(tok);
   }
-  for (int S = 1; S < nb; S *= 2) {
+  // (k_potrf_la has already formed the off-diagonal blocks of L^-1 beside the factorisation: no merge launches)
+  for (int S = 1; S < nb && !h->wi_valid; S *= 2) {
     // D rows of the level: every block i with (i / S) odd
     int drows = 0;
     for (int i = 0; i < nb; ++i)
