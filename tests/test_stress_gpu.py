@@ -129,3 +129,37 @@ def test_random_convolution_shapes_repeat_bit_identically():
             err = float((y.float() - ref).norm() / ref.norm())
             assert err < (6e-3 if dtype == torch.bfloat16 else 1e-3), (it, N, Cin, Cout, Hh, Ww, up, dtype, err)
             assert torch.equal(y, outs[0]), (it, "not bit-repeatable")
+
+
+@pytest.mark.parametrize("d", [768, 1024])
+def test_two_persistent_factorisations_side_by_side(d):
+    """The primal path's persistent Cholesky (1 walker + tile + L^-1 workgroups with flag hand-offs, 133 / 241 workgroups per
+    launch) issued from two handles on two streams without synchronisation in between: both launches must make progress side by
+    side on the 256 CUs (each handle owns its flags), every result against fp64."""
+    rng = np.random.Generator(np.random.PCG64(d))
+    rows, N, n_e = 2048, d + 40, 300                                   # N >= d: primal
+    H1, H2 = E.UceHandle.get("cuda:0"), E.UceHandle("cuda:0")
+    side = torch.cuda.Stream()
+    W = _dev(O.linear_default_weight(rows, d, rng))
+    W64 = W.double()
+    jobs, outs = [], []
+    try:
+        for it in range(6):
+            Call = O.clip_like_embeddings(N + 1, d, seed=int(rng.integers(1 << 30)))
+            C, G = _dev(Call[:N]), _dev(np.repeat(Call[N:N + 1], n_e, axis=0))
+            s = _dev((0.5 + rng.random(N)).astype(np.float32))
+            jobs.append((C, G, s))
+            if it % 2 == 0:
+                outs.append(H1.edit(C, G, s, 0.5, W))
+            else:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    outs.append(H2.edit(C, G, s, 0.5, W))
+        torch.cuda.synchronize()
+        H1.status()
+        H2.status()
+        for (C, G, s), out in zip(jobs, outs):
+            want = _exact(C, G, s, W64, n_e, d)
+            assert float((out.double() - want).norm() / want.norm()) < 1e-5
+    finally:
+        H2.close()

@@ -66,7 +66,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
 //   UCE_SATTN_QT        0: self-attention kernel by measured rule | 1: k_sattn, one query tile per wave | 2: two query tiles
 //                       wherever dh <= 48 | 3: the software-pipelined k_sattn_p wherever it exists
-//   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..22 diagonal blocks that also forms L^-1 |
+//   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt;

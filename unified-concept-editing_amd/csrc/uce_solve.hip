@@ -609,7 +609,11 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
 
 }  // namespace
 
-constexpr int POTRF_LA_MAX_NB = 22;        // 1 + nb (nb - 1) / 2 workgroups <= 232: all tiles resident on a 256-CU chip
+// The walker is the one workgroup that waits for higher-numbered ones (the tiles next to the diagonal), so it needs the
+// 1 + nb (nb - 1) / 2 factor workgroups of ITS launch resident; capped so that two launches from two handles / streams fit the
+// 256 CUs side by side (2 x 121 at nb = 16: d <= 1024; larger systems take the launch chain).  The W workgroups behind them wait
+// only for lower-numbered ones and may start late.
+constexpr int POTRF_LA_MAX_NB = 16;
 
 int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid) {
   if (n_valid <= 0 || n_valid > n) n_valid = n;
