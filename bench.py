@@ -342,10 +342,15 @@ def roofline_block(r):
     return top
 
 
+def r_small(name: str) -> bool:
+    return WORKLOADS[name][2] == 768 and WORKLOADS[name][0] + WORKLOADS[name][1] <= 128
+
+
 def config_leg(H, name: str, device, algo: int):
     n_e, n_p, d, _, idx = WORKLOADS[name]
-    steps = 20 if name != "sd14_erase2p3" else 50
-    r = run_edit(H, name, device, steps, 3, algo)
+    # enough steps that the timed region is tens of milliseconds (20 steps of a 0.1 ms edit measured 10-15 % slow: the first
+    # launches after a workload switch run on cold caches and a ramping clock)
+    r = run_edit(H, name, device, 200 if r_small(name) else 100, 20, algo)
     k0 = r["kernels"][0]
     out = dict(baseline_config=idx, workload=name, concepts=n_e + n_p, d=d, rows=r["inp"]["rows"],
                ms_per_step=round(r["ms_per_step"], 5), ms_per_step_events=round(r["ms_per_step_events"], 5),
