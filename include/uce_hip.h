@@ -42,7 +42,8 @@ enum {
   UCE_EINVAL = -22,   /* bad argument (null pointer, d not a multiple of 64, N <= 0, ...) */
   UCE_ENOMEM = -12,   /* workspace allocation failed */
   UCE_EDOM = -33,     /* system not positive definite (lambda <= 0 with rank-deficient C, s_i < 0) */
-  UCE_ENOSYS = -38,   /* feature not built */
+  UCE_ENOSYS = -38,   /* feature not built / not available in this process */
+  UCE_ECOMM = -70,    /* the collective library reported an error (uce_bcast) */
   UCE_EHIP = -1000    /* -1000 - hipError_t */
 };
 
@@ -213,9 +214,14 @@ int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, 
 int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const void* bias, void* y, int N, int H, int W,
                          int Cin, int Cout, int upsample, int dtype, uce_stream_t stream);
 
-/* e - the one exchange step of the multi-GPU generation path (broadcast of the edited weights from rank 0) is issued by
- * the host through torch.distributed (backend "nccl" = RCCL over xGMI): see uce_amd/generate.py.  The library holds
- * no communicator and exports no collective. */
+/* e - the one exchange step of the multi-GPU generation path (broadcast of the edited weights from rank 0 over RCCL / xGMI;
+ * generate-images-sd.py:17-19 loads the artifact on every process - here rank 0 loads it and the others receive it).
+ *   buf [bytes] on the device, in place on every rank; `comm` is the caller's ncclComm_t (RCCL), passed as void*.
+ * The Python host issues this step through torch.distributed (backend "nccl" = RCCL, uce_amd/generate.py); this entry point gives
+ * a host WITHOUT torch the same collective.  The library does not link RCCL: ncclBroadcast is resolved at the first call from the
+ * library named by UCE_RCCL_LIB, else from the RCCL already visible in the process, else from librccl.so (UCE_ENOSYS when none is
+ * there) - `comm` must come from that same RCCL. */
+int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,31 @@ def main(path: str) -> None:
         dist.all_reduce(t)                                        # the counters' reduction of generate_images
         torch.cuda.synchronize()
         assert bool((t == 1).all())
-        print("RCCL_BCAST_OK", dist.get_backend(), len(want))
+        # the same collective through the C ABI (uce_bcast: what a host without torch calls): a single-rank communicator
+        # created with torch's own RCCL, made globally visible so that the library resolves ncclBroadcast from that copy
+        import ctypes
+        from uce_amd import lib as L, edit as E
+        rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_char * 128)]
+
+        uid, comm = UniqueId(), ctypes.c_void_p()
+        rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+        H = E.UceHandle.get(dev)
+        blob = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+        keep = blob.clone()
+        rc = H.lib.uce_bcast(H._h, blob.data_ptr(), blob.numel() * 4, 0, comm, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0, L.load().uce_strerror(rc)
+        assert torch.equal(blob, keep)
+        assert H.lib.uce_bcast(H._h, blob.data_ptr(), 16, 0, None, None) == L.EINVAL       # no communicator
+        rccl.ncclCommDestroy(comm)
+        print("RCCL_BCAST_OK", dist.get_backend(), len(want), "uce_bcast ok")
     finally:
         dist.destroy_process_group()
 

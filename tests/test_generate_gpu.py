@@ -75,7 +75,7 @@ def test_rccl_broadcast_of_the_edited_weights_single_rank(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tests", "rccl_bcast_worker.py"), path], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "RCCL_BCAST_OK nccl 3" in r.stdout
+    assert "RCCL_BCAST_OK nccl 3 uce_bcast ok" in r.stdout
 
 
 def test_real_coco30k_rows_at_sd14_size(tmp_path):

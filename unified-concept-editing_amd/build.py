@@ -102,7 +102,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     stale_objs = set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - set(objs)
     for o in stale_objs:                      # a removed source must not stay linked in
         os.remove(o)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print("[uce_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

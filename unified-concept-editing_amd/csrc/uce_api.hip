@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -133,7 +134,7 @@ static int env_int(const char* name, int dflt) {
 
 extern "C" {
 
-int uce_version(void) { return 110; }
+int uce_version(void) { return 111; }
 
 const char* uce_strerror(int code) {
   switch (code) {
@@ -142,6 +143,7 @@ const char* uce_strerror(int code) {
     case UCE_ENOMEM: return "workspace allocation failed";
     case UCE_EDOM: return "system is not positive definite (check lambda > 0 and scales > 0)";
     case UCE_ENOSYS: return "not available in this build";
+    case UCE_ECOMM: return "collective (RCCL) call failed";
     default:
       if (code <= UCE_EHIP) return hipGetErrorString((hipError_t)(UCE_EHIP - code));
       return "unknown error";
@@ -445,6 +447,36 @@ int uce_profile_end(uce_handle_t h, uce_stream_t stream, char* report, size_t ca
     off += (size_t)w;
   }
   return UCE_OK;
+}
+
+// ncclBroadcast(const void* send, void* recv, size_t count, ncclDataType_t (ncclUint8 = 1), int root, ncclComm_t, hipStream_t)
+typedef int (*nccl_broadcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+
+static nccl_broadcast_fn resolve_nccl_broadcast() {
+  static nccl_broadcast_fn fn = []() -> nccl_broadcast_fn {
+    void* sym = nullptr;
+    if (const char* path = getenv("UCE_RCCL_LIB")) {               // an explicit library (the one `comm` was created with)
+      if (void* lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(lib, "ncclBroadcast");
+    }
+    if (!sym) sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");          // the RCCL the host process already carries
+    if (!sym) {
+      void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) sym = dlsym(lib, "ncclBroadcast");
+    }
+    return (nccl_broadcast_fn)sym;
+  }();
+  return fn;
+}
+
+int uce_bcast(uce_handle_t h, void* buf, size_t bytes, int root, void* comm, uce_stream_t stream) {
+  if (!h || !buf || !comm || root < 0) return UCE_EINVAL;
+  UCE_ENTER(h);
+  if (bytes == 0) return UCE_OK;
+  const nccl_broadcast_fn bc = resolve_nccl_broadcast();
+  if (!bc) return UCE_ENOSYS;
+  const int rc = bc(buf, buf, bytes, /* ncclUint8 */ 1, root, comm, (hipStream_t)stream);
+  return rc == 0 ? UCE_OK : UCE_ECOMM;
 }
 
 int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {

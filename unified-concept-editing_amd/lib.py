@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-OK, EINVAL, ENOMEM, EDOM, ENOSYS = 0, -22, -12, -33, -38
+OK, EINVAL, ENOMEM, EDOM, ENOSYS, ECOMM = 0, -22, -12, -33, -38, -70
 ALGO_AUTO, ALGO_PRIMAL, ALGO_DUAL = 0, 1, 2
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     "uce_delta_from_factors": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "uce_edit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _l, _i, _vp]),
     "uce_status": (_i, [_vp, C.POINTER(_i), _vp]),
+    "uce_bcast": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
     "uce_profile_begin": (_i, [_vp]),
     "uce_profile_end": (_i, [_vp, _vp, C.c_char_p, _sz]),
     "uce_debias_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
