@@ -307,7 +307,8 @@ def test_edit_edge_cases(H):
 
 
 @pytest.mark.parametrize("Ne,d,rows_", [(50, 768, 24960), (33, 768, 1500), (64, 1024, 2000), (100, 768, 3000),
-                                        (36, 2048, 1300), (200, 768, 1111)])
+                                        (36, 2048, 1300), (200, 768, 1111),
+                                        (160, 768, 1500), (130, 1024, 1100), (70, 2048, 1200)])   # half-filled last 128-concept batch
 def test_lowrank_project_and_update(H, Ne, d, rows_):
     """The two-kernel low-rank apply (projection, then update: what uce_edit launches) against fp64."""
     rng = np.random.Generator(np.random.PCG64(Ne + d))
@@ -330,7 +331,8 @@ def test_lowrank_project_and_update(H, Ne, d, rows_):
 
 @pytest.mark.parametrize("N_e,N_p,d,rows_", [(40, 10, 1024, 4096), (36, 4, 2048, 2600), (120, 30, 768, 5000),
                                              (65, 0, 768, 1024), (100, 0, 768, 24960), (100, 28, 768, 2048),
-                                             (60, 30, 1024, 2048), (70, 50, 2048, 1300), (128, 64, 768, 1500)])
+                                             (60, 30, 1024, 2048), (70, 50, 2048, 1300), (128, 64, 768, 1500),
+                                             (150, 20, 768, 1500), (180, 100, 1024, 1100)])
 def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
     """uce_edit's project / solve / update path (rows >= 1024) vs torch fp64 on the GPU, run twice back to back
     (the handle's workspace and the riders' ticket word are re-used): N <= 64 and 64 < N <= 128 take the
