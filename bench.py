@@ -292,7 +292,7 @@ def time_steps(step, steps: int, world: int, device):
     elapsed = time.perf_counter() - t0
     ev = e0.elapsed_time(e1) * 1e-3
     if world > 1:
-        t = torch.tensor([elapsed, ev], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, ev], dtype=torch.float64, device=_scalar_device(device))
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed, ev = float(t[0].item()), float(t[1].item())
     return elapsed, ev
@@ -377,6 +377,12 @@ def _sync(device) -> None:
         torch.cuda.synchronize()
 
 
+def _scalar_device(device):
+    """Where the few timing scalars of the collectives live: the device under RCCL, the host under gloo."""
+    import torch.distributed as dist
+    return torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_id="CompVis/stable-diffusion-v1-4",
                    dtype=torch.bfloat16, vae=True):
     """Secondary figure (BASELINE.json's second metric): images/s of the edited SD-1.4 pipeline,
@@ -457,12 +463,12 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
     el = time.perf_counter() - t0
     per_rank = [mine_s]
     if world > 1:
-        t = torch.tensor([el, 0.0 if failure is None else 1.0], dtype=torch.float64, device=device)
+        t = torch.tensor([el, 0.0 if failure is None else 1.0], dtype=torch.float64, device=_scalar_device(device))
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t[0].item())
         if failure is None and t[1].item() > 0:
             failure = "another rank failed"
-        mine_t = torch.tensor([mine_s], dtype=torch.float64, device=device)
+        mine_t = torch.tensor([mine_s], dtype=torch.float64, device=_scalar_device(device))
         gathered = [torch.zeros_like(mine_t) for _ in range(world)]
         torch.distributed.all_gather(gathered, mine_t)
         per_rank = [float(g.item()) for g in gathered]
@@ -624,11 +630,19 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # dry run of the N > 1 line on a box with fewer GPUs than ranks (tools / tests only): UCE_BENCH_SAME_DEVICE=1 puts every rank
+    # on cuda:0 and UCE_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("UCE_BENCH_SAME_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("UCE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from uce_amd import edit as E
     from uce_amd import cli
