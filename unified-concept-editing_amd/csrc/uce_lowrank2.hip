@@ -210,7 +210,7 @@ __device__ __forceinline__ void project_body_w(const float* __restrict__ W_old, 
 // Hand-off words (h->ticket, all zero between launches - nothing of the protocol lives in the kernel arguments, so a
 // launch can be captured into a hipGraph and replayed):
 //   [0] arrival counter of the Gram riders       (reset by the block that draws the last ticket)
-//   [1] stage word of the factorising block:  1 = L_00^-1 is in memory (two-block systems), 2 = every factor block is
+//   [1] stage word of the factorising block:  1 = L_00^-1 is in memory, 2 = L_10 too (two-block systems), 3 = every factor block is
 //   [2] completion counter of the solve riders   (the last one to finish resets [1] and [2])
 struct GramPotrfJob {
   const float* C;       // [N, d]; null = no riders
@@ -400,7 +400,7 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
   DBG(9);
   double2_t mv[4];
   if (j.nb == 1) {
-    wait_stage(j, 2);
+    wait_stage(j, 3);
     DBG(10);
     fetch_m(j.Linv, 64, mv);
     park_m(M0, mv);
@@ -424,17 +424,15 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
   sv_prod<false, true>(V2, M0, V0, nullptr, 1.0);         // Y0 -> V2
   DBG(10);
   wait_stage(j, 2);                                       // (its barrier also closes the product above)
-  {
-    double2_t mw[4];
-    fetch_m(j.Lmat + (size_t)64 * n, n, mv);              // block (1, 0) of L
-    fetch_m(j.Linv + 4096, 64, mw);
-    park_m(M1, mv);
-    park_m(M2, mw);
-  }
+  fetch_m(j.Lmat + (size_t)64 * n, n, mv);                // block (1, 0) of L: in memory while block 1 is still being eliminated
+  park_m(M1, mv);
+  __syncthreads();
+  sv_prod<false, false>(V1, M1, V2, V1, -1.0);            // C1 - L10 Y0 -> V1
+  wait_stage(j, 3);                                       // (barrier)
+  fetch_m(j.Linv + 4096, 64, mv);
+  park_m(M2, mv);
   __syncthreads();
   DBG(11);
-  sv_prod<false, false>(V1, M1, V2, V1, -1.0);            // C1 - L10 Y0 -> V1
-  __syncthreads();
   sv_prod<false, true>(V0, M2, V1, nullptr, 1.0);         // Y1 -> V0 (C0 is dead)
   __syncthreads();
   sv_prod<true, true>(V1, M2, V0, nullptr, 1.0);          // X1 -> V1
@@ -629,7 +627,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
                 [&](int row, int col, const double (&v)[4]) { store_linv(0, row, col, v); },
                 sc, tid, j.status, 0, j.N);
     DBG(4);
-    publish_stage(j, 2);
+    publish_stage(j, 3);
     DBG(5);
     return;
   }
@@ -670,36 +668,47 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     reduce_tile(vb, n4b, 64, false, o);
     park_tile(&Mi[0][0], o);
   }
-  publish_stage(j, 1);                                            // (its barrier: L_00^-1 is in LDS, the scratch is dead)
+  // Stages 1 and 2 are posted one phase late, behind a barrier every wave reaches with `s_waitcnt vmcnt(0)` long after the
+  // stores they cover were issued: nothing is drained on this block's critical path (the solve riders have the whole second
+  // elimination to use L_00^-1 and L_10).
+  auto post_stage = [&](unsigned stage) {
+    if (tid == 0) __hip_atomic_store(j.ticket + 1, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  __syncthreads();                                                // L_00^-1 is in LDS, the scratch is dead
   DBG(4);
   {
-    // both 64 x 64 x 64 products on all 8 waves: wave (wq, half) owns rows wr .. wr+31 x columns wc + 16 half .. +15
+    // L_10 = K_10 L_00^-T on all 8 waves, contraction only over the non-zero part of the triangular operand: the two waves
+    // of a SIMD (w, w + 4) take column blocks (0, 3) or (1, 2) - 20 of the 32 k-steps a full contraction would issue
+    const int twr = (w & 2) ? 32 : 0, twc = 16 * ((w & 1) ? (half ? 2 : 1) : (half ? 3 : 0));
+    // the Schur complement S = K_11 - L_10 L_10^T: wave (wq, half) owns rows wr .. wr+31 x columns wc + 16 half .. +15
     const int wc8 = wc + 16 * half;
-    auto prod = [&](double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign) {
+    auto prod = [&](double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign, int r0, int c0, int kb_end) {
       const int r = lane & 15, kk = lane >> 4;
 #pragma unroll 4
-      for (int kb = 0; kb < 16; ++kb) {
+      for (int kb = 0; kb < kb_end; ++kb) {
         const int t = kb * 4 + kk;
-        const double b0 = Q[wc8 + r][t];
-        a2[0] = mfma_f64(sign * P[wr + r][t], b0, a2[0]);
-        a2[1] = mfma_f64(sign * P[wr + 16 + r][t], b0, a2[1]);
+        const double b0 = Q[c0 + r][t];
+        a2[0] = mfma_f64(sign * P[r0 + r][t], b0, a2[0]);
+        a2[1] = mfma_f64(sign * P[r0 + 16 + r][t], b0, a2[1]);
       }
     };
     // D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4r, col = lane&15
-    const int oc = wc8 + (lane & 15), orq = lane >> 4;
+    const int orq = lane >> 4;
     double4_t pp[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
-    prod(pp, Mi, Li, 1.0);                                        // L_10 = K_10 L_00^-T
+    prod(pp, Mi, Li, 1.0, twr, twc, (twc + 16) / 4);
     double (*S)[LD] = (double (*)[LD])smem_raw;                   // K_11 -> the (dead) scratch region
     {
       double2_t k11[4];
       reduce_tile(vc, n4b, 64, true, k11);
       park_tile(&S[0][0], k11);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the stores of L_00^-1 (issued before the product above)
     __syncthreads();
+    post_stage(1);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Mi[wr + m * 16 + orq + 4 * r][oc] = pp[m][r];
+      for (int r = 0; r < 4; ++r) Mi[twr + m * 16 + orq + 4 * r][twc + (lane & 15)] = pp[m][r];
     __syncthreads();
     {
       const __amdgpu_buffer_rsrc_t l10_r = sc1_rsrc(j.Lmat + (size_t)64 * n, (unsigned)(64 * n * sizeof(double)));
@@ -709,12 +718,13 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
         st_sc1_x2(l10_r, (unsigned)(((e >> 6) * n + (e & 63)) * sizeof(double)), *(const double2_t*)&Mi[e >> 6][e & 63]);
       }
     }
+    const int oc = wc8 + (lane & 15);
     double4_t sacc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sacc[m][r] = S[wr + m * 16 + orq + 4 * r][oc];
-    prod(sacc, Mi, Mi, -1.0);                                     // S = K_11 - L_10 L_10^T
+    prod(sacc, Mi, Mi, -1.0, wr, wc8, 16);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -722,12 +732,13 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     __syncthreads();
   }
   UCE_POTRF64([&](int row, int col, double (&v)[4]) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drains the publish of L_10 before the elimination's first barrier
                 const pk_d2 a = *(const pk_d2*)&Li[row][col], b = *(const pk_d2*)&Li[row][col + 2];
                 v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
               },
               [&](int row, int col, const double (&v)[4]) { store_linv(1, row, col, v); },
-              sc, tid, j.status, 64, n2);
-  publish_stage(j, 2);
+              sc, tid, j.status, 64, n2, [&]() { post_stage(2); });
+  publish_stage(j, 3);
   DBG(5);
 }
 
