@@ -5,8 +5,8 @@
 //                         (blocked) Cholesky + block inverses of the dual system (N <= 64 / N <= 128), so the
 //                         latency-bound factorisation hides under the f32-MFMA-bound projection without any
 //                         cross-stream event (a HIP event hand-off between two streams measured 13-14 us each way).
-//   k_lr_update_s<D,..> : W_new = W_old + T R_e           one pass over the weights (N_edit <= 128; k_lr_update is the
-//                         ring-buffered form for 129..256): algorithmic bytes 8*rows*d (+ the small T and R).
+//   k_lr_update_s<D,..> : W_new = W_old + T R_e           one pass over the weights per 128 edit concepts (129..256: a second
+//                         pass in place): algorithmic bytes 8*rows*d (+ the small T and R).
 //
 // Splitting the update at T costs 2*4*rows*NEP bytes of extra traffic (6.4 MB at N_edit <= 64 for SD-1.4, 4 %) and
 // buys (a) overlap of the projection with the latency-bound small-system chain, (b) an update kernel whose LDS
@@ -779,104 +779,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// update: 4 waves, 64 rows per workgroup; wave w owns 64-column groups w, w+4, ...; lane j of a group
-// owns 4 consecutive columns, so W, R and the output all move 16 B per lane in full 256 B row
-// segments.  T tile [64, NEP] -> LDS once.  Per k-step one R fragment (L2) feeds 16 MFMAs.
-// ---------------------------------------------------------------------------------------------
-template <int D, int UP_MT, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_update(
-    const float* __restrict__ W_old, const float* __restrict__ T, const float* __restrict__ R,
-    float* __restrict__ W_new, long rows, int Ne, int NEP) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int d = D;
-  constexpr int SR = UP_MT * 16;
-  const int tld = NEP + 2;
-  float* Ts = (float*)smem_raw;                       // [64][tld]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const long R0 = (long)blockIdx.x * SR;
-
-  constexpr int MG = D / 256;                         // column groups per wave (3 / 4 / 8)
-  constexpr int RD = 4;                               // R fragments in flight
-  const int nks = (Ne + 3) >> 2;                      // k-steps that carry concepts
-  int rl_g = 0, rl_t = 0;
-  auto r_next = [&]() -> float4_t {
-    const int e = 4 * rl_t + lk;
-    const float4_t v = *(const float4_t*)(R + (size_t)(e < Ne ? e : Ne - 1) * d + (w + 4 * rl_g) * 64 + 4 * li);
-    if (++rl_t == nks) { rl_t = 0; rl_g = rl_g + 1 < MG ? rl_g + 1 : rl_g; }
-    return v;
-  };
-  auto res_load = [&](int gi, float4_t (&x)[UP_MT][4]) {
-#pragma unroll
-    for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        long gr = R0 + m * 16 + 4 * lk + r;
-        gr = gr < rows ? gr : rows - 1;
-        x[m][r] = *(const float4_t*)(W_old + gr * d + (w + 4 * gi) * 64 + 4 * li);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // first loads in flight before T is staged
-  float4_t res[UP_MT][4];
-  res_load(0, res);
-  float4_t ring[RD];
-#pragma unroll
-  for (int i = 0; i < RD; ++i) ring[i] = r_next();
-  {
-    const int f4_row = NEP >> 2;
-    for (int e = tid; e < SR * f4_row; e += 256) {
-      const int r = e / f4_row, c = (e - r * f4_row) << 2;
-      long gr = R0 + r;
-      gr = gr < rows ? gr : rows - 1;
-      const float4_t v = *(const float4_t*)(T + gr * NEP + c);
-      Ts[r * tld + c] = v[0];
-      Ts[r * tld + c + 1] = v[1];
-      Ts[r * tld + c + 2] = v[2];
-      Ts[r * tld + c + 3] = v[3];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int gi = 0; gi < MG; ++gi) {
-    float4_t acc[UP_MT][4];                           // acc[m][q][r]: row m*16 + 4*lk + r, column 4*li + q
-#pragma unroll
-    for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[m][q][r] = res[m][r][q];
-    if (gi + 1 < MG) res_load(gi + 1, res);           // next group's W rows, ahead of this group's stores
-#pragma unroll 1
-    for (int t = 0; t < nks; ++t) {
-      const float4_t b = ring[0];
-#pragma unroll
-      for (int i = 0; i + 1 < RD; ++i) ring[i] = ring[i + 1];
-      ring[RD - 1] = r_next();
-      const int e = 4 * t + lk;
-      float a[UP_MT];
-#pragma unroll
-      for (int m = 0; m < UP_MT; ++m) a[m] = (e < Ne) ? Ts[(m * 16 + li) * tld + e] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int m = 0; m < UP_MT; ++m)
-          acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[q], acc[m][q], 0, 0, 0);
-    }
-#pragma unroll
-    for (int m = 0; m < UP_MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long gr = R0 + m * 16 + 4 * lk + r;
-        if (gr < rows) {
-          const float4_t o = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-          __builtin_nontemporal_store(o, (float4_t*)(W_new + gr * d + (w + 4 * gi) * 64 + 4 * li));
-        }
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // update, single-buffered R, buffer addressing.
 //  * The register holding k-step t's R fragment is reloaded IN PLACE with the next column group's
 //    fragment right after the MFMAs of step t have consumed it.  Program order of the vector-memory
@@ -897,8 +799,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 
 template <int D, int UP_MT, int WPE, int NK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lr_update_s(
-    const float* __restrict__ W_old, const float* __restrict__ T, const float* __restrict__ R,
-    float* __restrict__ W_new, long rows, int Ne, int NEP) {
+    const float* W_old, const float* __restrict__ T, const float* __restrict__ R,
+    float* W_new, long rows, int Ne, int NEP, int t_stride) {
+  // (W_old may be W_new: the second pass of a 129..256-concept update adds onto the first pass's output in place - a
+  //  workgroup reads only the 16 rows it writes, and every element is read before it is written)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int d = D;
   constexpr int SR = UP_MT * 16;
@@ -943,7 +847,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       const int r = e / f4_row, c = (e - r * f4_row) << 2;
       long gr = R0 + r;
       gr = gr < rows ? gr : rows - 1;
-      const float4_t v = *(const float4_t*)(T + gr * NEP + c);
+      const float4_t v = *(const float4_t*)(T + gr * t_stride + c);
       Ts[r * tld + c] = c < Ne ? v[0] : 0.f;          // pad columns -> 0: the k loop reads unconditionally
       Ts[r * tld + c + 1] = c + 1 < Ne ? v[1] : 0.f;
       Ts[r * tld + c + 2] = c + 2 < Ne ? v[2] : 0.f;
@@ -1044,39 +948,23 @@ int launch_project_d(const float* W_old, const float* Dm, const float* Csub, flo
   }
 }
 
+// one pass W_new = W_in + T[:, 0 .. NEPw) R[0 .. N_w): T has row stride t_stride floats, N_w <= 128 concepts
 template <int D, int UP_MT, int WPE>
-int launch_update_v(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
-                    int NEP64, hipStream_t st) {
-  const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
-  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_update<D, UP_MT, WPE>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_once.commit(tok);
-  }
-  const long nwg = (rows + UP_MT * 16 - 1) / (UP_MT * 16);
-  hipLaunchKernelGGL((k_lr_update<D, UP_MT, WPE>), dim3((unsigned)nwg), dim3(256), smem, st, W_old, T, R, W_new, rows,
-                     N_edit, NEP64);
-  UCE_LAUNCH_CHECK();
-  return UCE_OK;
-}
-
-template <int D, int UP_MT, int WPE>
-int launch_update_s(const float* W_old, const float* T, const float* R, float* W_new, long rows, int N_edit,
-                    int NEP64, hipStream_t st) {
-  const size_t smem = (size_t)UP_MT * 16 * (NEP64 + 2) * sizeof(float);
+int launch_update_s(const float* W_in, const float* T, const float* R, float* W_new, long rows, int N_w,
+                    int NEPw, int t_stride, hipStream_t st) {
+  const size_t smem = (size_t)UP_MT * 16 * (NEPw + 2) * sizeof(float);
   const dim3 grid((unsigned)((rows + UP_MT * 16 - 1) / (UP_MT * 16))), block(256);
-  const int nks = (N_edit + 3) / 4;
+  const int nks = (N_w + 3) / 4;
   if (nks <= 8)
-    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 8>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 8>), grid, block, smem, st, W_in, T, R, W_new, rows, N_w, NEPw, t_stride);
   else if (nks <= 13)
-    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 13>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 13>), grid, block, smem, st, W_in, T, R, W_new, rows, N_w, NEPw, t_stride);
   else if (nks <= 16)
-    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 16>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 16>), grid, block, smem, st, W_in, T, R, W_new, rows, N_w, NEPw, t_stride);
   else if (nks <= 25)
-    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 25>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 25>), grid, block, smem, st, W_in, T, R, W_new, rows, N_w, NEPw, t_stride);
   else if (nks <= 32)
-    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 32>), grid, block, smem, st, W_old, T, R, W_new, rows, N_edit, NEP64);
+    hipLaunchKernelGGL((k_lr_update_s<D, UP_MT, WPE, 32>), grid, block, smem, st, W_in, T, R, W_new, rows, N_w, NEPw, t_stride);
   else
     return UCE_EINVAL;
   UCE_LAUNCH_CHECK();
@@ -1090,8 +978,14 @@ int launch_update_d(const float* W_old, const float* T, const float* R, float* W
   // (3 / 4 waves per SIMD measured in round 3: SDXL slab 564 -> 610 / 537 us, 100 concepts 45 -> 45 / 78 us (spills): kept at 2)
   // (measured in round 3 on the SDXL slab and without effect beyond the 520-570 us run-to-run spread: 32-row tiles; weight
   // rows of two column groups in flight instead of one)
-  if (N_edit <= 128) return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);
-  return launch_update_v<D, 4, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, st);   // 129 <= N_edit <= 256: ring-buffered form
+  if (N_edit <= 128) return launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, N_edit, NEP64, NEP64, st);
+  // 129 .. 256 concepts: two passes of the register-resident kernel over 128-concept windows of T and R, the second one in
+  // place on the first one's output (round 2's ring-buffered single-pass kernel for this range - R fragments through a
+  // 4-deep register ring, in-order vmcnt stalls, spills at d = 2048 - measured 143 us against 117 at 256 concepts on the
+  // SD-1.4 slab and 2093 against 1789 on the SDXL slab; it was 3-8 % ahead only just above 128 concepts)
+  const int rc = launch_update_s<D, 1, 2>(W_old, T, R, W_new, rows, 128, 128, NEP64, st);
+  if (rc) return rc;
+  return launch_update_s<D, 1, 2>(W_new, T + 128, R + (size_t)128 * D, W_new, rows, N_edit - 128, NEP64 - 128, NEP64, st);
 }
 
 }  // namespace
