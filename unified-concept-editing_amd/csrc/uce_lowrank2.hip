@@ -242,9 +242,6 @@ __host__ __device__ constexpr int gp_riders(int nb) { return GP_NB * nb * (nb + 
 __device__ __forceinline__ void st_sc1(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double ld_sc1(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // The same accesses 16 bytes wide (buffer_load/store_dwordx4 ... sc1; cache-policy bit 4 = sc1 on gfx950).  A CU
 // sustains only ~10 KB/us of 8-byte L1-bypassing loads (70 KB of slabs: 6.5 us of the chain): the wide form halves the
 // requests per byte.  Out-of-range offsets read as zero without touching memory - that is the mask.

@@ -93,8 +93,8 @@ struct PotrfLaJob {
   double* Wi;         // [n, n]: off-diagonal blocks of L^-1 (null: not wanted)
 };
 
-// `acquire` = false: the caller reads the payload with L1-bypassing (sc1) loads and needs no cache invalidate
-template <bool ACQUIRE = true>
+// One lane polls the flag (relaxed, agent scope), the workgroup passes a barrier; the payload is then read with L1-bypassing
+// (sc1) loads - no acquire fence (see the header comment).  Bounded: reports instead of hanging.
 __device__ __forceinline__ bool la_wait(const unsigned* flag, int* status) {
   bool ok = true;
   if (threadIdx.x == 0) {
@@ -109,7 +109,6 @@ __device__ __forceinline__ bool la_wait(const unsigned* flag, int* status) {
     }
   }
   __syncthreads();
-  if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return ok;
 }
 
@@ -363,8 +362,8 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     double (*Q)[LD] = P + 64;
     double4_t acc[2] = {(double4_t){0.0, 0.0, 0.0, 0.0}, (double4_t){0.0, 0.0, 0.0, 0.0}};
     for (int jj = tk; jj < ti; ++jj) {
-      la_wait<false>(fL + ti * nb + jj, j.status);
-      la_wait<false>(jj == tk ? fInv + tk : fW + jj * nb + tk, j.status);
+      la_wait(fL + ti * nb + jj, j.status);
+      la_wait(jj == tk ? fInv + tk : fW + jj * nb + tk, j.status);
       la_load_tile_sc1(P, j.Lmat + (size_t)ti * 64 * n + (size_t)jj * 64, n, false);
       if (jj == tk) la_load_tile_sc1(Q, j.Linv + (size_t)tk * 4096, 64, true);
       else la_load_tile_sc1(Q, j.Wi + (size_t)jj * 64 * n + (size_t)tk * 64, n, true);
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
       lw.prod(acc, P, Q, 1.0);
       __syncthreads();
     }
-    la_wait<false>(fInv + ti, j.status);
+    la_wait(fInv + ti, j.status);
     la_load_tile_sc1(P, j.Linv + (size_t)ti * 4096, 64, false);
     lw.each([&](int m, int r, int row, int col) { Q[col][row] = acc[m][r]; });       // transposed: the right operand again
     __syncthreads();
@@ -403,8 +402,8 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     }
   }
   for (int jj = 0; jj < tk; ++jj) {
-    la_wait<false>(fL + ti * nb + jj, j.status);
-    la_wait<false>(fL + tk * nb + jj, j.status);
+    la_wait(fL + ti * nb + jj, j.status);
+    la_wait(fL + tk * nb + jj, j.status);
     la_load_tile_sc1(P, j.Lmat + (size_t)ti * 64 * n + (size_t)jj * 64, n, false);
     la_load_tile_sc1(Q, j.Lmat + (size_t)tk * 64 * n + (size_t)jj * 64, n, false);
     __syncthreads();
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     finish();
     return;
   }
-  la_wait<false>(fInv + tk, j.status);
+  la_wait(fInv + tk, j.status);
   la_load_tile_sc1(Q, j.Linv + (size_t)tk * 4096, 64, false);
   lw.each([&](int m, int r, int row, int col) { P[row][col] = acc[m][r]; });
   __syncthreads();
