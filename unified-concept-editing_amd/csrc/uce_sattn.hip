@@ -324,6 +324,8 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 // matrix pipe at a third of its time in k_sattn: neither pipe saturated, the wave waiting on its own previous phase)
 // is broken across two tiles.  K is therefore staged one tile further ahead than V^T: separate double buffers.
 // ---------------------------------------------------------------------------------------------
+// (forced to three waves per SIMD at dh = 40 - 168 VGPRs, 22 spilled - it ran 2071 us against 1747 at two waves and 1580 for
+//  k_sattn with two query tiles per wave: measured in round 3, not adopted)
 template <int DHP, bool F16>
 __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
