@@ -201,6 +201,13 @@ def kernel_model(name: str, path: str, N: int, n_e: int, d: int, rows: int):
         return "mfma", 1.0 * N * N * d, F64_MFMA_PEAK_TF, "TFLOP/s", "f64 MFMA, lower tiles"
     if name == "k_apply_b3":
         return "mfma", 6.0 * 2.0 * rows * d * d, BF16_MFMA_PEAK_TF, "TFLOP/s", "bf16 MFMA, six partial products per fp32-equivalent product (2*rows*d^2 fp32-equivalent flop)"
+    if name == "k_apply_h2":
+        return "mfma", 3.0 * 2.0 * rows * d * d, BF16_MFMA_PEAK_TF, "TFLOP/s", ("f16 MFMA, three partial products per fp32-equivalent product "
+                                                                               "(2*rows*d^2 fp32-equivalent flop); direct-to-LDS operands")
+    if name == "k_split_h2":
+        return "hbm", 8.0 * rows * d, HBM_PEAK_GBS, "GB/s", "W_old f32 in, two f16 planes out (rides in the Cholesky launch when that is the persistent kernel)"
+    if name == "k_split_h2d":
+        return "hbm", 8.0 * d * d, HBM_PEAK_GBS, "GB/s", "(I + Delta)^T f32 in, two f16 planes out"
     if name == "k_apply":
         return "mfma", 2.0 * rows * d * d, F32_MFMA_PEAK_TF, "TFLOP/s", "f32 MFMA"
     if name == "k_split3":

@@ -98,7 +98,10 @@ int uce_ensure(uce_ctx* h, int d, int n) {
 }
 
 int uce_ensure_T(uce_ctx* h, long rows, int N_edit) {
-  const size_t need = (size_t)rows * (size_t)((N_edit + 63) / 64 * 64);
+  return uce_ensure_T_floats(h, (size_t)rows * (size_t)((N_edit + 63) / 64 * 64));
+}
+
+int uce_ensure_T_floats(uce_ctx* h, size_t need) {
   if (need <= h->T_elems) return UCE_OK;
   UCE_HIP_TRY(hipSetDevice(h->device));
   UCE_HIP_TRY(hipDeviceSynchronize());
@@ -163,7 +166,7 @@ int uce_create(uce_handle_t* out, int device) {
   {
     const int cap = lr_rider_cap();
     const int want = env_int("UCE_RIDER_MAX_N", cap);
-    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 1), env_int("UCE_TRISOLVE_VARIANT", 1),
+    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
                         want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
@@ -270,14 +273,19 @@ int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_
   if (!h || !W_old || !DeltaT || !W_new || rows < 0 || d <= 0 || d % 64 || W_old == W_new) return UCE_EINVAL;
   UCE_ENTER(h);
   if (rows == 0) return UCE_OK;
-  // default: bf16 matrix cores with a three-way split of both operands (fp32-equivalent products, 2.7x the
-  // f32-MFMA rate); UCE_APPLY_VARIANT=0 (read at uce_create) selects the exact-f32 MFMA kernel
+  // default: f16 matrix cores with a two-way split of both operands (fp32-equivalent products from three f16 MFMAs,
+  // uce_apply_h2.hip); UCE_APPLY_VARIANT (read at uce_create) = 1: the three-way bf16 split (six MFMAs per product),
+  // 0: the exact-f32 MFMA kernel
   if (h->sw.apply_variant == 0) {
     UceProfScope ps(h, "k_apply", (hipStream_t)stream);
     return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
   }
-  const int rc = uce_ensure(h, d, 64);
+  int rc = uce_ensure(h, d, 64);
   if (rc) return rc;
+  if (h->sw.apply_variant == 2) {
+    rc = launch_apply_h2(h, W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   return launch_apply_b3(W_old, DeltaT, h->DeltaP, W_new, rows, d, (hipStream_t)stream, h);
 }
 
@@ -354,7 +362,16 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     if (rc) return rc;
     rc = uce_gram(h, C, G, s, N, N_edit, d, lamb, h->M, h->Bt, stream);
     if (rc) return rc;
+    // the dense f16 apply needs W_old split into two f16 planes: a pass over W_old that depends on nothing else of the
+    // step - rider workgroups of the (latency-bound, 133-CU) persistent Cholesky launch do it when that launch is taken
+    h->h2_done_src = nullptr;
+    if (h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d)) {
+      h->h2_pending_src = W_old;
+      h->h2_pending_rows = rows;
+      h->h2_pending_d = d;
+    }
     rc = uce_solve_delta(h, h->M, h->Bt, d, h->DeltaT, stream);
+    h->h2_pending_src = nullptr;
     if (rc) return rc;
     return uce_apply(h, W_old, h->DeltaT, W_new, rows, d, stream);
   }

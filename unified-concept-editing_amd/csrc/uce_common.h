@@ -60,7 +60,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 // A/B switches for measurements (defaults = the measured best), read from the environment ONCE, when the handle is created:
 //   UCE_XATTN_VARIANT   1 (default): column-group kernel at generation-batch sizes | 0: always k_xattn | 2: the group kernel
 //                       at every size | 3: its 8-wave dh = 40 form
-//   UCE_APPLY_VARIANT   1: bf16 x 3 dense apply | 0: the f32-MFMA kernel
+//   UCE_APPLY_VARIANT   2: f16 x 2 dense apply, direct-to-LDS | 1: bf16 x 3 dense apply | 0: the f32-MFMA kernel
 //   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
 //   UCE_RIDER_MAX_N     largest dual system (64 or 128) factored by rider blocks of the projection launch; 0: never
 //   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
@@ -96,8 +96,18 @@ struct uce_ctx {
   unsigned* la_flags;   // hand-off flags of the persistent Cholesky (uce_solve.hip: k_potrf_la), zero between launches
   unsigned* ticket;  // hand-off words of the rider blocks (uce_lowrank2.hip), all zero between launches: [0] arrival counter
                      // of the Gram riders, [1] stage word of the factorising block, [2] completion counter of the solve riders
-  float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply
+  float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply; the dense f16 apply keeps the
+                  // planes of W_old and the scales here (uce_apply_h2.hip: apply_h2_workspace)
   size_t T_elems;
+  // uce_edit, primal path: W_old waiting to be split into f16 planes by rider workgroups of the Cholesky launch
+  // (h2_pending_*: set before uce_solve_delta, consumed by launch_potrf_slabs), and the W_old whose planes are in h->T
+  // (h2_done_*: set by that launch, consumed by launch_apply_h2)
+  const float* h2_pending_src;
+  long h2_pending_rows;
+  int h2_pending_d;
+  const float* h2_done_src;
+  long h2_done_rows;
+  int h2_done_d;
   void* Vt;       // V^T scratch of uce_sattn_fwd ([B, H, DVP, LkP] 16-bit elements)
   size_t Vt_elems;
   void* retired[32];   // outgrown Vt buffers: kept alive until uce_destroy (captured hipGraphs may still name them)
@@ -143,6 +153,10 @@ int launch_trisolve_inv(uce_ctx* h, int n, int m, const double* rhs64, const flo
 int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
 int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* planes, float* W_new, long rows, int d,
                     hipStream_t st, uce_ctx* h = nullptr);
+// f16 x 2 dense apply (uce_apply_h2.hip).  1: shape outside its buffer descriptors (take launch_apply_b3); 0: launched
+bool apply_h2_fits(long rows, int d);
+int apply_h2_workspace(uce_ctx* h, long rows, int d, unsigned short** Ap, float** rs, float** cb);
+int launch_apply_h2(uce_ctx* h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
 int launch_apply_lowrank(const float* W_old, const float* Dm, const float* R, float* W_new, long rows,
                          int d, int N_edit, hipStream_t st);
 bool apply_lowrank_fits(int d, int N_edit);
@@ -159,6 +173,7 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
 int uce_ensure_T(uce_ctx* h, long rows, int N_edit);
+int uce_ensure_T_floats(uce_ctx* h, size_t need);   // h->T holds >= need floats
 int uce_ensure_Vt(uce_ctx* h, size_t elems);
 size_t sattn_vt_elems(int B, int H, int Lk, int dh);
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,

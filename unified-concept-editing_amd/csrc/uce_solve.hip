@@ -12,6 +12,7 @@
 //   k_trisolve    : one workgroup per 16 right-hand-side columns: forward then backward
 //                   substitution with the inverted diagonal blocks; Y lives in LDS (n <= 1024).
 #include "uce_common.h"
+#include "uce_h2split.h"
 #include "uce_potrf64.h"
 #include <cstdlib>
 
@@ -91,6 +92,8 @@ struct PotrfLaJob {
   unsigned* flags;    // [nb * nb] panel (i, j) published | [nb] L_kk^-1 published | [nb] tiles (k, k-1), (k, k) handed over | [1] exits
                       // | [nb * nb] block (i, k) of L^-1 published
   double* Wi;         // [n, n]: off-diagonal blocks of L^-1 (null: not wanted)
+  H2SplitJob sp;      // sp.blocks rider workgroups behind the factorisation's own: the f16 split of W_old for the dense apply that
+                      // follows the solve (uce_apply_h2.hip), streamed on the CUs the factorisation leaves idle
 };
 
 // One lane polls the flag (relaxed, agent scope), the workgroup passes a barrier; the payload is then read with L1-bypassing
@@ -231,12 +234,21 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ unsigned s_last;
-    if (tid == 0) s_last = __hip_atomic_fetch_add(fDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(fDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - (unsigned)j.sp.blocks - 1 ? 1u : 0u;
     __syncthreads();
     if (s_last)
       for (int e = tid; e < nflags; e += 512) __hip_atomic_store(j.flags + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
+  if (j.sp.blocks && (int)blockIdx.x >= (int)gridDim.x - j.sp.blocks) {
+    // ------------------------------------------------------------------ riders: not part of the factorisation (nobody waits
+    // for them, they wait for nobody, they do not count in fDone); the highest block indices, so they are placed after
+    // every workgroup of the factorisation
+    const int rb = (int)blockIdx.x - ((int)gridDim.x - j.sp.blocks);
+    for (long row = (long)rb * 8 + (tid >> 6); row < j.sp.rows; row += (long)j.sp.blocks * 8)
+      h2_split_row<false>(j.sp.src, j.sp.hi, j.sp.lo, j.sp.inv, row, j.sp.d, tid & 63);
+    return;
+  }
   if (blockIdx.x == 0) {
     // ------------------------------------------------------------------ the walker
     Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
@@ -627,11 +639,31 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
     // variant 1 (default): the launch also forms the off-diagonal blocks of L^-1 (h->Wi) for the GEMM-shaped solve that
     // follows (uce_trinv.hip skips its merge launches); variant 2: factor only
     const bool with_inverse = h->sw.potrf_variant == 1 && h->Wi != nullptr;
-    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags, with_inverse ? h->Wi : nullptr};
     const int tiles = nb * (nb - 1) / 2;
-    hipLaunchKernelGGL(k_potrf_la, dim3(1 + tiles * (with_inverse ? 2 : 1)), dim3(512), POTRF_LA_SMEM, st, job);
+    const int own = 1 + tiles * (with_inverse ? 2 : 1);
+    // uce_edit's primal path leaves the W_old of the dense apply here: the factorisation occupies `own` CUs for its whole
+    // latency chain (d = 768: 133 for ~220 us), the rest of the chip streams the f16 split meanwhile (one workgroup per
+    // CU: this kernel's LDS).  Fewer than 64 free CUs: the apply launches its own split pass.
+    H2SplitJob sp{};
+    if (h->h2_pending_src && 250 - own >= 64) {
+      unsigned short* Ap;
+      float *rs, *cb;
+      const int rc = apply_h2_workspace(h, h->h2_pending_rows, h->h2_pending_d, &Ap, &rs, &cb);
+      if (rc) return rc;
+      const long want = (h->h2_pending_rows + 7) / 8;
+      sp = H2SplitJob{h->h2_pending_src, Ap, Ap + (size_t)h->h2_pending_rows * h->h2_pending_d, rs, h->h2_pending_rows, h->h2_pending_d,
+                      (int)(want < 250 - own ? want : 250 - own)};
+    }
+    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags, with_inverse ? h->Wi : nullptr, sp};
+    hipLaunchKernelGGL(k_potrf_la, dim3(own + sp.blocks), dim3(512), POTRF_LA_SMEM, st, job);
     UCE_LAUNCH_CHECK();
     h->wi_valid = with_inverse;
+    if (sp.blocks) {
+      h->h2_done_src = sp.src;
+      h->h2_done_rows = sp.rows;
+      h->h2_done_d = sp.d;
+    }
+    h->h2_pending_src = nullptr;
     return UCE_OK;
   }
   h->wi_valid = false;
