@@ -81,7 +81,38 @@ __global__ void k(double* out, unsigned long long* cyc, double seed, int nwaves_
   for (int i = 0; i < 64; ++i) f = fmaf(f, 1.0000001f, 1e-12f);
   STAMP(t1, f);
   if (tid == 0) cyc[7] = t1 - t0;
-  out[tid] = x + z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7] + r + acc + idx + f;
+  // (8) 16 dependent v_mfma_f64_16x16x4 (accumulator chain), (9) 16 x (mfma -> readlane -> fma on the scalar -> operand)
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 ca = {x, x, x, x};
+  double ma = x * 1e-3, mb = y;
+  STAMP(t0, ma);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ca = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, ca, 0, 0, 0);
+  asm volatile("" : "+v"(ca));
+  double cs = ca[0];
+  STAMP(t1, cs);
+  if (tid == 0) cyc[8] = t1 - t0;
+  STAMP(t0, cs);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    ca = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, ca, 0, 0, 0);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(ca[0]), 5), hi = __builtin_amdgcn_readlane(__double2hiint(ca[0]), 5);
+    ma = fma(__hiloint2double(hi, lo), 1e-9, ma);
+  }
+  cs = ca[1];
+  STAMP(t1, cs);
+  if (tid == 0) cyc[9] = t1 - t0;
+  // (10) 16 independent mfma f64 (4 accumulators x 4)
+  d4 cb[4] = {ca, ca, ca, ca};
+  STAMP(t0, ma);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, cb[j], 0, 0, 0);
+  cs = cb[0][0] + cb[1][0] + cb[2][0] + cb[3][0];
+  STAMP(t1, cs);
+  if (tid == 0) cyc[10] = t1 - t0;
+  out[tid] = cs + x + z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7] + r + acc + idx + f;
 }
 
 int main() {
@@ -92,12 +123,14 @@ int main() {
   for (int threads : {64, 256, 512}) {
     for (int rep = 0; rep < 3; ++rep) k<<<1, threads>>>(out, cyc, 1.5, 8);
     hipDeviceSynchronize();
-    unsigned long long h[8];
+    unsigned long long h[11];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     printf("threads %d: memtime pair %llu | 64 dep f64 fma %llu (%.1f each) | 64 indep f64 fma %llu (%.1f each) | 16 dep rcp_f64 %llu (%.1f each) | "
            "16 LDS publish rounds %llu (%.1f each) | 16 dep LDS reads %llu (%.1f each) | 16 barriers %llu (%.1f each) | 64 dep f32 fma %llu (%.1f)\n",
            threads, h[0], h[1], h[1] / 64.0, h[2], h[2] / 64.0, h[3], h[3] / 16.0, h[4], h[4] / 16.0, h[5], h[5] / 16.0, h[6], h[6] / 16.0,
            h[7], h[7] / 64.0);
+    printf("   16 dep mfma_f64_16x16x4 %llu (%.1f each) | 16 x (mfma -> readlane -> fma -> operand) %llu (%.1f each) | 16 indep mfma_f64 %llu (%.1f each)\n",
+           h[8], h[8] / 16.0, h[9], h[9] / 16.0, h[10], h[10] / 16.0);
   }
   return 0;
 }

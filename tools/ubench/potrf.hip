@@ -1,7 +1,13 @@
 // Times the 64 x 64 f64 Cholesky-inverse building block (uce_potrf64.h) alone: one 512-thread workgroup, the SPD
 // block in LDS, s_memtime around the call (-DPK_STAMPS: per-phase stamps).  Checks X A X^T = I, X lower triangular.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I include -I unified-concept-editing_amd/csrc tools/ubench/potrf.hip -o /tmp/potrf && /tmp/potrf
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I include -I unified-concept-editing_amd/csrc tools/ubench/potrf.hip -o /tmp/potrf && /tmp/potrf      (-DMF: the one-wave base-case form, potrf_mf.h; -DMF_STAMPS with it)
+#ifdef MF
+#include "potrf_mf.h"
+#define FACTOR potrf64_mf
+#else
 #include "uce_potrf64.h"
+#define FACTOR UCE_POTRF64
+#endif
 #include <cstdio>
 #include <cmath>
 #include <vector>
@@ -13,8 +19,16 @@ __global__ __launch_bounds__(512) void k(const double* A, double* Lo, double* Xo
   const int tid = threadIdx.x;
   for (int e = tid; e < 4096; e += 512) As[(e >> 6) * 66 + (e & 63)] = A[e];
   __syncthreads();
+#ifdef WARM
+  for (int rep = 0; rep < 2; ++rep) {                  // warm instruction cache: time the third call
+    FACTOR([&](int r, int c, double (&v)[4]) { for (int e = 0; e < 4; ++e) v[e] = As[r * 66 + c + e]; },
+                [&](int row, int col, const double (&v)[4]) { for (int e = 0; e < 4; ++e) Xo[row * 64 + col + e] = v[e]; },
+                sc, tid, status, 0, npiv);
+    __syncthreads();
+  }
+#endif
   const unsigned long long t0 = clock64();
-  UCE_POTRF64([&](int r, int c, double (&v)[4]) { for (int e = 0; e < 4; ++e) v[e] = As[r * 66 + c + e]; },
+  FACTOR([&](int r, int c, double (&v)[4]) { for (int e = 0; e < 4; ++e) v[e] = As[r * 66 + c + e]; },
               [&](int row, int col, const double (&v)[4]) { for (int e = 0; e < 4; ++e) Xo[row * 64 + col + e] = v[e]; },
               sc, tid, status, 0, npiv);
   const unsigned long long t1 = clock64();
@@ -22,6 +36,10 @@ __global__ __launch_bounds__(512) void k(const double* A, double* Lo, double* Xo
 #ifdef PK_STAMPS
   __syncthreads();
   if (tid == 0) for (int i = 0; i < 6; ++i) cyc[1 + i] = g_pkst[i] - t0;
+#endif
+#ifdef MF_STAMPS
+  __syncthreads();
+  if (tid == 0) { cyc[1] = t1 - t0; for (int i = 0; i < 19; ++i) cyc[2 + i] = g_mfst[i] - t0; }
 #endif
 }
 
@@ -39,12 +57,12 @@ int main() {
   double *dA, *dL, *dX;
   int* st;
   unsigned long long* cyc;
-  hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&st, 4); hipMalloc(&cyc, 64);
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&st, 4); hipMalloc(&cyc, 512);
   hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
   hipMemset(st, 0, 4);
   const size_t smem = sizeof(Potrf64Scratch) + 64 * 66 * 8;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  for (int npiv : {64, 50, 8}) {
+  for (int npiv : {64, 50, 36, 17, 8, 1}) {
     unsigned long long best = ~0ull;
     for (int rep = 0; rep < 5; ++rep) {
       k<<<1, 512, smem>>>(dA, dL, dX, st, cyc, npiv);
@@ -53,6 +71,15 @@ int main() {
       hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
       if (h < best) best = h;
       hipMemcpy(st, cyc, 56, hipMemcpyDeviceToHost);
+#ifdef MF_STAMPS
+      if (rep == 4) {
+        unsigned long long m[24];
+        hipMemcpy(m, cyc, 22 * 8, hipMemcpyDeviceToHost);
+        printf("  total %llu | entry %llu |", m[1], m[2]);
+        for (int p = 0; p < 4; ++p) printf(" p%d: glue@%llu base@%llu done@%llu |", p, m[3 + 3 * p], m[4 + 3 * p], m[5 + 3 * p]);
+        printf(" w0 end %llu w1 %llu w2 %llu w3 %llu | barrier in %llu out %llu\n", m[15], m[16], m[17], m[18], m[19], m[20]);
+      }
+#endif
 #ifdef PK_STAMPS
       if (rep == 4) printf("  stamps (cycles from entry): start %llu | tiles loaded %llu | lines initialised, first pair out %llu | loop done %llu | pivots scaled %llu | assembled %llu\n", st[1], st[2], st[3], st[4], st[5], st[6]);
 #endif
@@ -61,14 +88,16 @@ int main() {
     hipMemcpy(L.data(), dL, n * n * 8, hipMemcpyDeviceToHost);
     hipMemcpy(X.data(), dX, n * n * 8, hipMemcpyDeviceToHost);
     double e1 = 0, e2 = 0;
-    if (npiv == 64) {
+    {
+      // the factor hands out L^-1 only: check X A' X^T = I (A' = the leading npiv x npiv block of A, identity beyond) and
+      // that X is lower triangular
+      auto Ap = [&](int r, int c) { return (r < npiv && c < npiv) ? A[r * n + c] : (r == c ? 1.0 : 0.0); };
       for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
-          // the factor hands out L^-1 only: check X A X^T = I and that X is lower triangular
           double b = 0;
           for (int k2 = 0; k2 < n; ++k2) {
             double t = 0;
-            for (int k3 = 0; k3 < n; ++k3) t += A[k2 * n + k3] * X[j * n + k3];
+            for (int k3 = 0; k3 < n; ++k3) t += Ap(k2, k3) * X[j * n + k3];
             b += X[i * n + k2] * t;
           }
           e2 = fmax(e2, fabs(b - (i == j ? 1.0 : 0.0)));

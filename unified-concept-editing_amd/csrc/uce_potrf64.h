@@ -267,7 +267,12 @@ __device__ __forceinline__ void potrf64_pk(LoadA loadA, StoreX storeX, Potrf64Sc
 // rank-4 steps with the trailing update on v_mfma_f64_16x16x4_f64 (K = 4 is exactly one MFMA per 16 x 16 tile, 16 steps
 // instead of 32; 49 000 - 53 000: a 4 x 4 pivot-block inverse is a longer dependent chain than two 2 x 2 ones and the
 // update arithmetic the MFMA removes is a fifth of the step), four pivots per barrier on the VALU (48 000), a fully
-// unrolled loop (instruction-fetch bound: 50 KB of run-once code took 75 000 - 90 000).
+// unrolled loop (instruction-fetch bound: 50 KB of run-once code took 75 000 - 90 000).  Round 3: a blocked form whose
+// 16 x 16 base case runs inside ONE wave with no barrier and no LDS round trip per pivot (the pivot row is an MFMA operand
+// vector as it lies in the D layout; tools/ubench/potrf_mf.h, correct on every npiv): 46 900 cycles - a pivot costs
+// ~550 cycles there, not the ~130 of its dependency chain (68-cycle f64 MFMA, 19-cycle v_rcp_f64, 5-cycle f64 FMA:
+// tools/ubench/lat.hip), because a wave64 VALU instruction issues in 4 cycles and the step needs ~50 of them (uniform
+// register selects, operand masks, the scalar-side pivot prediction) plus three 64-cycle f64 MFMAs on one SIMD.
 #define UCE_POTRF64 potrf64_pk
 
 // Factors diagonal block 0 (512 threads).  With nsplit > 1 the block is first summed from the split-K slabs of the
