@@ -97,6 +97,77 @@ def test_apply_matches_f64(H, rows_, d):
     assert O.rel_fro(out.cpu(), want) < 2e-6      # 768-term f32 fmaf chains
 
 
+def _handle_with(env_name, value):
+    """The A/B switches are read when a handle is created: a handle of its own for a forced variant."""
+    import os
+    from uce_amd import edit as E
+    old = os.environ.get(env_name)
+    os.environ[env_name] = value
+    try:
+        return E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ[env_name]
+        else:
+            os.environ[env_name] = old
+
+
+@pytest.mark.parametrize("variant", ["1", "0"])
+@pytest.mark.parametrize("rows_,d", [(128, 128), (1000, 768), (333, 1024)])
+def test_apply_other_forms_match_f64(variant, rows_, d):
+    """UCE_APPLY_VARIANT=1 (three-way bf16 split) and 0 (f32 MFMA): the forms the default two-way f16 split replaced stay
+    correct - they are what a shape outside its buffer descriptors falls back to."""
+    rng = np.random.Generator(np.random.PCG64(rows_ + 1))
+    W = O.linear_default_weight(rows_, d, rng)
+    DT = (rng.standard_normal((d, d)) * (0.5 / math.sqrt(d))).astype(np.float32)
+    DT[0, 1] += 3.0
+    Hv = _handle_with("UCE_APPLY_VARIANT", variant)
+    try:
+        out = Hv.apply(_dev(W), _dev(DT)).cpu()
+    finally:
+        Hv.close()
+    want = W.astype(np.float64) + W.astype(np.float64) @ DT.astype(np.float64).T
+    assert O.rel_fro(out, want) < 2e-6
+
+
+def test_apply_f16_split_scales_rows_and_columns(H):
+    """The two-way f16 split takes a power-of-two scale per row of W_old and per row of (I + Delta)^T: rows of W 2^40
+    apart, an all-zero row, columns of Delta far below the identity - the scaled result must carry fp32-level error on
+    every row separately (a Frobenius norm over the whole matrix would hide the small rows)."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    rows_, d = 640, 768
+    W = O.linear_default_weight(rows_, d, rng)
+    W *= np.ldexp(1.0, rng.integers(-20, 21, size=(rows_, 1))).astype(np.float32)
+    W[17] = 0.0
+    DT = (rng.standard_normal((d, d)) * (0.5 / math.sqrt(d))).astype(np.float32)
+    DT[:, 5] *= 1e-6
+    DT[9] *= 1e-5
+    out = H.apply(_dev(W), _dev(DT)).cpu().numpy().astype(np.float64)
+    want = W.astype(np.float64) + W.astype(np.float64) @ DT.astype(np.float64).T
+    assert np.all(out[17] == 0.0)
+    rown = np.linalg.norm(want, axis=1)
+    err = np.linalg.norm(out - want, axis=1)
+    ok = rown > 0
+    assert float((err[ok] / rown[ok]).max()) < 2e-6
+
+
+def test_primal_edit_riders_against_the_separate_calls(H):
+    """uce_edit's primal path hands two jobs to rider workgroups of the persistent Cholesky launch - the f16 split of W_old
+    and the Bt half of the Gram (A alone is then split over the concepts) - and uce_gram / uce_solve_delta / uce_apply do
+    the same work in launches of their own: the same result up to the summation order of A, and the same bits on a
+    second run (every reduction has a fixed order)."""
+    C, G, s = _synthetic(900, 400, 768, seed=5)
+    rng = np.random.Generator(np.random.PCG64(5))
+    W = _dev(O.linear_default_weight(2000, 768, rng))
+    Cd, Gd, sd = _dev(C), _dev(G), _dev(s)
+    out = H.edit(Cd, Gd, sd, 0.5, W, algo=L.ALGO_PRIMAL, check=True)
+    assert torch.equal(out, H.edit(Cd, Gd, sd, 0.5, W, algo=L.ALGO_PRIMAL, check=True))
+    A, Bt = H.gram(Cd, Gd, sd, 0.5)
+    DT = H.solve_delta(A, Bt)
+    H.status()
+    assert O.rel_fro(out.cpu(), H.apply(W, DT).cpu().double().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("N,Ne,d", [(5, 2, 64), (50, 50, 768), (64, 10, 128), (300, 200, 768), (40, 36, 2048),
                                     (65, 65, 128)])
 def test_dual_factors_and_lowrank_apply(H, N, Ne, d):

@@ -360,18 +360,43 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   if (algo == UCE_ALGO_PRIMAL) {
     rc = uce_ensure(h, d, d);
     if (rc) return rc;
-    rc = uce_gram(h, C, G, s, N, N_edit, d, lamb, h->M, h->Bt, stream);
-    if (rc) return rc;
-    // the dense f16 apply needs W_old split into two f16 planes: a pass over W_old that depends on nothing else of the
-    // step - rider workgroups of the (latency-bound, 133-CU) persistent Cholesky launch do it when that launch is taken
+    // Two pieces of this step depend on nothing but its inputs and are not needed before the Cholesky is over: the f16
+    // split of W_old (for the dense apply) and Bt, the right-hand side of the solve.  When the factorisation is the
+    // persistent launch (133 CUs busy for ~215 us at d = 768, latency-bound), rider workgroups of THAT launch do both on
+    // the CUs it leaves idle, and the Gram launch in front of it computes A alone, split over the concepts.
+    const bool ride = potrf_la_has_room(h, d);
     h->h2_done_src = nullptr;
-    if (h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d)) {
-      h->h2_pending_src = W_old;
-      h->h2_pending_rows = rows;
-      h->h2_pending_d = d;
+    h->bt_pending = GramPrimalArgs{};
+    if (ride) {
+      if (N_edit > 0)
+        h->bt_pending = GramPrimalArgs{C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (N_edit + 31) / 32 * 32, (size_t)0};
+      if (h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d)) {
+        h->h2_pending_src = W_old;
+        h->h2_pending_rows = rows;
+        h->h2_pending_d = d;
+      }
     }
-    rc = uce_solve_delta(h, h->M, h->Bt, d, h->DeltaT, stream);
+    {
+      UceProfScope ps(h, "k_gram_primal", (hipStream_t)stream);
+      rc = launch_gram_primal(h, C, G ? G : C, s, N, N_edit, d, lamb, h->M, h->Bt, (hipStream_t)stream,
+                              ride && N_edit > 0 ? 1 : 0);
+    }
+    if (rc) return rc;
+    {
+      UceProfScope ps(h, "potrf", (hipStream_t)stream);
+      rc = launch_potrf(h, h->M, d, (hipStream_t)stream);
+    }
     h->h2_pending_src = nullptr;
+    if (!rc && h->bt_pending.C) {                                   // the factorisation took another form: Bt in a launch of its own
+      UceProfScope ps(h, "k_gram_primal", (hipStream_t)stream);
+      rc = launch_gram_primal(h, C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (hipStream_t)stream, 2);
+    }
+    h->bt_pending = GramPrimalArgs{};
+    if (rc) return rc;
+    {
+      UceProfScope ps(h, "k_trisolve", (hipStream_t)stream);
+      rc = launch_trisolve(h, d, d, h->Bt, nullptr, d, h->DeltaT, d, (hipStream_t)stream, h->M);
+    }
     if (rc) return rc;
     return uce_apply(h, W_old, h->DeltaT, W_new, rows, d, stream);
   }

@@ -74,6 +74,19 @@ struct UceSwitches {
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
 // width and the largest SPD system (primal: n = d, dual: n = roundup(N, 64)) seen so far.
+// arguments of one primal Gram tile job (uce_gram_tile.h)
+struct GramPrimalArgs {
+  const float* C;       // [N, d]
+  const float* G;       // [N_edit, d]
+  const float* s;       // [N]
+  int N, N_edit, d;
+  float lamb;
+  double* outA;         // [d, d] (+ split * slab_stride)
+  double* outBt;
+  int kchunk;           // concepts per split
+  size_t slab_stride;
+};
+
 struct uce_ctx {
   int device;
   UceSwitches sw;
@@ -108,6 +121,9 @@ struct uce_ctx {
   const float* h2_done_src;
   long h2_done_rows;
   int h2_done_d;
+  // ... and the Bt half of the primal Gram (the right-hand side: not needed before the solve), for the same riders.
+  // bt_pending.C != null after uce_solve_delta's factorisation: nobody took it, uce_edit launches it itself.
+  GramPrimalArgs bt_pending;
   void* Vt;       // V^T scratch of uce_sattn_fwd ([B, H, DVP, LkP] 16-bit elements)
   size_t Vt_elems;
   void* retired[32];   // outgrown Vt buffers: kept alive until uce_destroy (captured hipGraphs may still name them)
@@ -132,7 +148,7 @@ int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, lon
                     int dtype, hipStream_t st, int* rc);
 
 int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
-                       int d, float lamb, double* A, double* Bt, hipStream_t st);
+                       int d, float lamb, double* A, double* Bt, hipStream_t st, int which = 0);
 // Also writes Dm = G - C_e and resets h->status.  When the system is a single 64-block and the
 // Gram was split over K, the slabs are left unreduced: *nsplit_out > 1 and the matrix to factor
 // is h->slabs with *slab_stride_out (k_potrf_first sums them).
@@ -142,6 +158,7 @@ int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, f
 // n_valid (0 = n): rows / columns >= n_valid are the identity padding of the system (their pivots are skipped).
 int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid = 0);
 int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st, int n_valid = 0);
+bool potrf_la_has_room(const uce_ctx* h, int n);   // the persistent Cholesky launch will run for an n x n system and has CUs for riders
 // X = M^-1 RHS after launch_potrf.  RHS is f64 [n, m] (rhs64) or f32 [rhs_rows, m] (rhs32, rows
 // beyond rhs_rows are zero).  out f32 [out_rows, m] gets rows 0..out_rows-1 of X.
 // `scratch` [n, n] f64 (optional): the factored matrix, dead after launch_potrf - with it, systems of >= 3 diagonal

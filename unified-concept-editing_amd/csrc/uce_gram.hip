@@ -10,160 +10,27 @@
 // tile, each wave a 32x32 quadrant (2x2 MFMA tiles).  Split-K partial tiles go to slabs that a
 // reduction kernel sums in a fixed order (bit-repeatable; no atomics).
 #include "uce_common.h"
+#include "uce_gram_tile.h"
 
 namespace {
 
-constexpr int KC = 32;        // K-chunk staged in LDS per iteration
 constexpr int NT_LD = 40;     // row stride (floats) of the k-contiguous NT tiles: conflict-free b128
-
-// lower-triangular tile enumeration: t -> (ti, tj) with ti >= tj
-__device__ __forceinline__ void tri_decode(int t, int& ti, int& tj) {
-  int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while ((a + 1) * (a + 2) / 2 <= t) ++a;
-  while (a * (a + 1) / 2 > t) --a;
-  ti = a;
-  tj = t - a * (a + 1) / 2;
-}
-
-// store one wave's 32x32 quadrant held in 2x2 f64 MFMA accumulators
-__device__ __forceinline__ void store_quadrant(double* out, int ld, int row0, int col0,
-                                               const double4_t (&acc)[2][2], int lane, bool mirror,
-                                               double diag_val, const float* inv_s, float lamb,
-                                               int n_valid, bool add_diag) {
-  const int c = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + m * 16 + rq + 4 * r;
-        const int col = col0 + n * 16 + c;
-        double v = acc[m][n][r];
-        if (add_diag && row == col) {
-          if (inv_s) {
-            // a non-positive scale makes K indefinite: poison the pivot so potrf reports it
-            const float sv = (row < n_valid) ? inv_s[row] : 1.f;
-            v += (row < n_valid) ? ((sv > 0.f) ? (double)lamb / (double)sv : __builtin_nan("")) : 1.0;
-          }
-          else v += diag_val;
-        }
-        out[(size_t)row * ld + col] = v;
-        if (mirror) out[(size_t)col * ld + row] = v;
-      }
-}
 
 // ------------------------------------------------------------------------------------------
 // primal: tiles [0, nA) are the lower-triangular tiles of A, tiles [nA, nA + nb*nb) those of Bt
 // ------------------------------------------------------------------------------------------
-// 8 waves: two quads of 4 waves, each quad a full 64 x 64 tile over ALTERNATE 32-concept chunks (its own LDS staging);
-// quad 1's accumulators are added to quad 0's through LDS at the end (fixed order: bit-repeatable).  With one wave per
-// SIMD (round 2: 4 waves) the f64 MFMA pipe sat idle through every staging write, barrier and fragment read of its only
-// wave: 0.33 of the f64 peak; two waves per SIMD cover each other's stalls.
-__global__ __launch_bounds__(512) void k_gram_primal(const float* __restrict__ C,
-                                                     const float* __restrict__ G,
-                                                     const float* __restrict__ s, int N, int N_edit,
-                                                     int d, float lamb, double* __restrict__ outA,
-                                                     double* __restrict__ outBt, int kchunk,
-                                                     size_t slab_stride) {
+// tiles tile0 .. of the enumeration [A lower tiles | Bt tiles]: the whole Gram (tile0 = 0, all tiles), A only, or Bt only
+__global__ __launch_bounds__(512) void k_gram_primal(GramPrimalArgs a, int tile0) {
   __shared__ __attribute__((aligned(16))) unsigned char stage_raw[2 * 2 * KC * 64 * sizeof(float)];   // 32 KB
   __shared__ float Ss[2][KC];
-  float (*Xs)[KC][64] = (float (*)[KC][64])stage_raw;                         // [2][KC][64]
-  float (*Ys)[KC][64] = (float (*)[KC][64])(stage_raw + 2 * KC * 64 * sizeof(float));
-  double (*Red)[64] = (double (*)[64])stage_raw;   // [64][64]: quad 1's tile on its way to quad 0 (the staging is dead by then)
-
-  const int nb = d / 64;
+  const int nb = a.d / 64;
   const int nA = nb * (nb + 1) / 2;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int half = w >> 2, wq = w & 3, ht = tid & 255;
-  const int wr = wq >> 1, wc = wq & 1;
+  const int t = (int)blockIdx.x + tile0;
   int ti, tj;
-  bool isA = (int)blockIdx.x < nA;
-  if (isA) tri_decode(blockIdx.x, ti, tj);
-  else { int t = blockIdx.x - nA; ti = t / nb; tj = t % nb; }
-  const int split = blockIdx.y;
-  const int Ktot = isA ? N : N_edit;
-  const int k_begin = split * kchunk;
-  const int k_end = min(Ktot, k_begin + kchunk);
-
-  double4_t acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int lrow = ht >> 4;           // 0..15
-  const int lc4 = (ht & 15) * 4;      // 0..60
-  // register prefetch of this quad's next 32-concept chunk: its global loads are in flight while the current one is multiplied
-  float4_t px[KC / 16], py[KC / 16];
-  float ps = 0.f;
-  auto g_load = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < KC / 16; ++p) {
-      const int n = k0 + p * 16 + lrow;
-      px[p] = (float4_t){0.f, 0.f, 0.f, 0.f};
-      py[p] = px[p];
-      if (n < k_end) {
-        px[p] = *(const float4_t*)(C + (size_t)n * d + ti * 64 + lc4);
-        const float4_t cy = *(const float4_t*)(C + (size_t)n * d + tj * 64 + lc4);
-        // stage X = C[:, ti tile], Y = C[:, tj tile] (A) or (G - C)[:, tj tile] (Bt)
-        if (isA) py[p] = cy;
-        else py[p] = *(const float4_t*)(G + (size_t)n * d + tj * 64 + lc4) - cy;
-      }
-    }
-    if (ht < KC) ps = (k0 + ht < k_end) ? s[k0 + ht] : 0.f;
-  };
-  // quad `half` owns chunks half, half + 2, ...; the loop count is the same for both quads (barriers are workgroup-wide):
-  // a quad whose chunk lies beyond k_end stages zeros
-  const int kq = k_begin + half * KC;
-  if (k_begin < k_end) g_load(kq);
-  for (int k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
-#pragma unroll
-    for (int p = 0; p < KC / 16; ++p) {
-      *(float4_t*)&Xs[half][p * 16 + lrow][lc4] = px[p];
-      *(float4_t*)&Ys[half][p * 16 + lrow][lc4] = py[p];
-    }
-    if (ht < KC) Ss[half][ht] = ps;
-    __syncthreads();
-    if (k0 + 2 * KC < k_end) g_load(k0 + 2 * KC + half * KC);
-#pragma unroll
-    for (int kb = 0; kb < KC / 4; ++kb) {
-      const int kk = kb * 4 + (lane >> 4);
-      const double sc = (double)Ss[half][kk];
-      const double a0 = (double)Xs[half][kk][wr * 32 + (lane & 15)] * sc;
-      const double a1 = (double)Xs[half][kk][wr * 32 + 16 + (lane & 15)] * sc;
-      const double b0 = (double)Ys[half][kk][wc * 32 + (lane & 15)];
-      const double b1 = (double)Ys[half][kk][wc * 32 + 16 + (lane & 15)];
-      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
-  }
-  // quad 1 -> LDS -> quad 0 (D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15)
-  {
-    const int c = lane & 15, rq = lane >> 4;
-    if (half == 1) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Red[wr * 32 + m * 16 + rq + 4 * r][wc * 32 + n * 16 + c] = acc[m][n][r];
-    }
-    __syncthreads();
-    if (half == 1) return;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][n][r] += Red[wr * 32 + m * 16 + rq + 4 * r][wc * 32 + n * 16 + c];
-  }
-  double* out = (isA ? outA : outBt) + (size_t)split * slab_stride;
-  store_quadrant(out, d, ti * 64 + wr * 32, tj * 64 + wc * 32, acc, lane, isA && ti != tj,
-                 (double)lamb, nullptr, lamb, 0, isA && split == 0);
+  const bool isA = t < nA;
+  if (isA) tri_decode(t, ti, tj);
+  else { ti = (t - nA) / nb; tj = (t - nA) % nb; }
+  gram_primal_tile(a, isA, ti, tj, (int)blockIdx.y, stage_raw, Ss);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -273,35 +140,49 @@ static int pick_split(int tiles, int kchunks_total) {
   return want < 1 ? 1 : want;
 }
 
+// which = 0: A and Bt (one launch, split over the concepts when the tiles alone do not fill the chip); 1: A only - the
+// caller has arranged for Bt elsewhere (uce_edit: rider workgroups of the Cholesky launch); 2: Bt only
 int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
-                       int d, float lamb, double* A, double* Bt, hipStream_t st) {
+                       int d, float lamb, double* A, double* Bt, hipStream_t st, int which) {
   const int nb = d / 64;
-  const int tiles = nb * (nb + 1) / 2 + nb * nb;
-  const int chunks = (N + KC - 1) / KC;
+  const int nA = nb * (nb + 1) / 2;
+  const int tile0 = which == 2 ? nA : 0;
+  const int tiles = which == 1 ? nA : (which == 2 ? nb * nb : nA + nb * nb);
+  const int Kmax = which == 2 ? N_edit : N;
+  if (Kmax <= 0) {                                    // (Bt of an edit without edit concepts)
+    UCE_HIP_TRY(hipMemsetAsync(Bt, 0, (size_t)d * d * sizeof(double), st));
+    return UCE_OK;
+  }
+  const int chunks = (Kmax + KC - 1) / KC;
   int nsplit = pick_split(tiles, chunks);
+  // A alone (78 lower tiles at d = 768): ONE round of workgroups - 3 x 78 = 234 on 256 CUs, not 4 x 78 in two rounds
+  if (which == 1 && tiles < 128 && 256 / tiles >= 1) nsplit = 256 / tiles < chunks ? 256 / tiles : chunks;
   int kchunk = ((chunks + nsplit - 1) / nsplit) * KC;
-  nsplit = (N + kchunk - 1) / kchunk;
+  nsplit = (Kmax + kchunk - 1) / kchunk;
   const size_t mat = (size_t)d * d;
   if (nsplit == 1) {
-    hipLaunchKernelGGL(k_gram_primal, dim3(tiles, 1), dim3(512), 0, st, C, G, s, N, N_edit, d, lamb, A, Bt,
-                       kchunk, (size_t)0);
+    const GramPrimalArgs a{C, G, s, N, N_edit, d, lamb, A, Bt, kchunk, (size_t)0};
+    hipLaunchKernelGGL(k_gram_primal, dim3(tiles, 1), dim3(512), 0, st, a, tile0);
     UCE_LAUNCH_CHECK();
     return UCE_OK;
   }
-  // slabs: [nsplit][A | Bt]
-  const size_t need = (size_t)nsplit * 2 * mat * sizeof(double);
+  // slabs: [nsplit][A | Bt] (both), [nsplit][A] or [nsplit][Bt]
+  const size_t stride = which == 0 ? 2 * mat : mat;
+  const size_t need = (size_t)nsplit * stride * sizeof(double);
   if (need > h->slabs_bytes) return UCE_ENOMEM;
   double* sA = h->slabs;
-  double* sB = h->slabs + mat;
-  hipLaunchKernelGGL(k_gram_primal, dim3(tiles, nsplit), dim3(512), 0, st, C, G, s, N, N_edit, d, lamb, sA,
-                     sB, kchunk, 2 * mat);
+  double* sB = which == 0 ? h->slabs + mat : h->slabs;
+  const GramPrimalArgs a{C, G, s, N, N_edit, d, lamb, sA, sB, kchunk, stride};
+  hipLaunchKernelGGL(k_gram_primal, dim3(tiles, nsplit), dim3(512), 0, st, a, tile0);
   UCE_LAUNCH_CHECK();
   // a split whose k-range is beyond N_edit still writes zeros to its Bt slab, so both reduce fully
   const int thr = 256;
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
-                     (const double*)sA, 2 * mat, nsplit, A, mat);
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
-                     (const double*)sB, 2 * mat, nsplit, Bt, mat);
+  if (which != 2)
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
+                       (const double*)sA, stride, nsplit, A, mat);
+  if (which != 1)
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((mat + thr - 1) / thr)), dim3(thr), 0, st,
+                       (const double*)sB, stride, nsplit, Bt, mat);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

@@ -13,18 +13,13 @@
 //                   substitution with the inverted diagonal blocks; Y lives in LDS (n <= 1024).
 #include "uce_common.h"
 #include "uce_h2split.h"
+#include "uce_gram_tile.h"
 #include "uce_potrf64.h"
 #include <cstdlib>
 
 namespace {
 
-__device__ __forceinline__ void tri_decode(int t, int& a, int& b) {
-  a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while ((a + 1) * (a + 2) / 2 <= t) ++a;
-  while (a * (a + 1) / 2 > t) --a;
-  b = t - a * (a + 1) / 2;
-}
-
+// (tri_decode: uce_gram_tile.h)
 // Factors diagonal block 0 (body shared with the fused projection+factor launch, uce_potrf64.h).
 __global__ __launch_bounds__(512) void k_potrf_first(const double* __restrict__ M, int n, int nsplit,
                                                      size_t slab_stride, double* __restrict__ Lmat,
@@ -94,6 +89,8 @@ struct PotrfLaJob {
   double* Wi;         // [n, n]: off-diagonal blocks of L^-1 (null: not wanted)
   H2SplitJob sp;      // sp.blocks rider workgroups behind the factorisation's own: the f16 split of W_old for the dense apply that
                       // follows the solve (uce_apply_h2.hip), streamed on the CUs the factorisation leaves idle
+  GramPrimalArgs bt;  // bt.C != null: the same riders then compute the d/64 x d/64 tiles of Bt = C_e^T S_e (G - C_e), the right-hand
+                      // side of the solve that follows - nothing in this launch reads it
 };
 
 // One lane polls the flag (relaxed, agent scope), the workgroup passes a barrier; the payload is then read with L1-bypassing
@@ -245,8 +242,17 @@ __global__ __launch_bounds__(512) void k_potrf_la(PotrfLaJob j) {
     // for them, they wait for nobody, they do not count in fDone); the highest block indices, so they are placed after
     // every workgroup of the factorisation
     const int rb = (int)blockIdx.x - ((int)gridDim.x - j.sp.blocks);
-    for (long row = (long)rb * 8 + (tid >> 6); row < j.sp.rows; row += (long)j.sp.blocks * 8)
-      h2_split_row<false>(j.sp.src, j.sp.hi, j.sp.lo, j.sp.inv, row, j.sp.d, tid & 63);
+    if (j.sp.src)
+      for (long row = (long)rb * 8 + (tid >> 6); row < j.sp.rows; row += (long)j.sp.blocks * 8)
+        h2_split_row<false>(j.sp.src, j.sp.hi, j.sp.lo, j.sp.inv, row, j.sp.d, tid & 63);
+    if (j.bt.C) {
+      const int nbt = j.bt.d / 64;
+      float (*Ss)[KC] = (float (*)[KC])(smem_raw + 2 * 2 * KC * 64 * sizeof(float));
+      for (int t = rb; t < nbt * nbt; t += j.sp.blocks) {
+        gram_primal_tile(j.bt, false, t / nbt, t % nbt, 0, smem_raw, Ss);
+        __syncthreads();                                         // the next tile's staging overwrites the reduction tile
+      }
+    }
     return;
   }
   if (blockIdx.x == 0) {
@@ -626,10 +632,28 @@ __global__ __launch_bounds__(256) void k_trisolve(const double* __restrict__ Lma
 // only for lower-numbered ones and may start late.
 constexpr int POTRF_LA_MAX_NB = 16;
 
+// the persistent launch is taken for this system, and `*own` workgroups are its own
+static bool potrf_la_taken(const uce_ctx* h, int n, int nsplit, int* own) {
+  const int nb = n / 64;
+  if (!(nsplit == 1 && nb >= 3 && nb <= POTRF_LA_MAX_NB && h->sw.potrf_variant != 0 && h->la_flags)) return false;
+  const bool with_inverse = h->sw.potrf_variant == 1 && h->Wi != nullptr;
+  *own = 1 + nb * (nb - 1) / 2 * (with_inverse ? 2 : 1);
+  return true;
+}
+constexpr int POTRF_LA_RIDER_CUS = 250;   // workgroups the launch may place at once (one per CU: this kernel's LDS), a few CUs spare
+constexpr int POTRF_LA_MIN_RIDERS = 64;
+
+// uce_edit asks before it hands the launch its rider jobs (the split of W_old, the Bt half of the Gram)
+bool potrf_la_has_room(const uce_ctx* h, int n) {
+  int own = 0;
+  return potrf_la_taken(h, n, 1, &own) && POTRF_LA_RIDER_CUS - own >= POTRF_LA_MIN_RIDERS;
+}
+
 int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid) {
   if (n_valid <= 0 || n_valid > n) n_valid = n;
   const int nb = n / 64;
-  if (nsplit == 1 && nb >= 3 && nb <= POTRF_LA_MAX_NB && h->sw.potrf_variant != 0 && h->la_flags) {
+  int own = 0;
+  if (potrf_la_taken(h, n, nsplit, &own)) {
     // one persistent launch with look-ahead (k_potrf_la)
     static PerDeviceOnce la_once;
     if (const int tok = la_once.first()) {
@@ -639,30 +663,33 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
     // variant 1 (default): the launch also forms the off-diagonal blocks of L^-1 (h->Wi) for the GEMM-shaped solve that
     // follows (uce_trinv.hip skips its merge launches); variant 2: factor only
     const bool with_inverse = h->sw.potrf_variant == 1 && h->Wi != nullptr;
-    const int tiles = nb * (nb - 1) / 2;
-    const int own = 1 + tiles * (with_inverse ? 2 : 1);
     // uce_edit's primal path leaves the W_old of the dense apply here: the factorisation occupies `own` CUs for its whole
     // latency chain (d = 768: 133 for ~220 us), the rest of the chip streams the f16 split meanwhile (one workgroup per
     // CU: this kernel's LDS).  Fewer than 64 free CUs: the apply launches its own split pass.
     H2SplitJob sp{};
-    if (h->h2_pending_src && 250 - own >= 64) {
-      unsigned short* Ap;
-      float *rs, *cb;
-      const int rc = apply_h2_workspace(h, h->h2_pending_rows, h->h2_pending_d, &Ap, &rs, &cb);
-      if (rc) return rc;
-      const long want = (h->h2_pending_rows + 7) / 8;
-      sp = H2SplitJob{h->h2_pending_src, Ap, Ap + (size_t)h->h2_pending_rows * h->h2_pending_d, rs, h->h2_pending_rows, h->h2_pending_d,
-                      (int)(want < 250 - own ? want : 250 - own)};
+    GramPrimalArgs bt{};
+    const int room = POTRF_LA_RIDER_CUS - own;
+    if (room >= POTRF_LA_MIN_RIDERS) {
+      if (h->h2_pending_src) {
+        unsigned short* Ap;
+        float *rs, *cb;
+        const int rc = apply_h2_workspace(h, h->h2_pending_rows, h->h2_pending_d, &Ap, &rs, &cb);
+        if (rc) return rc;
+        sp = H2SplitJob{h->h2_pending_src, Ap, Ap + (size_t)h->h2_pending_rows * h->h2_pending_d, rs, h->h2_pending_rows, h->h2_pending_d, 0};
+      }
+      if (h->bt_pending.C) bt = h->bt_pending;
+      if (sp.src || bt.C) sp.blocks = room;
     }
-    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags, with_inverse ? h->Wi : nullptr, sp};
+    const PotrfLaJob job{M, n, nb, n_valid, h->Lmat, h->Linv, h->status, h->la_flags, with_inverse ? h->Wi : nullptr, sp, bt};
     hipLaunchKernelGGL(k_potrf_la, dim3(own + sp.blocks), dim3(512), POTRF_LA_SMEM, st, job);
     UCE_LAUNCH_CHECK();
     h->wi_valid = with_inverse;
-    if (sp.blocks) {
+    if (sp.src) {
       h->h2_done_src = sp.src;
       h->h2_done_rows = sp.rows;
       h->h2_done_d = sp.d;
     }
+    if (bt.C) h->bt_pending.C = nullptr;                           // taken (uce_edit launches Bt itself when this is still set)
     h->h2_pending_src = nullptr;
     return UCE_OK;
   }
