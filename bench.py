@@ -259,7 +259,7 @@ def kernel_breakdown(H, inp, algo: int, step, iters: int = 30):
                    achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
                    **({"algorithmic_bytes": work} if bound == "hbm" else {"algorithmic_flops": work}), note=note)
         t = traffic.get(kname)
-        ent["traffic"] = t.get("total_bytes") if isinstance(t, dict) else None
+        ent["traffic"] = t.get("chain_bytes", t.get("total_bytes")) if isinstance(t, dict) else None
         if isinstance(t, dict) and t.get("mfma_util") is not None:
             ent["mfma_util"] = t["mfma_util"]
         if isinstance(t, dict):
