@@ -79,10 +79,13 @@ int uce_solve_rhs(uce_handle_t h, double* A, const double* B, int d, int m, floa
 
 /* a5 - apply (replaces `mat1 @ inverse` of uce_sd_erase.py:82 for ALL modules in one launch):
  *   W_new [rows,d] = W_old + W_old Delta ; rows = sum of the modules' out_features (the host
- *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  Products carry fp32 accuracy: both operands
- *   are split exactly into three bf16 terms and the six significant partial products run on the bf16 matrix
- *   cores with fp32 accumulation (error <= one fp32 rounding per product; UCE_APPLY_VARIANT=0 selects the
- *   f32-MFMA kernel whose products are bit-exact fmaf chains). */
+ *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  Products carry fp32 accuracy: each row of W_old
+ *   and of (I + Delta)^T is scaled by a power of two and split exactly into two f16 terms, the three significant
+ *   partial products run on the f16 matrix cores with fp32 accumulation, the scales leave in the epilogue (error
+ *   <= one fp32 rounding per product for elements within 2^16 of their row's maximum, 2^-40 of that maximum
+ *   below).  UCE_APPLY_VARIANT (read at uce_create) = 1: the three-way bf16 split, six products, no scales - also
+ *   what a slab beyond 2 GB of planes takes; 0: the f32-MFMA kernel whose products are bit-exact fmaf chains.
+ *   Uses the handle's row workspace (uce_reserve_rows(h, rows, d + 64) pre-sizes it). */
 int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,
               uce_stream_t stream);
 
