@@ -426,6 +426,32 @@ def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
         assert O.rel_fro(out.cpu(), (W64 + W64 @ Delta).cpu()) < EPS_BUILD
 
 
+@pytest.mark.parametrize("N_e,N_p,d,rows_", [
+    (900, 700, 192, 700),      # 3 diagonal blocks: the smallest system the persistent Cholesky (and its riders) takes; 1600
+                               # concepts against 6 lower tiles: the concept split of A is capped by the slab workspace
+    (300, 100, 256, 1300),     # 4 blocks, rows not a multiple of the 320-row apply tile
+    (600, 500, 1024, 2500),    # 16 blocks: the launch has no room for riders - the apply splits W_old itself, one Gram launch
+    (0, 300, 256, 640),        # nothing to edit: Bt = 0, W_new = W_old (I + 0)
+    (70, 10, 2048, 1000),      # primal forced below d: 32 blocks take the launch chain
+])
+def test_primal_edit_other_widths(H, N_e, N_p, d, rows_):
+    """uce_edit's primal path at every way it can be put together: riders (d = 192 ... 960), no room for riders (d = 1024),
+    the launch chain (d = 2048), no edit concepts."""
+    C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e + d)
+    rng = np.random.Generator(np.random.PCG64(d))
+    W = O.linear_default_weight(rows_, d, rng)
+    Cd, sd, Wd = _dev(C), _dev(s), _dev(W)
+    Gd = _dev(G) if N_e else None
+    out = H.edit(Cd, Gd, sd, 0.5, Wd, algo=L.ALGO_PRIMAL, check=True)
+    if N_e == 0:
+        # W (I + 0): the two f16 terms of a weight carry 22 of its 24 significand bits - one fp32 rounding, not a copy
+        assert O.rel_fro(out.cpu(), W.astype(np.float64)) < 1e-7
+        return
+    _, _, DTe = _exact(C, G, s, 0.5)
+    want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
+    assert O.rel_fro(out.cpu(), want) < EPS_BUILD
+
+
 @pytest.mark.parametrize("N_e,N_p", [(1, 0), (2, 1), (4, 0), (3, 5), (16, 0), (10, 7), (20, 0), (31, 0), (32, 0), (20, 13),
                                      (47, 0), (48, 0), (40, 9), (63, 0), (64, 0), (66, 0), (96, 0), (127, 0)])
 def test_edit_every_segment_of_the_64x64_block(H, N_e, N_p):

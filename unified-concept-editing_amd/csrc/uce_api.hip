@@ -365,8 +365,16 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     // persistent launch (133 CUs busy for ~215 us at d = 768, latency-bound), rider workgroups of THAT launch do both on
     // the CUs it leaves idle, and the Gram launch in front of it computes A alone, split over the concepts.
     const bool ride = potrf_la_has_room(h, d);
-    h->h2_done_src = nullptr;
-    h->bt_pending = GramPrimalArgs{};
+    struct RiderJobs {                       // whatever way this path is left, nothing stays behind for a later factorisation / apply
+      uce_ctx* h;
+      explicit RiderJobs(uce_ctx* h_) : h(h_) { clear(); }
+      ~RiderJobs() { clear(); }
+      void clear() {
+        h->h2_pending_src = nullptr;
+        h->h2_done_src = nullptr;
+        h->bt_pending = GramPrimalArgs{};
+      }
+    } jobs(h);
     if (ride) {
       if (N_edit > 0)
         h->bt_pending = GramPrimalArgs{C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (N_edit + 31) / 32 * 32, (size_t)0};
@@ -386,12 +394,10 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
       UceProfScope ps(h, "potrf", (hipStream_t)stream);
       rc = launch_potrf(h, h->M, d, (hipStream_t)stream);
     }
-    h->h2_pending_src = nullptr;
     if (!rc && h->bt_pending.C) {                                   // the factorisation took another form: Bt in a launch of its own
       UceProfScope ps(h, "k_gram_primal", (hipStream_t)stream);
       rc = launch_gram_primal(h, C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (hipStream_t)stream, 2);
     }
-    h->bt_pending = GramPrimalArgs{};
     if (rc) return rc;
     {
       UceProfScope ps(h, "k_trisolve", (hipStream_t)stream);

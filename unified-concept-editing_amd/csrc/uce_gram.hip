@@ -156,7 +156,11 @@ int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* 
   const int chunks = (Kmax + KC - 1) / KC;
   int nsplit = pick_split(tiles, chunks);
   // A alone (78 lower tiles at d = 768): ONE round of workgroups - 3 x 78 = 234 on 256 CUs, not 4 x 78 in two rounds
-  if (which == 1 && tiles < 128 && 256 / tiles >= 1) nsplit = 256 / tiles < chunks ? 256 / tiles : chunks;
+  if (which == 1 && tiles < 128) {
+    nsplit = 256 / tiles < chunks ? 256 / tiles : chunks;
+    const size_t cap = h->slabs_bytes / ((size_t)d * d * sizeof(double));   // the slab workspace is sized for the one-launch form
+    if ((size_t)nsplit > cap) nsplit = cap ? (int)cap : 1;
+  }
   int kchunk = ((chunks + nsplit - 1) / nsplit) * KC;
   nsplit = (Kmax + kchunk - 1) / kchunk;
   const size_t mat = (size_t)d * d;
