@@ -293,6 +293,11 @@ def time_steps(step, steps: int, world: int, device):
         torch.cuda.synchronize()
 
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the first timing event of a process costs ~40 ms of one-off runtime set-up: spend it outside the timed region
+    # (seen as 0.28 ms/step "wall" against 0.064 ms/step of events when the edit leg was the first thing a run did)
+    warm = torch.cuda.Event(enable_timing=True)
+    warm.record()
+    warm.synchronize()
     barrier()
     t0 = time.perf_counter()
     e0.record()

@@ -1,4 +1,4 @@
-out=gpurun_out/r3z; mkdir -p $out
+out=gpurun_out/r3final; mkdir -p $out
 timeout 1500 python -m pytest tests -m gpu -q --timeout 300 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
 tail -4 $out/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
