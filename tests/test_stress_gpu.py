@@ -69,10 +69,11 @@ def test_random_edits_back_to_back_on_two_handles_and_streams(seed):
         H2.close()
 
 
-@pytest.mark.parametrize("n_e,n_p", [(50, 0), (100, 20)])
+@pytest.mark.parametrize("n_e,n_p", [(50, 0), (100, 20), (600, 400)])
 def test_edit_replays_from_a_captured_graph(n_e, n_p):
     """The rider hand-off keeps no launch-specific value in the kernel arguments (the stage word and its reset live on the
-    device), so a captured uce_edit can be replayed: three replays on changed weights, each against fp64."""
+    device), so a captured uce_edit can be replayed: three replays on changed weights, each against fp64.  (600 + 400
+    concepts: the primal path - the persistent Cholesky launch with its rider jobs, whose flags the launch clears itself.)"""
     d, rows = 768, 2048
     rng = np.random.Generator(np.random.PCG64(n_e))
     H = E.UceHandle.get("cuda:0")
