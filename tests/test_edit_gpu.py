@@ -85,7 +85,7 @@ def test_solve_reports_indefinite_system(H):
     assert O.rel_fro(DT.cpu(), np.eye(d)) < 1e-7
 
 
-@pytest.mark.parametrize("rows_,d", [(96, 64), (128, 128), (1000, 768), (24960, 768), (333, 1024)])
+@pytest.mark.parametrize("rows_,d", [(96, 64), (128, 128), (1000, 768), (24960, 768), (333, 1024), (700, 2048)])
 def test_apply_matches_f64(H, rows_, d):
     rng = np.random.Generator(np.random.PCG64(rows_))
     W = O.linear_default_weight(rows_, d, rng)

@@ -167,7 +167,8 @@ int uce_create(uce_handle_t* out, int device) {
     const int cap = lr_rider_cap();
     const int want = env_int("UCE_RIDER_MAX_N", cap);
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
-                        want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0)};
+                        want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
+                        env_int("UCE_POTRF_RIDER_CUS", 250)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }

@@ -640,13 +640,13 @@ static bool potrf_la_taken(const uce_ctx* h, int n, int nsplit, int* own) {
   *own = 1 + nb * (nb - 1) / 2 * (with_inverse ? 2 : 1);
   return true;
 }
-constexpr int POTRF_LA_RIDER_CUS = 250;   // workgroups the launch may place at once (one per CU: this kernel's LDS), a few CUs spare
+// (h->sw.potrf_rider_cus, default 250: workgroups the launch may place at once - one per CU: this kernel's LDS -, a few CUs spare)
 constexpr int POTRF_LA_MIN_RIDERS = 64;
 
 // uce_edit asks before it hands the launch its rider jobs (the split of W_old, the Bt half of the Gram)
 bool potrf_la_has_room(const uce_ctx* h, int n) {
   int own = 0;
-  return potrf_la_taken(h, n, 1, &own) && POTRF_LA_RIDER_CUS - own >= POTRF_LA_MIN_RIDERS;
+  return potrf_la_taken(h, n, 1, &own) && h->sw.potrf_rider_cus - own >= POTRF_LA_MIN_RIDERS;
 }
 
 int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid) {
@@ -668,7 +668,7 @@ int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_str
     // CU: this kernel's LDS).  Fewer than 64 free CUs: the apply launches its own split pass.
     H2SplitJob sp{};
     GramPrimalArgs bt{};
-    const int room = POTRF_LA_RIDER_CUS - own;
+    const int room = h->sw.potrf_rider_cus - own;
     if (room >= POTRF_LA_MIN_RIDERS) {
       if (h->h2_pending_src) {
         unsigned short* Ap;
