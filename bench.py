@@ -197,7 +197,8 @@ def kernel_model(name: str, path: str, N: int, n_e: int, d: int, rows: int):
         return "mfma", n_sys ** 3 / 3.0, F64_MFMA_PEAK_TF, "TFLOP/s", ("f64 blocked Cholesky (latency chain of n pivots); on the primal path its "
                                                                        "rider workgroups also compute Bt and the f16 split of W_old")
     if name == "k_gram_primal":
-        if 3 <= d // 64 <= 16 and n_e > 0:      # the persistent Cholesky launch follows: its rider workgroups compute Bt (and split W_old)
+        nb = d // 64                            # (mirrors uce_solve.hip:potrf_la_has_room: 250 - (1 + nb (nb - 1)) >= 64 riders)
+        if 3 <= nb <= 14 and n_e > 0:           # the persistent Cholesky launch follows: its rider workgroups compute Bt (and split W_old)
             return "mfma", 1.0 * N * d * d, F64_MFMA_PEAK_TF, "TFLOP/s", ("f64 MFMA, lower tiles of A split over the concepts + slab reduction; "
                                                                           "Bt (2*N_e*d^2 flop) rides in the Cholesky launch")
         return "mfma", (N + 2.0 * n_e) * d * d, F64_MFMA_PEAK_TF, "TFLOP/s", "f64 MFMA, lower tiles of A + all of Bt"
