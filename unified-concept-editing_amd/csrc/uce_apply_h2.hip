@@ -9,8 +9,8 @@
 // relative.  THREE f16 MFMAs per fp32-equivalent product - half of the six the three-way bf16 split (uce_apply_b3.hip)
 // needs for the same accuracy.  What the bf16 form gets for free and this one has to provide is RANGE: f16 spans
 // 2^-14 .. 2^15, so every row of W_old and every row of (I + Delta)^T gets its own power-of-two scale (the row maximum
-// goes to [2^14, 2^15); elements more than 2^18 below their row's maximum lose low bits of x_l - nothing the
-// Frobenius norm can see); the scales factor out of the product as  out[m][n] = acc[m][n] * 2^-e_m * 2^-f_n,  exact.
+// goes to [2^14, 2^15); elements more than 2^16 below their row's maximum have a denormal x_l: an absolute error of
+// <= 2^-29 of that maximum - nothing a Frobenius norm can see, nor any row of W against I + Delta); the scales factor out of the product as  out[m][n] = acc[m][n] * 2^-e_m * 2^-f_n,  exact.
 //
 //   k_split_h2 / _h2d  one wave per row: row maximum -> scale -> the two f16 planes + the inverse scale.  W_old
 //                      [rows, d] (HBM pass: 4 B in, 4 B out per element) and (I + Delta)^T [d, d] (IDENT: + 1 on the
