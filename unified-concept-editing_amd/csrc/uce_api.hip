@@ -137,7 +137,7 @@ static int env_int(const char* name, int dflt) {
 
 extern "C" {
 
-int uce_version(void) { return 111; }
+int uce_version(void) { return 112; }
 
 const char* uce_strerror(int code) {
   switch (code) {
