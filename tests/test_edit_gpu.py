@@ -452,6 +452,21 @@ def test_primal_edit_other_widths(H, N_e, N_p, d, rows_):
     assert O.rel_fro(out.cpu(), want) < EPS_BUILD
 
 
+@pytest.mark.parametrize("N_e,N_p,d,rows_", [(400, 300, 768, 3000), (300, 20, 768, 700), (500, 100, 1024, 1500)])
+def test_dual_edit_beyond_256_edit_concepts(H, N_e, N_p, d, rows_):
+    """N < d with more than 256 edit concepts: dual system -> Cholesky (the persistent launch, carrying the f16 split of
+    W_old as a rider job where it has room) -> R -> Delta = Dm^T R -> the dense apply; twice on the same handle."""
+    C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e + N_p)
+    rng = np.random.Generator(np.random.PCG64(N_e))
+    _, _, DTe = _exact(C, G, s, 0.5)
+    Cd, Gd, sd = _dev(C), _dev(G), _dev(s)
+    for rep in range(2):
+        W = O.linear_default_weight(rows_, d, rng)
+        out = H.edit(Cd, Gd, sd, 0.5, _dev(W), check=True)
+        want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
+        assert O.rel_fro(out.cpu(), want) < EPS_BUILD
+
+
 @pytest.mark.parametrize("N_e,N_p", [(1, 0), (2, 1), (4, 0), (3, 5), (16, 0), (10, 7), (20, 0), (31, 0), (32, 0), (20, 13),
                                      (47, 0), (48, 0), (40, 9), (63, 0), (64, 0), (66, 0), (96, 0), (127, 0)])
 def test_edit_every_segment_of_the_64x64_block(H, N_e, N_p):

@@ -349,6 +349,22 @@ int uce_apply_lowrank(uce_handle_t h, const float* W_old, const float* Dm, const
   return launch_apply_lowrank(W_old, Dm, R, W_new, rows, d, N_edit, (hipStream_t)stream);
 }
 
+// Jobs uce_edit leaves for the rider workgroups of the persistent Cholesky launch (h->h2_pending_*, h->bt_pending) and
+// what that launch reports back (h->h2_done_*): whatever way uce_edit is left, nothing stays behind for a later
+// factorisation or apply on the same handle.
+namespace {
+struct RiderJobs {
+  uce_ctx* h;
+  explicit RiderJobs(uce_ctx* h_) : h(h_) { clear(); }
+  ~RiderJobs() { clear(); }
+  void clear() {
+    h->h2_pending_src = nullptr;
+    h->h2_done_src = nullptr;
+    h->bt_pending = GramPrimalArgs{};
+  }
+};
+}  // namespace
+
 int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit, int d,
              float lamb, const float* W_old, float* W_new, long rows, int algo, uce_stream_t stream) {
   if (!h || !C || !s || !W_old || !W_new || N <= 0 || N_edit < 0 || N_edit > N || d <= 0 || d % 64 ||
@@ -366,16 +382,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     // persistent launch (133 CUs busy for ~215 us at d = 768, latency-bound), rider workgroups of THAT launch do both on
     // the CUs it leaves idle, and the Gram launch in front of it computes A alone, split over the concepts.
     const bool ride = potrf_la_has_room(h, d);
-    struct RiderJobs {                       // whatever way this path is left, nothing stays behind for a later factorisation / apply
-      uce_ctx* h;
-      explicit RiderJobs(uce_ctx* h_) : h(h_) { clear(); }
-      ~RiderJobs() { clear(); }
-      void clear() {
-        h->h2_pending_src = nullptr;
-        h->h2_done_src = nullptr;
-        h->bt_pending = GramPrimalArgs{};
-      }
-    } jobs(h);
+    RiderJobs jobs(h);
     if (ride) {
       if (N_edit > 0)
         h->bt_pending = GramPrimalArgs{C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (N_edit + 31) / 32 * 32, (size_t)0};
@@ -455,7 +462,17 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     UceProfScope ps(h, "k_lr_update", st);
     return launch_lr_update(W_old, h->T, h->R, W_new, rows, d, N_edit, st);
   }
+  // More than 256 edit concepts against N < d: the dual system's Cholesky (persistent from 3 diagonal blocks), then Delta and
+  // the dense apply - whose f16 split of W_old again rides in the Cholesky launch
+  RiderJobs jobs(h);
+  if (!apply_lowrank_fits(d, N_edit) && h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d) &&
+      potrf_la_has_room(h, n_pad)) {
+    h->h2_pending_src = W_old;
+    h->h2_pending_rows = rows;
+    h->h2_pending_d = d;
+  }
   rc = uce_dual_factors(h, C, G, s, N, N_edit, d, lamb, h->Dm, h->R, stream);
+  h->h2_pending_src = nullptr;
   if (rc) return rc;
   if (apply_lowrank_fits(d, N_edit))
     return uce_apply_lowrank(h, W_old, h->Dm, h->R, W_new, rows, d, N_edit, stream);
