@@ -168,7 +168,7 @@ int uce_create(uce_handle_t* out, int device) {
     const int want = env_int("UCE_RIDER_MAX_N", cap);
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
                         want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
-                        env_int("UCE_POTRF_RIDER_CUS", 250)};
+                        env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
@@ -418,7 +418,9 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   const int n_pad = round_up(N, 64);
   rc = uce_ensure(h, d, n_pad);
   if (rc) return rc;
-  if (N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit)) {
+  if (N_edit >= 1 && rows >= 1024 && lowrank_split_supported(d, N_edit) && N_edit <= h->sw.split_max_ne && N <= h->sw.split_max_n) {
+    // (more than 128 edit concepts: the dense form below - Delta + the f16 apply - is 25-33 % ahead of two projection and two
+    //  update passes since round 3, tools/ab_split.py; UCE_SPLIT_MAX_NE=256 brings the two-pass form back)
     // N <= 128: THREE launches on the caller's stream, no events (forking the Gram -> Cholesky -> solve chain onto a
     // side stream beside a rider-less projection was measured at 105 us against 70: the two cross-stream event
     // waits cost more than the overlap buys):
@@ -465,8 +467,8 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   // More than 256 edit concepts against N < d: the dual system's Cholesky (persistent from 3 diagonal blocks), then Delta and
   // the dense apply - whose f16 split of W_old again rides in the Cholesky launch
   RiderJobs jobs(h);
-  if (!apply_lowrank_fits(d, N_edit) && h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d) &&
-      potrf_la_has_room(h, n_pad)) {
+  const bool dense = !apply_lowrank_fits(d, N_edit) || (N_edit >= 1 && (N_edit > h->sw.split_max_ne || N > h->sw.split_max_n));
+  if (dense && h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d) && potrf_la_has_room(h, n_pad)) {
     h->h2_pending_src = W_old;
     h->h2_pending_rows = rows;
     h->h2_pending_d = d;
@@ -474,7 +476,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   rc = uce_dual_factors(h, C, G, s, N, N_edit, d, lamb, h->Dm, h->R, stream);
   h->h2_pending_src = nullptr;
   if (rc) return rc;
-  if (apply_lowrank_fits(d, N_edit))
+  if (!dense)
     return uce_apply_lowrank(h, W_old, h->Dm, h->R, W_new, rows, d, N_edit, stream);
   rc = uce_delta_from_factors(h, h->Dm, h->R, N_edit, d, h->DeltaT, stream);
   if (rc) return rc;

@@ -60,6 +60,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 // A/B switches for measurements (defaults = the measured best), read from the environment ONCE, when the handle is created:
 //   UCE_XATTN_VARIANT   1 (default): column-group kernel at generation-batch sizes | 0: always k_xattn | 2: the group kernel
 //                       at every size | 3: its 8-wave dh = 40 form
+//   UCE_SPLIT_MAX_NE / UCE_SPLIT_MAX_N  uce_edit takes the project + update form up to this many edit concepts / concepts in all (beyond: Delta + dense apply)
 //   UCE_POTRF_RIDER_CUS workgroups (CUs) the persistent Cholesky launch may occupy with its riders included (default 250; 0: no riders)
 //   UCE_APPLY_VARIANT   2: f16 x 2 dense apply, direct-to-LDS | 1: bf16 x 3 dense apply | 0: the f32-MFMA kernel
 //   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
@@ -70,7 +71,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
-  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus;
+  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
