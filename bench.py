@@ -162,7 +162,7 @@ def edit_path(N: int, n_e: int, d: int, rows: int, algo: int) -> str:
     dual = (algo == 2) or (algo == 0 and round_up(N, 64) < d)
     if not dual:
         return "primal"
-    if 1 <= n_e <= 256 and d in (768, 1024, 2048) and rows >= 1024:
+    if 1 <= n_e <= 128 and d in (768, 1024, 2048) and rows >= 1024:      # (UCE_SPLIT_MAX_NE: beyond, Delta + the dense apply)
         return "dual_lowrank"
     return "dual_other"
 
