@@ -168,7 +168,8 @@ int uce_create(uce_handle_t* out, int device) {
     const int want = env_int("UCE_RIDER_MAX_N", cap);
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
                         want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
-                        env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30)};
+                        env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30),
+                        env_int("UCE_PROJECT_LA", 1)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
@@ -446,15 +447,25 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
         rc = launch_gram_dual(h, C, s, N, d, lamb, h->M, n_pad, nullptr, nullptr, 0, &nsplit, &slab_stride, st);
       }
       if (rc) return rc;
-      {
-        UceProfScope ps(h, "potrf", st);
-        rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st, N)
-                          : launch_potrf(h, h->M, n_pad, st, N);
+      // 3 ... 16 diagonal blocks (129 ... 1024 concepts): the persistent Cholesky runs in the FIRST workgroups of the
+      // projection launch - neither needs anything from the other (tools/ab_split.py; UCE_PROJECT_LA=0: two launches)
+      PotrfLaJob la{};
+      int own = 0;
+      if (nsplit == 1 && N_edit <= 128 && h->sw.project_la && potrf_la_job(h, h->M, n_pad, N, &la, &own)) {
+        UceProfScope ps(h, "k_lr_project", st);
+        rc = launch_lr_project_la(W_old, G, C, h->T, rows, d, N_edit, la, own, st);
+        if (rc) return rc;
+      } else {
+        {
+          UceProfScope ps(h, "potrf", st);
+          rc = (nsplit > 1) ? launch_potrf_slabs(h, h->slabs, n_pad, nsplit, slab_stride, st, N)
+                            : launch_potrf(h, h->M, n_pad, st, N);
+        }
+        if (rc) return rc;
+        UceProfScope ps(h, "k_lr_project", st);
+        rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st);
+        if (rc) return rc;
       }
-      if (rc) return rc;
-      UceProfScope ps(h, "k_lr_project", st);
-      rc = launch_lr_project(W_old, G, C, h->T, rows, d, N_edit, st);
-      if (rc) return rc;
     }
     if (!riders) {
       UceProfScope ps(h, "k_trisolve", st);

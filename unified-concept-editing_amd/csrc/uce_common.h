@@ -61,6 +61,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_XATTN_VARIANT   1 (default): column-group kernel at generation-batch sizes | 0: always k_xattn | 2: the group kernel
 //                       at every size | 3: its 8-wave dh = 40 form
 //   UCE_SPLIT_MAX_NE / UCE_SPLIT_MAX_N  uce_edit takes the project + update form up to this many edit concepts / concepts in all (beyond: Delta + dense apply)
+//   UCE_PROJECT_LA      1: N > 128 with <= 128 edit concepts: the persistent Cholesky inside the projection launch | 0: in front of it
 //   UCE_POTRF_RIDER_CUS workgroups (CUs) the persistent Cholesky launch may occupy with its riders included (default 250; 0: no riders)
 //   UCE_APPLY_VARIANT   2: f16 x 2 dense apply, direct-to-LDS | 1: bf16 x 3 dense apply | 0: the f32-MFMA kernel
 //   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
@@ -71,7 +72,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
-  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n;
+  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -87,6 +88,33 @@ struct GramPrimalArgs {
   double* outBt;
   int kchunk;           // concepts per split
   size_t slab_stride;
+};
+
+// W_old [rows, d] -> planes hi / lo [rows, d] f16 + inv [rows] (2^-e per row); `blocks` rider workgroups (0: none)
+struct H2SplitJob {
+  const float* src;
+  unsigned short* hi;
+  unsigned short* lo;
+  float* inv;
+  long rows;
+  int d;
+  int blocks;
+};
+
+// job of the persistent Cholesky launch (uce_potrf_la.h)
+struct PotrfLaJob {
+  double* M;          // [n, n] system (lower tiles read; the tiles (i, i-1) and (i, i) are overwritten with their updates)
+  int n, nb, n_valid;
+  double* Lmat;       // [n, n]: off-diagonal blocks of L
+  double* Linv;       // [nb][64][64]
+  int* status;
+  unsigned* flags;    // [nb * nb] panel (i, j) published | [nb] L_kk^-1 published | [nb] tiles (k, k-1), (k, k) handed over | [1] exits
+                      // | [nb * nb] block (i, k) of L^-1 published
+  double* Wi;         // [n, n]: off-diagonal blocks of L^-1 (null: not wanted)
+  H2SplitJob sp;      // sp.blocks rider workgroups behind the factorisation's own: the f16 split of W_old for the dense apply that
+                      // follows the solve (uce_apply_h2.hip), streamed on the CUs the factorisation leaves idle
+  GramPrimalArgs bt;  // bt.C != null: the same riders then compute the d/64 x d/64 tiles of Bt = C_e^T S_e (G - C_e), the right-hand
+                      // side of the solve that follows - nothing in this launch reads it
 };
 
 struct uce_ctx {
@@ -160,7 +188,11 @@ int launch_gram_dual(uce_ctx* h, const float* C, const float* s, int N, int d, f
 // n_valid (0 = n): rows / columns >= n_valid are the identity padding of the system (their pivots are skipped).
 int launch_potrf_slabs(uce_ctx* h, double* M, int n, int nsplit, size_t slab_stride, hipStream_t st, int n_valid = 0);
 int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st, int n_valid = 0);
-bool potrf_la_has_room(const uce_ctx* h, int n);   // the persistent Cholesky launch will run for an n x n system and has CUs for riders
+bool potrf_la_has_room(const uce_ctx* h, int n);
+// the job of the persistent launch for the n x n system M, if that launch is the form the system takes (else false): for a
+// caller that hosts the factorisation in a launch of its own (launch_lr_project_la); *own = its workgroups
+bool potrf_la_job(uce_ctx* h, double* M, int n, int n_valid, PotrfLaJob* job, int* own);
+size_t potrf_la_smem();   // the persistent Cholesky launch will run for an n x n system and has CUs for riders
 // X = M^-1 RHS after launch_potrf.  RHS is f64 [n, m] (rhs64) or f32 [rhs_rows, m] (rhs32, rows
 // beyond rhs_rows are zero).  out f32 [out_rows, m] gets rows 0..out_rows-1 of X.
 // `scratch` [n, n] f64 (optional): the factored matrix, dead after launch_potrf - with it, systems of >= 3 diagonal
@@ -191,6 +223,9 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
                       const float* s = nullptr, int N = 0, float lamb = 0.f, float* R = nullptr);
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
+// the projection with the persistent Cholesky of the dual system (la, own workgroups) in the first workgroups of the launch
+int launch_lr_project_la(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d, int N_edit,
+                         const PotrfLaJob& la, int own, hipStream_t st);
 int uce_ensure_T(uce_ctx* h, long rows, int N_edit);
 int uce_ensure_T_floats(uce_ctx* h, size_t need);   // h->T holds >= need floats
 int uce_ensure_Vt(uce_ctx* h, size_t elems);

@@ -3,16 +3,6 @@
 #pragma once
 #include "uce_common.h"
 
-// W_old [rows, d] -> planes hi / lo [rows, d] f16 + inv [rows] (2^-e per row); `blocks` rider workgroups (0: none)
-struct H2SplitJob {
-  const float* src;
-  unsigned short* hi;
-  unsigned short* lo;
-  float* inv;
-  long rows;
-  int d;
-  int blocks;
-};
 
 typedef unsigned int h2s_uint2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 h2s_f16x2_t __attribute__((ext_vector_type(2)));

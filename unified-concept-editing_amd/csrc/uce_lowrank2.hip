@@ -13,6 +13,7 @@
 // footprint is tiny, so several workgroups per CU stream W with their phases naturally interleaved.
 #include "uce_common.h"
 #include "uce_potrf64.h"
+#include "uce_potrf_la.h"
 
 // -DUCE_CHAIN_DEBUG: wall-clock stamps (100 MHz) of the rider chain's phases, read back with uce_debug_read
 // (tools/dbg_chain.py); compiled out of the product library.
@@ -915,6 +916,53 @@ int pick_mt2(long rows, int extra) {
   return best;
 }
 
+// The projection with the persistent Cholesky of a dual system of 3 ... 16 diagonal blocks in its FIRST n_la workgroups
+// (uce_potrf_la.h; 129 ... 1024 concepts with at most 128 of them edited: the factorisation needs nothing from the
+// projection and the projection nothing from it - they used to be two launches in a row).  The factorisation's workgroups
+// come first in the grid, so they are placed before any projection tile (its waits never depend on later workgroups).
+template <int D, int MT, int CT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_project_la(
+    const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ Csub,
+    float* __restrict__ T, long rows, int Ne, int NEP, PotrfLaJob la, int n_la) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((int)blockIdx.x < n_la) {
+    potrf_la_body(la, (int)blockIdx.x, n_la, smem_raw);
+    return;
+  }
+  float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD]
+  constexpr int M0 = (MT + 1) / 2;
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
+    project_body_w<D, MT, M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, n_la);
+  else
+    project_body_w<D, MT, MT - M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, n_la);
+}
+
+template <int D, int MT, int CT>
+int launch_project_la(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit, int NEP64,
+                      const PotrfLaJob& la, int own, hipStream_t st) {
+  size_t smem = (size_t)2 * (MT * 16 + 64 * CT) * PJ_LD * sizeof(float);
+  if (smem < potrf_la_smem()) smem = potrf_la_smem();
+  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+  if (const int tok = attr_once.first()) {
+    // (what it needs, not the 160 KB the plain projection asks for: the hosted factorisation has a static LDS word)
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_project_la<D, MT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_once.commit(tok);
+  }
+  const long nwg = (rows + MT * 16 - 1) / (MT * 16) + own;
+  hipLaunchKernelGGL((k_lr_project_la<D, MT, CT>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, Dm, Csub, T, rows, N_edit,
+                     NEP64, la, own);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+template <int D, int CT>
+int launch_project_la_d(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit, int NEP64,
+                        const PotrfLaJob& la, int own, hipStream_t st) {
+  // (one tile height per width keeps the instantiations of the hosted factorisation few: 7 x 16 rows tile SD-1.4's slab in 223)
+  if constexpr (D == 2048) return launch_project_la<D, 5, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, la, own, st);
+  else return launch_project_la<D, 7, CT>(W_old, Dm, Csub, T, rows, N_edit, NEP64, la, own, st);
+}
+
 template <int D, int MT, int CT>
 int launch_project(const float* W_old, const float* Dm, const float* Csub, float* T, long rows, int N_edit,
                    int NEP64, const GramPotrfJob& job, hipStream_t st) {
@@ -1016,6 +1064,23 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
   if (d == 2048)
     return wide ? launch_project_d<2048, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st)
                 : launch_project_d<2048, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, job, st);
+  return UCE_EINVAL;
+}
+
+int launch_lr_project_la(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d, int N_edit,
+                         const PotrfLaJob& la, int own, hipStream_t st) {
+  const int NEP64 = (N_edit + 63) / 64 * 64;
+  if (N_edit < 1 || N_edit > 128) return UCE_EINVAL;
+  const bool wide = NEP64 > 64;
+  if (d == 768)
+    return wide ? launch_project_la_d<768, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, la, own, st)
+                : launch_project_la_d<768, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, la, own, st);
+  if (d == 1024)
+    return wide ? launch_project_la_d<1024, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, la, own, st)
+                : launch_project_la_d<1024, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, la, own, st);
+  if (d == 2048)
+    return wide ? launch_project_la_d<2048, 2>(W_old, X, Csub, T, rows, N_edit, NEP64, la, own, st)
+                : launch_project_la_d<2048, 1>(W_old, X, Csub, T, rows, N_edit, NEP64, la, own, st);
   return UCE_EINVAL;
 }
 
