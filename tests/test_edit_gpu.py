@@ -452,6 +452,26 @@ def test_primal_edit_other_widths(H, N_e, N_p, d, rows_):
     assert O.rel_fro(out.cpu(), want) < EPS_BUILD
 
 
+@pytest.mark.parametrize("env,value,N_e,N_p", [("UCE_PROJECT_LA", "0", 100, 80), ("UCE_SPLIT_MAX_NE", "256", 200, 60),
+                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600)])
+def test_edit_forms_behind_the_switches(env, value, N_e, N_p):
+    """The forms uce_edit no longer takes by default stay correct behind their switches: the dual system's Cholesky in a
+    launch of its own in front of the projection, the two-pass project + update form for 129 ... 256 edit concepts, the
+    primal path without rider jobs."""
+    d, rows_ = 768, 2500
+    C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e)
+    rng = np.random.Generator(np.random.PCG64(N_p))
+    W = O.linear_default_weight(rows_, d, rng)
+    _, _, DTe = _exact(C, G, s, 0.5)
+    Hv = _handle_with(env, value)
+    try:
+        out = Hv.edit(_dev(C), _dev(G), _dev(s), 0.5, _dev(W), check=True).cpu()
+    finally:
+        Hv.close()
+    want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
+    assert O.rel_fro(out, want) < EPS_BUILD
+
+
 @pytest.mark.parametrize("N_e,N_p,d,rows_", [(400, 300, 768, 3000), (300, 20, 768, 700), (500, 100, 1024, 1500)])
 def test_dual_edit_beyond_256_edit_concepts(H, N_e, N_p, d, rows_):
     """N < d with more than 256 edit concepts: dual system -> Cholesky (the persistent launch, carrying the f16 split of
