@@ -403,12 +403,14 @@ def test_lowrank_project_and_update(H, Ne, d, rows_):
 @pytest.mark.parametrize("N_e,N_p,d,rows_", [(40, 10, 1024, 4096), (36, 4, 2048, 2600), (120, 30, 768, 5000),
                                              (65, 0, 768, 1024), (100, 0, 768, 24960), (100, 28, 768, 2048),
                                              (60, 30, 1024, 2048), (70, 50, 2048, 1300), (128, 64, 768, 1500),
-                                             (150, 20, 768, 1500), (180, 100, 1024, 1100)])
+                                             (150, 20, 768, 1500), (180, 100, 1024, 1100),
+                                             (100, 100, 1024, 2048), (64, 100, 2048, 1300), (20, 500, 768, 1024)])
 def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
     """uce_edit's project / solve / update path (rows >= 1024) vs torch fp64 on the GPU, run twice back to back
     (the handle's workspace and the riders' ticket word are re-used): N <= 64 and 64 < N <= 128 take the
-    Gram + Cholesky rider blocks inside the projection launch (one and three system tiles), larger N the
-    launch chain; SD-1.x / SD-2.x / SDXL widths; non-uniform scales."""
+    Gram + Cholesky rider blocks inside the projection launch (one and three system tiles), larger N (with at most 128 edit
+    concepts) the persistent Cholesky hosted in the projection launch's first workgroups; SD-1.x / SD-2.x / SDXL widths;
+    non-uniform scales."""
     N = N_e + N_p
     Call = O.clip_like_embeddings(N + 1, d, seed=N + d)
     C, G = Call[:N], np.repeat(Call[N:N + 1], N_e, axis=0)
