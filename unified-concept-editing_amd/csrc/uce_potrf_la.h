@@ -144,6 +144,37 @@ struct LaWave {
     wc8 = 16 * ((w & 1) ? (hf ? 2 : 1) : (hf ? 3 : 0));
   }
   __device__ __forceinline__ int tri_kb_end() const { return (wc8 + 16) / 4; }
+  // the Schur complement of a diagonal tile is symmetric and only its lower 16 x 16 tiles are read by the elimination
+  // (10 of 16): per SIMD 3, 3, 2, 2 tiles instead of 4 each - wave w takes a pair of row tiles of one column tile, waves
+  // 4 and 5 a single diagonal tile, waves 6 and 7 nothing.  nm = row tiles of this wave (prod_n / each_n).
+  int nm = 2;
+  __device__ __forceinline__ void use_schur_map() {
+    const int w = threadIdx.x >> 6;
+    constexpr int WR[8] = {0, 32, 32, 32, 16, 48, 0, 0}, WC[8] = {0, 0, 16, 32, 16, 48, 0, 0}, NM[8] = {2, 2, 2, 2, 1, 1, 0, 0};
+    wr = WR[w];
+    wc8 = WC[w];
+    nm = NM[w];
+  }
+  __device__ __forceinline__ void prod_n(double4_t (&a2)[2], const double (*P)[LD], const double (*Q)[LD], double sign) const {
+    if (nm == 2) prod(a2, P, Q, sign);
+    else if (nm == 1) {
+      const int r = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+      for (int kb = 0; kb < 16; ++kb) {
+        const int t = kb * 4 + kk;
+        a2[0] = mfma_f64(sign * P[wr + r][t], Q[wc8 + r][t], a2[0]);
+      }
+    }
+  }
+  template <typename F>
+  __device__ __forceinline__ void each_n(F f) const {
+    const int oc = wc8 + (lane & 15), orq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      if (m < nm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f(m, r, wr + m * 16 + orq + 4 * r, oc);
+  }
   // accumulator <-> tile (D layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 r, col = lane & 15)
   template <typename F>
   __device__ __forceinline__ void each(F f) const {
@@ -181,6 +212,8 @@ __device__ __forceinline__ void potrf_la_body(const PotrfLaJob& j, const int bid
   const LaWave lw;
   LaWave lwt;
   lwt.use_tri_map();
+  LaWave lws;
+  lws.use_schur_map();
   auto finish = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -254,10 +287,10 @@ __device__ __forceinline__ void potrf_la_body(const PotrfLaJob& j, const int bid
         la_publish_tile(A, j.Lmat + (size_t)k * 64 * n + (size_t)(k - 1) * 64, n);
         pending = fL + k * nb + (k - 1);
         double4_t sacc[2];
-        lw.each([&](int m, int r, int row, int col) { sacc[m][r] = S[row][col]; });
-        lw.prod(sacc, A, A, -1.0);                                 // Schur complement of the diagonal tile
+        lws.each_n([&](int m, int r, int row, int col) { sacc[m][r] = S[row][col]; });
+        lws.prod_n(sacc, A, A, -1.0);                              // Schur complement of the diagonal tile (its lower tiles)
         __syncthreads();
-        lw.each([&](int m, int r, int row, int col) { S[row][col] = sacc[m][r]; });
+        lws.each_n([&](int m, int r, int row, int col) { S[row][col] = sacc[m][r]; });
         __syncthreads();
       }
       LADBG(k, 3);
