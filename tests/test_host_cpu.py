@@ -208,16 +208,50 @@ def test_even_chunk_respects_cap_and_balances():
     assert even_chunk(32, 15) == 11 and even_chunk(32, 22) == 16 and even_chunk(32, 64) == 32
 
 
-def test_edit_slab_rejects_negative_scales_and_nonpositive_lambda():
-    """The solver is Cholesky-only: a negative scale / lamb <= 0 is refused with a clear error before any launch
-    (the reference's LU inverse would accept it)."""
+def test_edit_slab_routes_indefinite_systems_to_the_general_form():
+    """Negative scales / lamb <= 0 make lamb*I + C^T S C symmetric INDEFINITE: the reference's LU inverse accepts them, the
+    Cholesky path cannot.  edit_slab decides on the host from the scalars (no launch) and hands such jobs to the
+    normal-equations form; SPD jobs go to uce_edit as before."""
     from uce_amd import edit as E
+    assert E.check_spd_inputs([1.0, 0.0, 2.5], 0.5)
+    assert not E.check_spd_inputs([1.0, -0.5, 1.0], 0.5)
+    assert not E.check_spd_inputs(torch.ones(3), 0.0)
+    assert not E.check_spd_inputs(torch.ones(3), -1.0)
+
+    calls = []
+
+    class FakeHandle:
+        def edit(self, C, G, s, lamb, W, algo=0, check=False):
+            calls.append(("edit", tuple(C.shape)))
+            return W.clone()
+
+        def gram(self, C, G, s, lamb):
+            calls.append(("gram", float(s.min())))
+            d = C.shape[1]
+            return torch.eye(d, dtype=torch.float64) * 2.0, torch.zeros(d, d, dtype=torch.float64)
+
+        def solve_delta(self, A, Bt):
+            calls.append(("solve_delta", float(A[0, 0])))          # A A of the fake 2 I
+            return torch.zeros(A.shape[0], A.shape[0])
+
+        def status(self):
+            calls.append(("status",))
+
+        def apply(self, W, DT):
+            calls.append(("apply",))
+            return W.clone()
+
     slab = E.WeightSlab(["m"], [0], [4], torch.zeros(4, 64))
     C, G = torch.randn(3, 64), torch.randn(2, 64)
-    with pytest.raises(ValueError, match="scales"):
-        E.edit_slab(None, slab, C, G, torch.tensor([1.0, -0.5, 1.0]), 0.5)
-    with pytest.raises(ValueError, match="lamb"):
-        E.edit_slab(None, slab, C, G, torch.ones(3), 0.0)
+    E.edit_slab(FakeHandle(), slab, C, G, torch.tensor([1.0, 1.0, 1.0]), 0.5)
+    assert [c[0] for c in calls] == ["edit"]
+    calls.clear()
+    E.edit_slab(FakeHandle(), slab, C, G, torch.tensor([1.0, -0.5, 1.0]), 0.5)
+    assert [c[0] for c in calls] == ["gram", "solve_delta", "status", "apply"]
+    assert calls[0][1] == -0.5 and calls[1][1] == 4.0
+    calls.clear()
+    E.edit_slab(FakeHandle(), slab, C, G, torch.ones(3), 0.0)
+    assert [c[0] for c in calls] == ["gram", "solve_delta", "status", "apply"]
 
 
 def test_conv_dispatch_rule_and_padded_narrow_weights():

@@ -479,28 +479,47 @@ def drop_zero_scale_rows(C, G, s, n_edit: int):
 # the drop-in entry points
 # --------------------------------------------------------------------------------------------
 
-def check_spd_inputs(scales, lamb: float) -> None:
-    """The solver is Cholesky-only (SPD system); the reference's general LU inverse (torch.inverse, uce_sd_erase.py:82) would
-    accept negative scales / lamb <= 0.  Host-side check of the few scalars a job is built from - callers that build
-    `s` themselves run it ONCE (no device read-back per edit; the device-side pivot check reports through uce_status)."""
+def check_spd_inputs(scales, lamb: float) -> bool:
+    """True when the closed-form system lamb*I + sum_i s_i c_i c_i^T is symmetric POSITIVE DEFINITE by construction (all
+    scales >= 0, lamb > 0): the Cholesky solver's case.  Host-side look at the few scalars a job is built from - callers
+    that build `s` themselves run it ONCE (no device read-back per edit; the device-side pivot check reports through
+    uce_status).  False: negative scales / lamb <= 0, which the reference's general LU inverse (torch.inverse,
+    uce_sd_erase.py:82) accepts - edit_slab then takes the normal-equations form below."""
     vals = [float(v) for v in (scales.tolist() if isinstance(scales, torch.Tensor) else scales)]
-    if any(v < 0 for v in vals) or not (lamb > 0):
-        raise ValueError("erase/edit/preserve scales must be >= 0 and lamb > 0: the closed-form system "
-                         "lamb*I + sum_i s_i c_i c_i^T is solved by a Cholesky factorisation (SPD only)")
+    return not (any(v < 0 for v in vals) or not (lamb > 0))
+
+
+def edit_slab_general(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: torch.Tensor, s: torch.Tensor,
+                      lamb: float) -> WeightSlab:
+    """The edit for a symmetric INDEFINITE system (negative scales or lamb <= 0; reference: the same
+    `mat1 @ torch.inverse(mat2)` - its LU inverse does not care about definiteness).  A = lamb I + C^T S C is symmetric and,
+    unless singular, A A is symmetric positive definite, so  Delta^T = A^-1 Bt = (A A)^-1 (A Bt):  the f64 Gram of the
+    primal form (uce_gram), two f64 library GEMMs on the device (rocBLAS through torch), the f64 Cholesky solve on the
+    squared system (uce_solve_delta: a singular A shows up as a non-positive pivot) and the dense apply.  The condition
+    number is squared, in f64: relative error ~1e-16 cond(A)^2 - below the fp32 LU of the reference (~6e-8 cond(A)) for
+    cond(A) < 6e8."""
+    A, Bt = handle.gram(C, G, s, lamb)
+    A2 = A @ A
+    A2 = 0.5 * (A2 + A2.T)                                  # the factorisation reads the lower triangle; keep it the symmetric part
+    DT = handle.solve_delta(A2.contiguous(), (A @ Bt).contiguous())
+    handle.status()
+    return slab.like(handle.apply(slab.data, DT))
 
 
 def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[torch.Tensor], s: torch.Tensor,
-              lamb: float, algo: int = _lib.ALGO_AUTO, validated: bool = False) -> WeightSlab:
+              lamb: float, algo: int = _lib.ALGO_AUTO, validated: bool = False, spd: bool = True) -> WeightSlab:
+    """`validated`: the caller has run check_spd_inputs / drop_zero_scale_rows itself and passes `spd`."""
     n_edit = 0 if G is None else G.shape[0]
     if not validated:
-        check_spd_inputs(s, lamb)
-    if not validated:                                  # (validated callers have already dropped zero-scale rows)
+        spd = check_spd_inputs(s, lamb)
         C, G, s, n_edit = drop_zero_scale_rows(C, G, s, n_edit)
     if C.shape[0] == 0 or n_edit == 0:
         # nothing pulls the weights anywhere: W_new = W_old exactly (Delta = 0)
         return slab.like(slab.data.clone())
     if G is not None and G.shape[0] == 0:
         G = None
+    if not spd:
+        return edit_slab_general(handle, slab, C, G, s, lamb)
     out = handle.edit(C, G, s, lamb, slab.data, algo=algo, check=True)
     return slab.like(out)
 
@@ -544,7 +563,7 @@ class DebiasState:
         self.C = torch.cat([C_edit] + ([C_pres] if n_p else [])).contiguous()
         self.s = torch.tensor([float(edit_scale)] * n_e + [float(preserve_scale)] * n_p, dtype=torch.float32,
                               device=handle.device)
-        check_spd_inputs([edit_scale, preserve_scale], lamb)     # once: the per-iteration edits skip the read-back of `s`
+        self.spd = check_spd_inputs([edit_scale, preserve_scale], lamb)   # once: the per-iteration edits skip the read-back of `s`
         self.Dsum = torch.zeros(n_e, C_debias.shape[0], dtype=torch.float64, device=handle.device)
         self.current = slab.like(slab.data.clone())
 
@@ -553,5 +572,5 @@ class DebiasState:
         if self.no_edit:
             return self.current
         G = self.handle.debias_targets(self.C_edit, self.C_debias, self.Dsum)
-        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb, self.algo, validated=True)
+        self.current = edit_slab(self.handle, self.slab, self.C, G, self.s, self.lamb, self.algo, validated=True, spd=self.spd)
         return self.current
