@@ -81,9 +81,9 @@ int uce_solve_rhs(uce_handle_t h, double* A, const double* B, int d, int m, floa
  *   W_new [rows,d] = W_old + W_old Delta ; rows = sum of the modules' out_features (the host
  *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  Products carry fp32 accuracy: each row of W_old
  *   and of (I + Delta)^T is scaled by a power of two and split exactly into two f16 terms, the three significant
- *   partial products run on the f16 matrix cores with fp32 accumulation, the scales leave in the epilogue (error
- *   <= one fp32 rounding per product for elements within 2^16 of their row's maximum, <= 2^-29 of that maximum
- *   below).  UCE_APPLY_VARIANT (read at uce_create) = 1: the three-way bf16 split, six products, no scales - also
+ *   partial products run on the f16 matrix cores with fp32 accumulation, the scales leave in the epilogue (each
+ *   operand carries 22 significand bits - 2^-22 relative - for elements within 2^16 of their row's maximum, <= 2^-29
+ *   of that maximum below; 3.2e-7 rel. Frobenius against fp64 on the SD-1.4 slab; bf16 split 4.3e-7, f32-MFMA kernel 6.8e-7).  UCE_APPLY_VARIANT (read at uce_create) = 1: the three-way bf16 split, six products, no scales - also
  *   what a slab beyond 2 GB of planes takes; 0: the f32-MFMA kernel whose products are bit-exact fmaf chains.
  *   Uses the handle's row workspace (uce_reserve_rows(h, rows, d + 64) pre-sizes it). */
 int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d,

@@ -254,6 +254,45 @@ def test_edit_slab_routes_indefinite_systems_to_the_general_form():
     assert [c[0] for c in calls] == ["gram", "solve_delta", "status", "apply"]
 
 
+def test_two_way_f16_split_model_carries_fp32_products():
+    """The arithmetic of the dense apply (csrc/uce_apply_h2.hip, uce_h2split.h), restated in numpy: a row scaled by a power
+    of two into [2^14, 2^15) splits into two f16 terms - 11 + 11 significand bits - with a residual of <= 2^-22 of the element
+    (fp32 keeps 24 bits: 2^-24) for elements within 2^16 of the row maximum, and the three products x_l y_h + x_h y_l + x_h y_h under the exact scales
+    reproduce the fp64 product of a weight matrix with I + Delta to fp32 level - also with rows 2^40 apart and a zero row."""
+    rng = np.random.Generator(np.random.PCG64(11))
+
+    def split(X):
+        mx = np.abs(X).max(axis=1)
+        E = np.clip((mx.astype(np.float32).view(np.uint32) >> 23).astype(np.int64), 30, 240)
+        s = np.ldexp(1.0, 141 - E)[:, None]                         # row maximum -> [2^14, 2^15)
+        y = (X.astype(np.float64) * s).astype(np.float32)           # exact: a power of two
+        h = y.astype(np.float16)
+        lo = (y - h.astype(np.float32)).astype(np.float16)          # the subtraction is exact in fp32
+        return h.astype(np.float64), lo.astype(np.float64), 1.0 / s, y.astype(np.float64)
+
+    rows, d = 96, 256
+    W = (rng.uniform(-1, 1, (rows, d)) / 16).astype(np.float32)
+    W *= np.ldexp(1.0, rng.integers(-20, 21, size=(rows, 1))).astype(np.float32)
+    W[5] = 0.0
+    h, lo, inv, y = split(W)
+    big = np.abs(y) >= np.abs(y).max(axis=1, keepdims=True) * 2.0 ** -16
+    resid = np.abs(h + lo - y)
+    assert np.all(resid[big] <= np.abs(y[big]) * 2.0 ** -22)         # 22 significand bits
+    assert np.all(resid <= np.maximum(np.abs(y) * 2.0 ** -22, 2.0 ** -25))   # below: the f16 denormal grid
+    assert np.all(np.abs(h).max(axis=1) <= 2.0 ** 15)                # far inside f16's range (65504)
+
+    DT = (rng.standard_normal((d, d)) * (0.5 / np.sqrt(d))).astype(np.float32)
+    B = DT + np.eye(d, dtype=np.float32)                             # rows of (I + Delta)^T
+    bh, bl, binv, _ = split(B)
+    acc = lo @ bh.T + h @ bl.T + h @ bh.T                            # the MFMAs accumulate exact products
+    out = acc * inv * binv.T
+    want = W.astype(np.float64) @ B.astype(np.float64).T
+    rown = np.linalg.norm(want, axis=1)
+    ok = rown > 0
+    assert float((np.linalg.norm(out - want, axis=1)[ok] / rown[ok]).max()) < 3e-7
+    assert np.all(out[5] == 0.0)
+
+
 def test_conv_dispatch_rule_and_padded_narrow_weights():
     """Host logic of the convolution dispatch: which layers go to the implicit-GEMM kernels (measured rule), and the
     zero-padded copy of a narrow-output weight (VAE conv_out) follows in-place updates of the parameters."""

@@ -2,11 +2,12 @@
 // (reference: `mat1 @ torch.inverse(mat2)` per module, uce_sd_erase.py:82 - here one launch for all modules).
 //
 // An fp32 value scaled by a power of two into [2^14, 2^15) splits EXACTLY into two f16 values,
-//     x s = x_h + x_l,   x_h = rn_f16(x s)  (11 significand bits),  x_l = rn_f16(x s - x_h)  (the next 11; the
-//     subtraction is exact in fp32 and leaves <= 13 bits, so x_l is within 2^-24 |x s|: one fp32 rounding),
+//     x s = x_h + x_l + e,   x_h = rn_f16(x s)  (11 significand bits),  x_l = rn_f16(x s - x_h)  (the next 11; the
+//     subtraction is exact in fp32 and leaves <= 13 bits),  |e| <= 2^-22 |x s|: 22 of fp32's 24 significand bits,
 // and a product x y is taken as   x_l y_h + x_h y_l + x_h y_h   (small terms first): every partial product of two f16
 // values is exact inside the MFMA (22-bit significand, fp32 accumulation), the dropped term x_l y_l is below 2^-22
-// relative.  THREE f16 MFMAs per fp32-equivalent product - half of the six the three-way bf16 split (uce_apply_b3.hip)
+// relative.  Against fp64 the whole apply measures 3.2e-7 rel. Frobenius on the SD-1.4 slab (bf16 x 3: 4.3e-7, the f32-MFMA
+// kernel: 6.8e-7 - fp32 accumulation over 768 terms dominates either way).  THREE f16 MFMAs per fp32-equivalent product - half of the six the three-way bf16 split (uce_apply_b3.hip)
 // needs for the same accuracy.  What the bf16 form gets for free and this one has to provide is RANGE: f16 spans
 // 2^-14 .. 2^15, so every row of W_old and every row of (I + Delta)^T gets its own power-of-two scale (the row maximum
 // goes to [2^14, 2^15); elements more than 2^16 below their row's maximum have a denormal x_l: an absolute error of
