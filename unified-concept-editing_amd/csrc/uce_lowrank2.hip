@@ -56,13 +56,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pj_rsrc(const float* base, lon
 template <int D, int MT, int NMT, int CT = 2>
 __device__ __forceinline__ void project_body_w(const float* __restrict__ W_old, const float* __restrict__ Dm,
                                                const float* __restrict__ Csub, float* __restrict__ T,
-                                               long rows, int Ne, int NEP, float* Wc, int mbase, int blk_off) {
+                                               long rows, int Ne, int NEP, float* Wc, int mbase, int blk_off,
+                                               int c4_of_wave = -1, bool active = true, int zero_from = 4) {
   constexpr int d = D;
   constexpr int SR = MT * 16;
   constexpr int NCB = 64 * CT;                        // concepts per batch
   float* Dc = Wc + 2 * SR * PJ_LD;                    // [2][NCB][PJ_LD]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int c4 = w & 3;
+  const int c4 = c4_of_wave >= 0 ? c4_of_wave : (w & 3);   // column tile of this wave (of the 4 CT a batch holds)
   const int li = lane & 15, lk = lane >> 4;
   const long R0 = (long)(blockIdx.x - blk_off) * SR;
 
@@ -192,7 +193,11 @@ __device__ __forceinline__ void project_body_w(const float* __restrict__ W_old, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const long gr = R0 + (mbase + m) * 16 + 4 * lk + r;
-            if (gr < rows) T[gr * NEP + bt * NCB + (c * 4 + c4) * 16 + li] = acc[c][m][r];
+            if (active && gr < rows) {
+              T[gr * NEP + bt * NCB + (c * 4 + c4) * 16 + li] = acc[c][m][r];
+              if (c4 == 0)                                           // column tiles nobody computes (remapped waves): the padding stays zero
+                for (int dc = zero_from; dc < 4; ++dc) T[gr * NEP + bt * NCB + dc * 16 + li] = 0.f;
+            }
           }
       }
     }
@@ -740,6 +745,50 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   DBG(5);
 }
 
+
+// Which 16-column tile and which row tiles of the workgroup's MT x 4 (x CT) tile grid a wave takes.  The standing map gives
+// wave w column tile w & 3 and one half of the row tiles, so a SIMD (waves w, w + 4) carries MT tiles whatever N_e is - with
+// 36 edit concepts (the SDXL debias slab) a quarter of them multiply zero padding, with 2 (BASELINE config 1) three
+// quarters.  For CT = 1 and fewer than four LIVE column tiles (N_e <= 48) the waves share the live tiles instead: one live
+// tile - a row tile per wave; two - four waves per column tile; three - 3 + 3 + 2 waves, paired on the SIMDs so that none
+// carries more than ceil(3 MT / 4) + 1.  Every wave still takes part in the staging and the barriers; a wave without a
+// tile of its own repeats tile 0 and does not store; the waves of column tile 0 write the zeros of the tiles nobody computes
+// (T's padding columns stay zero as before).
+template <int D, int MT, int CT>
+__device__ __forceinline__ void project_dispatch(const float* __restrict__ W_old, const float* __restrict__ Dm,
+                                                 const float* __restrict__ Csub, float* __restrict__ T, long rows, int Ne,
+                                                 int NEP, float* Wc, int blk_off) {
+  constexpr int M0 = (MT + 1) / 2;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int live = (Ne + 15) >> 4;
+  if (CT > 1 || live >= 4) {
+    if (w < 4) project_body_w<D, MT, M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, blk_off);
+    else project_body_w<D, MT, MT - M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, blk_off);
+    return;
+  }
+  if constexpr (CT == 1) {
+    int c4, part, parts;                      // this wave: column tile, its index among the `parts` waves of that tile
+    if (live == 1) { c4 = 0; part = w; parts = 8; }
+    else if (live == 2) { c4 = w & 1; part = w >> 1; parts = 4; }
+    else {                                    // column tiles 0, 1: waves {0, 3, 6}, {1, 4, 7}; column tile 2: waves {2, 5}
+      c4 = w < 6 ? w % 3 : w - 6;
+      part = w < 6 ? w / 3 : 2;
+      parts = c4 == 2 ? 2 : 3;
+    }
+    const int base = MT / parts, extra = MT % parts;             // row tiles [m0, m0 + nm)
+    int nm = base + (part < extra ? 1 : 0);
+    int m0 = part * base + (part < extra ? part : extra);
+    const bool active = nm > 0;
+    if (!active) { nm = 1; m0 = 0; }
+    switch (nm) {
+      case 1: project_body_w<D, MT, 1, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, m0, blk_off, c4, active, live); break;
+      case 2: project_body_w<D, MT, 2, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, m0, blk_off, c4, active, live); break;
+      case 3: project_body_w<D, MT, 3, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, m0, blk_off, c4, active, live); break;
+      default: project_body_w<D, MT, 4, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, m0, blk_off, c4, active, live); break;
+    }
+  }
+}
+
 constexpr size_t GP_SMEM1 = (size_t)4 * 64 * GP_LD * sizeof(float) + 64 * GP_TLD * sizeof(double) + 16;   // one system tile
 __host__ __device__ constexpr size_t gp_smem(int nb) {
   const size_t g = nb <= 1 ? GP_SMEM1 : (GP_SMEM1 > GP_F2_SMEM ? GP_SMEM1 : GP_F2_SMEM);
@@ -766,13 +815,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   DBG(0);
   float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD]
-  constexpr int M0 = (MT + 1) / 2;
-  {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
-      project_body_w<D, MT, M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, has_rider);
-    else
-      project_body_w<D, MT, MT - M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, has_rider);
-  }
+  project_dispatch<D, MT, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, has_rider);
   DBG(1);
 }
 
@@ -930,11 +973,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     return;
   }
   float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD]
-  constexpr int M0 = (MT + 1) / 2;
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256)
-    project_body_w<D, MT, M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, 0, n_la);
-  else
-    project_body_w<D, MT, MT - M0, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, M0, n_la);
+  project_dispatch<D, MT, CT>(W_old, Dm, Csub, T, rows, Ne, NEP, Wc, n_la);
 }
 
 template <int D, int MT, int CT>
