@@ -293,6 +293,40 @@ def test_two_way_f16_split_model_carries_fp32_products():
     assert np.all(out[5] == 0.0)
 
 
+def test_projection_live_tile_wave_map_covers_every_tile_once():
+    """csrc/uce_lowrank2.hip:project_dispatch restated: with 1 / 2 / 3 live 16-concept tiles the eight waves of a projection
+    workgroup share the live tiles - every (column tile, row tile) pair belongs to exactly one storing wave, no wave takes
+    more than four row tiles (the largest instantiation), and no SIMD (waves w, w + 4) carries more than the standing
+    map's MT tiles."""
+    def wave_map(w, live, MT):
+        if live == 1:
+            c4, part, parts = 0, w, 8
+        elif live == 2:
+            c4, part, parts = w & 1, w >> 1, 4
+        else:
+            c4 = w % 3 if w < 6 else w - 6
+            part = w // 3 if w < 6 else 2
+            parts = 2 if c4 == 2 else 3
+        base, extra = MT // parts, MT % parts
+        nm = base + (1 if part < extra else 0)
+        m0 = part * base + min(part, extra)
+        return c4, m0, nm
+
+    for MT in (5, 6, 7, 8):
+        for live in (1, 2, 3):
+            owner = {}
+            per_simd = [0, 0, 0, 0]
+            for w in range(8):
+                c4, m0, nm = wave_map(w, live, MT)
+                assert 0 <= c4 < live and 0 <= nm <= 4
+                per_simd[w & 3] += nm
+                for m in range(m0, m0 + nm):
+                    assert (c4, m) not in owner, (MT, live, w, c4, m)
+                    owner[(c4, m)] = w
+            assert set(owner) == {(c, m) for c in range(live) for m in range(MT)}
+            assert max(per_simd) <= MT and max(per_simd) <= -(-live * MT // 4) + 1, (MT, live, per_simd)
+
+
 def test_conv_dispatch_rule_and_padded_narrow_weights():
     """Host logic of the convolution dispatch: which layers go to the implicit-GEMM kernels (measured rule), and the
     zero-padded copy of a narrow-output weight (VAE conv_out) follows in-place updates of the parameters."""
