@@ -248,6 +248,97 @@ def uce_debias_ref(
     return out
 
 
+def uce_debias_ref_keyed(
+    weights: Sequence[torch.Tensor],
+    embeds: Dict[str, torch.Tensor],
+    edit: Sequence[str],
+    debias: Sequence[str],
+    preserve: Sequence[str],
+    direction_scales: Sequence[np.ndarray],
+    edit_scale: float,
+    preserve_scale: float,
+    lamb: float,
+    dtype: torch.dtype = torch.float32,
+) -> List[torch.Tensor]:
+    """uce_sd_debias.py:68-140 with the reference's STRING-KEYED caches: `uce_guide_outputs` holds ONE tensor per unique
+    string and per module (:69-88), and :124-126 adds the drift to it IN PLACE.  So a string listed twice among the edit
+    concepts drifts twice per iteration (the second visit starts from what the first left), a string that is both an edit
+    and a preserve concept preserves the DRIFTED output (:132), and a debias concept that is also an edit concept is itself
+    rescaled / shifted and then used as the direction of the later edit concepts.  `embeds`: {string: [1, d]}."""
+    weights = [w.to(dtype) for w in weights]
+    v: Dict[str, List[torch.Tensor]] = {}
+    for g in list(edit) + list(debias) + list(preserve):          # :69-88
+        if g in v:
+            continue
+        v[g] = [torch.nn.functional.linear(embeds[g].to(dtype), w) for w in weights]
+    out = [w.clone() for w in weights]
+    for direction_scale in direction_scales:
+        if np.abs(direction_scale).max() == 0:                      # :110-112
+            break
+        for m, w_old in enumerate(weights):
+            d = w_old.shape[1]
+            mat1 = lamb * w_old
+            mat2 = lamb * torch.eye(d, dtype=dtype)
+            for idx, e in enumerate(edit):                          # :120-130
+                c_i = embeds[e].to(dtype).T
+                v_i_star = v[e][m]
+                for i, concept in enumerate(debias):
+                    v_i_star += direction_scale[idx][i] * v[concept][m]   # in place on the cached tensor, :126
+                v_i_star = v_i_star.T
+                mat1 += edit_scale * (v_i_star @ c_i.T)
+                mat2 += edit_scale * (c_i @ c_i.T)
+            for p in preserve:                                      # :133-138
+                c_i = embeds[p].to(dtype).T
+                v_i_star = v[p][m].T
+                mat1 += preserve_scale * (v_i_star @ c_i.T)
+                mat2 += preserve_scale * (c_i @ c_i.T)
+            out[m] = mat1 @ torch.inverse(mat2.float()).to(dtype)
+    return out
+
+
+def debias_keyed_targets(embeds: Dict[str, torch.Tensor], edit: Sequence[str], debias: Sequence[str],
+                         preserve: Sequence[str], direction_scales: Sequence[np.ndarray]
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Closed form of the keyed loop above.  Every cached guide output is W g_x for an EFFECTIVE embedding g_x that does
+    not depend on the module (the in-place updates are linear combinations with scalar coefficients), so the loop is a
+    recursion on g_x in embedding space, float64.  Returns (G_edit [N_e, d], G_pres [N_p, d]) of the LAST executed
+    iteration: the target each row of that iteration's sums was given."""
+    g = {}
+    for x in list(edit) + list(debias) + list(preserve):
+        if x not in g:
+            g[x] = embeds[x].double().reshape(-1).clone()
+    G_e = torch.stack([g[e] for e in edit]) if len(edit) else torch.zeros(0, 0, dtype=torch.float64)
+    G_p = torch.stack([g[p] for p in preserve]) if len(preserve) else torch.zeros(0, G_e.shape[1] if len(edit) else 0,
+                                                                                 dtype=torch.float64)
+    for ds in direction_scales:
+        if np.abs(ds).max() == 0:
+            break
+        rows_e = []
+        for idx, e in enumerate(edit):
+            for i, concept in enumerate(debias):
+                g[e] += float(ds[idx][i]) * g[concept]          # the right-hand side is evaluated first, like torch's
+            rows_e.append(g[e].clone())
+        G_e = torch.stack(rows_e)
+        if len(preserve):
+            G_p = torch.stack([g[p].clone() for p in preserve])
+    return G_e, G_p
+
+
+def uce_exact64_rows(weights: Sequence[torch.Tensor], C: torch.Tensor, G: torch.Tensor, s: torch.Tensor,
+                     lamb: float) -> List[torch.Tensor]:
+    """W_new = (lamb W + sum_i s_i (W g_i) c_i^T)(lamb I + sum_i s_i c_i c_i^T)^-1 for arbitrary rows (c_i, g_i, s_i),
+    float64 (uce_sd_debias.py:114-140 with the targets given)."""
+    C, G, s = C.double(), G.double(), s.double()
+    d = C.shape[1]
+    A = lamb * torch.eye(d, dtype=torch.float64) + C.T @ (s[:, None] * C)
+    out = []
+    for w in weights:
+        w = w.double()
+        mat1 = lamb * w + (w @ G.T) @ (s[:, None] * C)
+        out.append(torch.linalg.solve(A, mat1.T).T)
+    return out
+
+
 def debias_targets(edit: torch.Tensor, debias: torch.Tensor,
                    direction_scales: Sequence[np.ndarray]) -> torch.Tensor:
     """Closed form of the cumulative drift: after t iterations the target of edit concept e

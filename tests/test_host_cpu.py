@@ -9,7 +9,7 @@ import torch
 
 from oracle import uce_oracle as O
 from tests import fakepipe
-from tests.golden_io import Case
+from tests.golden_io import Case, DEBIAS_ALIAS_CASES, DEBIAS_CASES, keyed_embeds
 from uce_amd import REPO_ROOT
 from uce_amd import edit as E
 
@@ -76,6 +76,43 @@ def test_drop_zero_scale_rows():
     s = torch.tensor([0.0, 1.0, 0.0, 2.0])
     C2, G2, s2, ne = E.drop_zero_scale_rows(C, G, s, 2)
     assert ne == 1 and C2.shape[0] == 2 and torch.equal(G2, G[1:2]) and s2.tolist() == [1.0, 2.0]
+
+
+def test_debias_alias_predicate():
+    assert not E.debias_keys_alias(["Doctor", "Nurse"], ["male", "female"], ["Monet"])
+    assert not E.debias_keys_alias(["Doctor"], ["male", "female"], ["male", "Monet", "Monet"])   # only EDIT concepts are written
+    assert E.debias_keys_alias(["Doctor", "Nurse", "Doctor"], ["male", "female"], [])
+    assert E.debias_keys_alias(["Doctor", "Nurse"], ["male", "female"], ["Nurse"])
+    assert E.debias_keys_alias(["male", "Doctor"], ["male", "female"], [])
+
+
+@pytest.mark.parametrize("name", DEBIAS_ALIAS_CASES + DEBIAS_CASES)
+def test_debias_alias_step_follows_the_keyed_oracle(name):
+    """The product's host recursion on coefficient rows (edit.debias_alias_step, what DebiasState runs when the lists alias)
+    against the oracle's recursion on the embeddings themselves, iteration by iteration."""
+    c = Case(name)
+    m = c.meta
+    keys = (m["edit"], m["debias"], m["preserve"])
+    emb = keyed_embeds(c)
+    uniq = []
+    for k in keys[0] + keys[1] + keys[2]:
+        if k not in uniq:
+            uniq.append(k)
+    Cu = torch.cat([emb[k] for k in uniq]).double()
+    coef = {k: np.eye(len(uniq))[i] for i, k in enumerate(uniq)}
+    ds = [x for x in c.arr("direction_scales") if np.abs(x).max() != 0]
+    for t, D in enumerate(ds):
+        Dm, moved_pres, pure = E.debias_alias_step(keys, uniq, coef, D)
+        assert sorted(moved_pres + pure) == list(range(len(keys[2])))
+        first = torch.cat([c.t("C_edit")] + [c.t("C_pres")[j:j + 1] for j in moved_pres]).double()
+        G = first + torch.from_numpy(Dm) @ Cu
+        G_e, G_p = O.debias_keyed_targets(emb, *keys, ds[:t + 1])
+        want = torch.cat([G_e] + [G_p[j:j + 1] for j in moved_pres])
+        assert float((G - want).abs().max()) < 1e-12 * float(want.abs().max())
+        for j in pure:
+            assert torch.equal(G_p[j], c.t("C_pres")[j].double())
+    if name in DEBIAS_CASES:
+        assert not E.debias_keys_alias(*keys) and moved_pres == []
 
 
 @pytest.mark.parametrize("name", ["cli_erase_art_expand", "cli_erase_object_default", "cli_erase_object_expand_guided"])

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from oracle import uce_oracle as O
-from tests.golden_io import Case, ERASE_CASES, DEBIAS_CASES, SDPA_CASES, rows
+from tests.golden_io import Case, ERASE_CASES, DEBIAS_CASES, DEBIAS_ALIAS_CASES, SDPA_CASES, rows, keyed_embeds
 
 
 @pytest.mark.parametrize("name", ERASE_CASES)
@@ -54,6 +54,43 @@ def test_debias_collapses_to_cumulative_drift(name):
     for g, ex, ref in zip(got, c.w_exact64(), c.w_ref32()):
         assert O.rel_fro(g, ex) < 1e-12
         assert O.rel_fro(ref, ex) < 5e-3
+
+
+@pytest.mark.parametrize("name", DEBIAS_CASES + DEBIAS_ALIAS_CASES)
+def test_debias_keyed_oracle_matches_reference(name):
+    """The string-keyed restatement (one cached, in-place-drifted guide output per unique string) against the reference's
+    own output - on the aliased lists (duplicate edit concept / edit+preserve / edit+debias) and on the plain ones."""
+    c = Case(name)
+    m = c.meta
+    ds = [x for x in c.arr("direction_scales")]
+    got = O.uce_debias_ref_keyed(c.w_old(), keyed_embeds(c), m["edit"], m["debias"], m["preserve"], ds,
+                                 m["edit_scale"], m["preserve_scale"], m["lamb"])
+    for g, ref in zip(got, c.w_ref32()):
+        assert O.rel_fro(g, ref) < 2e-6
+
+
+@pytest.mark.parametrize("name", DEBIAS_ALIAS_CASES)
+def test_debias_keyed_closed_form(name):
+    """The aliased loop collapses to a recursion on effective embeddings: targets from debias_keyed_targets + the general
+    closed form reproduce the fixture's fp64 arbiter, and the reference sits at its usual fp32 distance from it.  The
+    independent-rows closed form (debias_targets) does NOT describe these lists."""
+    c = Case(name)
+    m = c.meta
+    ds = [x for x in c.arr("direction_scales")]
+    emb = keyed_embeds(c)
+    G_e, G_p = O.debias_keyed_targets(emb, m["edit"], m["debias"], m["preserve"], ds)
+    has_p = len(m["preserve"]) > 0
+    C = torch.cat([c.t("C_edit")] + ([c.t("C_pres")] if has_p else []))
+    G = torch.cat([G_e] + ([G_p] if has_p else []))
+    s = torch.tensor([m["edit_scale"]] * len(m["edit"]) + [m["preserve_scale"]] * len(m["preserve"]))
+    got = O.uce_exact64_rows(c.w_old(), C, G, s, m["lamb"])
+    naive = O.uce_edit_exact64(c.w_old(), rows(c.arr("C_edit")),
+                               [g[None] for g in O.debias_targets(c.t("C_edit"), c.t("C_debias"), ds)],
+                               rows(c.arr("C_pres")), m["edit_scale"], m["preserve_scale"], m["lamb"])
+    for g, nv, ex, ref in zip(got, naive, c.w_exact64(), c.w_ref32()):
+        assert O.rel_fro(g, ex) < 1e-12
+        assert O.rel_fro(ref, ex) < 5e-4
+        assert O.rel_fro(nv, ex) > 1e-3          # the quirk is visible: ignoring the aliasing misses the reference
 
 
 def test_collapse_to_module_independent_M():

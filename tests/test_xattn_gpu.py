@@ -33,6 +33,36 @@ def test_xattn_golden(H, name):
     assert O.rel_fro(o.double(), c.t("o_f32")) < max(1.5 * err_ref, 4e-3)
 
 
+@pytest.mark.parametrize("name", SDPA_CASES)
+def test_xattn_golden_at_the_generation_batch(H, name):
+    """The torch-SDPA fixtures at the shape the generation loop launches (B = 32 = 16 prompts x CFG, full Lq), where
+    uce_xattn_fwd takes the 640-byte column-group kernel k_xattn_g by default (dh = 40 / 80) - the fixture's 2 x 64 query
+    rows are repeated over the batch and along Lq (query rows and samples are independent), and EVERY replica has to
+    reproduce torch's output for the original rows."""
+    c = Case(name)
+    m = c.meta
+    q, k, v = (c.t(x).view(torch.bfloat16) for x in ("q", "k", "v"))
+    B0, lq, C = q.shape
+    Lq = {"sdpa_Lq4096_dh40": 4096, "sdpa_Lq1024_dh80": 1024, "sdpa_Lq256_dh160": 256, "sdpa_Lq64_dh160": 64}[name]
+    rb, rl = 32 // B0, Lq // lq
+    Q = q.repeat(rb, rl, 1).cuda()
+    K, V = k.repeat(rb, 1, 1).cuda(), v.repeat(rb, 1, 1).cuda()
+    o = H.xattn(Q, K, V, m["H"])
+    blocks = o.view(rb, B0, rl, lq, C).double()                 # [batch replica, sample, Lq replica, row, channel]
+    ref32 = c.t("o_f32").double().cuda()[None, :, None]
+    ref64 = O.xattn_ref(q, k, v, m["H"]).cuda()[None, :, None]
+    sdpa_bf16 = c.t("o_bf16").view(torch.bfloat16).double()
+    err_ref = O.rel_fro(sdpa_bf16, c.t("o_f32"))
+    # per replica: norm over (sample, row, channel)
+    def rel(x, y):
+        num = (x - y).pow(2).sum(dim=(1, 3, 4)).sqrt()
+        return float((num / y.pow(2).sum(dim=(1, 3, 4)).sqrt()).max())
+    assert rel(blocks, ref64) < TOL_BF16
+    assert rel(blocks, ref32) < max(1.5 * err_ref, 4e-3)
+    # replicas of the same rows are the same bits (no dependence on the tile position / workgroup)
+    assert bool((o.view(rb, B0, rl, lq, C) == o.view(rb, B0, rl, lq, C)[:1, :, :1]).all())
+
+
 @pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
     (2, 8, 4096, 77, 40, torch.bfloat16),     # SD-1.4 full shapes (SURVEY 8a row a10)
     (2, 8, 1024, 77, 80, torch.bfloat16),

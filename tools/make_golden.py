@@ -282,12 +282,24 @@ def run_debias_case(deb_mod, case: str, out_dir: str, d: int, edit: List[str], d
                     lamb, tmp, case, 0.05, 0.1, 10, 20, 7.5)
         state = _load_state(os.path.join(tmp, case + ".safetensors"))
     C_edit, C_deb, C_pres = _emb_rows(pipe, edit), _emb_rows(pipe, debias), _emb_rows(pipe, preserve)
-    G = uce_oracle.debias_targets(torch.from_numpy(C_edit), torch.from_numpy(C_deb), scripted)
-    te = [torch.from_numpy(r[None]) for r in C_edit]
-    tg = [g[None] for g in G]
-    tp = [torch.from_numpy(r[None]) for r in C_pres]
     ws = [w for _, w in w_old]
-    exact = uce_oracle.uce_edit_exact64(ws, te, tg, tp, edit_scale, preserve_scale, lamb)
+    if len(set(edit)) == len(edit) and not (set(edit) & (set(debias) | set(preserve))):
+        G = uce_oracle.debias_targets(torch.from_numpy(C_edit), torch.from_numpy(C_deb), scripted)
+        te = [torch.from_numpy(r[None]) for r in C_edit]
+        tg = [g[None] for g in G]
+        tp = [torch.from_numpy(r[None]) for r in C_pres]
+        exact = uce_oracle.uce_edit_exact64(ws, te, tg, tp, edit_scale, preserve_scale, lamb)
+    else:
+        # a string cached once and drifted in place (uce_sd_debias.py:122-127): the keyed closed form is the arbiter
+        embeds = {}
+        for names, rows_ in ((edit, C_edit), (debias, C_deb), (preserve, C_pres)):
+            for n, r in zip(names, rows_):
+                embeds[n] = torch.from_numpy(r[None])
+        G_e, G_p = uce_oracle.debias_keyed_targets(embeds, edit, debias, preserve, scripted)
+        Call = torch.from_numpy(np.concatenate([C_edit, C_pres]) if len(C_pres) else C_edit)
+        Gall = torch.cat([G_e, G_p]) if len(C_pres) else G_e
+        sall = torch.tensor([edit_scale] * len(edit) + [preserve_scale] * len(preserve))
+        exact = uce_oracle.uce_exact64_rows(ws, Call, Gall, sall, lamb)
     arrays = dict(
         meta=np.array(json.dumps(dict(
             kind="debias", d=d, lamb=lamb, edit_scale=edit_scale, preserve_scale=preserve_scale,
@@ -453,6 +465,17 @@ def main() -> None:
         run_debias_case(deb_mod, "debias_n4x2_d768", args.out, 768,
                         ["Doctor", "Nurse", "Carpenter", "Teacher"], ["male", "female"], ["Monet"],
                         scripted, 1.0, 1.0, 0.5, seed=12)
+    # the string-keyed caches of the reference (uce_sd_debias.py:69-88) drifted in place (:122-127):
+    # (1) an edit concept listed twice, (2) a string that is both an edit and a preserve concept, (3) debias concepts
+    # that are edit concepts themselves (their cached output is rescaled, then used as the others' direction)
+    for case, ed, db, pr, sd in (
+            ("debias_alias_dupedit_d768", ["Doctor", "Nurse", "Doctor"], ["male", "female"], ["Monet"], 31),
+            ("debias_alias_editpres_d768", ["Doctor", "Nurse"], ["male", "female"], ["Nurse", "Monet"], 32),
+            ("debias_alias_editisdebias_d768", ["male", "Doctor", "female"], ["male", "female"], [], 33)):
+        if want(case):
+            rs = np.random.Generator(np.random.PCG64(sd))
+            scripted = [np.round(rs.uniform(-0.5, 0.5, size=(len(ed), len(db))), 1) for _ in range(3)]
+            run_debias_case(deb_mod, case, args.out, 768, ed, db, pr, scripted, 1.0, 0.8, 0.5, seed=sd + 100)
     # BASELINE config 4: SDXL-shaped, 36 professions x 2, 3 scripted iterations
     if want("debias_n36x2_d2048"):
         import pandas as pd

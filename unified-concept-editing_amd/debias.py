@@ -109,7 +109,8 @@ def UCE(pipe, classify, edit_concepts, debias_concepts, preserve_concepts, edit_
     C_edit = torch.stack([embeds[e] for e in edit_concepts]).contiguous()
     C_deb = torch.stack([embeds[c] for c in debias_concepts]).contiguous()
     C_pres = torch.stack([embeds[p] for p in preserve_concepts]).contiguous() if preserve_concepts else None
-    state = E.DebiasState(handle, slab, C_edit, C_deb, C_pres, edit_scale, preserve_scale, lamb, algo=algo)
+    state = E.DebiasState(handle, slab, C_edit, C_deb, C_pres, edit_scale, preserve_scale, lamb, algo=algo,
+                          keys=(list(edit_concepts), list(debias_concepts), list(preserve_concepts)))
     if hasattr(pipe, "to"):
         pipe = pipe.to(torch.bfloat16)                         # :90
     start_time = time.time()

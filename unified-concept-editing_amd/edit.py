@@ -545,18 +545,79 @@ def UCE(pipe, edit_concepts, guide_concepts, preserve_concepts, erase_scale, pre
     return (new, path) if return_slab else None
 
 
+def debias_keys_alias(edit_keys: Sequence, debias_keys: Sequence, preserve_keys: Sequence) -> bool:
+    """True when the reference's string-keyed cache (uce_sd_debias.py:69-88) makes two rows share ONE drifting tensor: an
+    edit concept listed twice, or an edit concept that is also a debias or a preserve concept (:122-127 mutate the cached
+    guide output of the EDIT concept in place; debias-only and preserve-only strings are never written)."""
+    e = list(edit_keys)
+    return len(set(e)) != len(e) or bool(set(e) & (set(debias_keys) | set(preserve_keys)))
+
+
+def debias_alias_step(keys, uniq: Sequence, coef: Dict, D: np.ndarray):
+    """One iteration of uce_sd_debias.py:120-133 on the coefficients of the cached guide outputs (`coef[k]`: float64 row over
+    `uniq`, updated IN PLACE like the reference's tensors; g_k = coef[k] @ C_uniq).  Returns
+      Dm         [n_e + len(moved_pres), len(uniq)]  target minus the row's own embedding, as coefficients
+      moved_pres preserve rows whose cached output has drifted (they are edit rows of this iteration's system)
+      pure       preserve rows still equal to their own embedding."""
+    ek, dk, pk = keys
+    pos = {k: i for i, k in enumerate(uniq)}
+    moved, own = [], []
+    for idx, e in enumerate(ek):                                 # :120-127, in list order; right-hand side first
+        for i, concept in enumerate(dk):
+            coef[e] = coef[e] + float(D[idx][i]) * coef[concept]
+        moved.append(coef[e].copy())
+        own.append(pos[e])
+    moved_pres, pure = [], []
+    for j, p_ in enumerate(pk):                                  # :132-133: the cached output as it is NOW
+        c = coef[p_]
+        if np.count_nonzero(c) == 1 and c[pos[p_]] == 1.0:
+            pure.append(j)
+        else:
+            moved.append(c.copy())
+            own.append(pos[p_])
+            moved_pres.append(j)
+    Dm = np.stack(moved)
+    Dm[np.arange(len(own)), own] -= 1.0                          # uce_debias_targets adds the row's own embedding
+    return Dm, moved_pres, pure
+
+
 class DebiasState:
     """Iteration state of the debias loop (uce_sd_debias.py:95-141) in closed form: the drift
     the reference adds in place to its cached guide outputs accumulates, and every iteration
-    re-solves from W_old, so the weights after iteration t depend only on sum_{t'<=t} D_t'."""
+    re-solves from W_old, so the weights after iteration t depend only on sum_{t'<=t} D_t'.
+
+    `keys` = (edit, debias, preserve) string lists.  The reference caches ONE guide output per unique string, so when the
+    lists alias (debias_keys_alias) the drift of one row is seen by another: the state then follows the reference's update
+    order on the COEFFICIENTS of every cached output over the unique embeddings (the outputs are W g_x with g_x a linear
+    combination of embeddings - module independent), a few scalars on the host per iteration, and hands the targets to
+    the same device path (uce_debias_targets + uce_edit)."""
 
     def __init__(self, handle: UceHandle, slab: WeightSlab, C_edit: torch.Tensor, C_debias: torch.Tensor,
                  C_pres: Optional[torch.Tensor], edit_scale: float, preserve_scale: float, lamb: float,
-                 algo: int = _lib.ALGO_AUTO):
+                 algo: int = _lib.ALGO_AUTO, keys: Optional[Tuple[Sequence, Sequence, Sequence]] = None):
         self.handle, self.slab, self.lamb, self.algo = handle, slab, lamb, algo
         self.C_edit, self.C_debias = C_edit, C_debias
         n_e = C_edit.shape[0]
         n_p = 0 if C_pres is None else C_pres.shape[0]
+        self.current = slab.like(slab.data.clone())
+        self.aliased = keys is not None and debias_keys_alias(*keys)
+        if self.aliased:
+            ek, dk, pk = (list(k) for k in keys)
+            if (len(ek), len(dk), len(pk)) != (n_e, C_debias.shape[0], n_p):
+                raise ValueError("debias keys do not match the embedding rows")
+            self.keys = (ek, dk, pk)
+            uniq: List = []
+            rows = []
+            for k, r in zip(ek + dk + pk, list(C_edit) + list(C_debias) + (list(C_pres) if n_p else [])):
+                if k not in uniq:
+                    uniq.append(k)
+                    rows.append(r)
+            self.uniq = uniq
+            self.C_uniq = torch.stack(rows).contiguous()
+            self.coef = {k: np.eye(len(uniq), dtype=np.float64)[i] for i, k in enumerate(uniq)}   # g_k = coef[k] @ C_uniq
+            self.C_pres = C_pres
+            self.scales = (float(edit_scale), float(preserve_scale))
+            return
         if float(preserve_scale) == 0.0:                         # zero-scale rows contribute nothing: dropped here, once
             n_p = 0
         self.no_edit = float(edit_scale) == 0.0                  # nothing pulls the weights anywhere
@@ -565,9 +626,22 @@ class DebiasState:
                               device=handle.device)
         self.spd = check_spd_inputs([edit_scale, preserve_scale], lamb)   # once: the per-iteration edits skip the read-back of `s`
         self.Dsum = torch.zeros(n_e, C_debias.shape[0], dtype=torch.float64, device=handle.device)
-        self.current = slab.like(slab.data.clone())
+
+    def _step_aliased(self, D: np.ndarray) -> WeightSlab:
+        Dm, moved_pres, pure = debias_alias_step(self.keys, self.uniq, self.coef, D)
+        n_e = len(self.keys[0])
+        Cf = torch.cat([self.C_edit] + [self.C_pres[j:j + 1] for j in moved_pres]).contiguous()
+        G = self.handle.debias_targets(Cf, self.C_uniq, torch.as_tensor(Dm, device=self.handle.device))
+        C = torch.cat([Cf] + [self.C_pres[j:j + 1] for j in pure]).contiguous()
+        s = torch.tensor([self.scales[0]] * n_e + [self.scales[1]] * (len(moved_pres) + len(pure)), dtype=torch.float32,
+                         device=self.handle.device)
+        # rows with scale 0 still drift (above) but contribute nothing: edit_slab drops them
+        self.current = edit_slab(self.handle, self.slab, C, G, s, self.lamb, self.algo)
+        return self.current
 
     def step(self, direction_scale: np.ndarray) -> WeightSlab:
+        if self.aliased:
+            return self._step_aliased(np.asarray(direction_scale, dtype=np.float64))
         self.Dsum += torch.as_tensor(np.asarray(direction_scale, dtype=np.float64), device=self.handle.device)
         if self.no_edit:
             return self.current
