@@ -562,7 +562,6 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
     MFMA peak (the loop is VALU-bound on the online softmax, not MFMA-bound)."""
     import torch.nn.functional as F
     from uce_amd import edit as E
-    from uce_amd.sd import unet as sd_unet
     H = E.UceHandle.get(device)
     traffic = load_traffic().get("sattn", {})
     out = []
@@ -578,8 +577,7 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
         if with_torch:
             sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)  # noqa: E731
             ent["torch_sdpa_us"] = round(time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), iters) * 1e3, 1)
-        # what the U-Net launches at this shape (sd/unet.py: measured rule) - the kernel above or torch's SDPA
-        ent["unet_dispatch"] = "uce_sattn_fwd" if sd_unet.sattn_prefers_hip(L) else "torch_sdpa"
+        ent["unet_dispatch"] = "uce_sattn_packed_fwd"      # every attn1 layer, whatever its length (sd/unet.py: no library attention)
         t = traffic.get(f"B{B}_L{L}_dh{dh}")
         if isinstance(t, dict):
             ent["traffic"] = t.get("total_bytes")

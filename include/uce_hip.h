@@ -168,6 +168,12 @@ int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, v
 int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H,
                   int Lq, int Lk, int dh, float scale, int dtype, uce_stream_t stream);
 
+/* The same self-attention reading q, k and v from ONE packed projection qkv [B, L, 3 * H * dh] (columns [0, C) = q, [C, 2C) = k,
+ * [2C, 3C) = v with C = H * dh): what the fused to_q | to_k | to_v linear of an attn1 layer writes (uce_linear_fwd on the three
+ * weights concatenated along their rows) - the three [B, L, C] tensors never exist.  o [B, L, C]. */
+int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, float scale, int dtype,
+                         uce_stream_t stream);
+
 /* SURVEY section 8(f) row 3 - GroupNorm (+ SiLU) of the U-Net / VAE at inference (diffusers ResnetBlock2D:
  * conv(silu(group_norm(x)))) for channels-last activations:  x, y [N, HW, C] (an NCHW tensor in
  * torch.channels_last memory format), gamma, beta [C], all bf16 or f16; G <= 64 groups of C/G consecutive
@@ -175,8 +181,10 @@ int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, v
  * caller-owned scratch. */
 int uce_groupnorm_chunks(int HW);
 int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, const void* gamma, const void* beta, void* y,
-                           float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype, uce_stream_t stream);
-/* `addend` (may be NULL): [N, C], same dtype; x + addend[n][c] is what gets normalised - the time-embedding add of
+                           float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype, long addend_ld,
+                           uce_stream_t stream);
+/* `addend` (may be NULL): [N, C] with row stride addend_ld elements (0: C; a multiple of 8 - a column slice of the U-Net's one
+ * hoisted time-projection GEMM), same dtype; x + addend[n][c] is what gets normalised - the time-embedding add of
  * ResnetBlock2D and the bias of the convolution that produced x, folded into the normalisation.
  * uce_add_bias_nhwc_fwd: y = a + b + bias[c] over [pixels, C] (b and bias may be NULL): the residual joins. */
 int uce_add_bias_nhwc_fwd(uce_handle_t h, const void* a, const void* b, const void* bias, void* y, long pixels, int C,
@@ -210,12 +218,33 @@ int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* residual, const
 int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
                        uce_stream_t stream);
 
-/* The same convolution as ONE implicit-GEMM kernel (csrc/uce_conv_igemm.hip): the nine taps are gathered on the way
- * into LDS, no patch matrix exists.  x [N, H, W, Cin] (or [N, H/2, W/2, Cin] with upsample = 1), w [Cout, 3, 3, Cin] (a
- * channels-last Conv2d weight), bias [Cout] or NULL, y [N, H, W, Cout]; bf16 or f16, f32 accumulation; Cin % 64 == 0,
- * Cout % 8 == 0. */
+/* Patch matrix of a 3x3 / pad 1 convolution with FOUR input channels (conv_in on the latents, U-Net and VAE decoder):
+ * x [N, H, W, 4] -> cols [N*H*W, 64] (16-bit elements): column (ky*3 + kx)*4 + c, columns 36..63 zero - the convolution is then
+ * uce_linear_fwd against the weight laid out the same way ([Cout, 64]). */
+int uce_im2col3x3_c4(uce_handle_t h, const void* x, void* cols, int N, int H, int W, uce_stream_t stream);
+
+/* The same convolution as ONE implicit-GEMM kernel (csrc/uce_conv_dma.hip, uce_conv_igemm.hip): the nine taps are gathered on the
+ * way into LDS, no patch matrix exists.  x [N, H, W, Cin] (with upsample = 1: [N, H/2, W/2, Cin], the convolution of its 2x
+ * nearest-neighbour upsampling; with stride = 2: [N, 2H, 2W, Cin], diffusers' Downsample2D), w [Cout, 3, 3, Cin] (a channels-last
+ * Conv2d weight), bias [Cout] or NULL, residual [N, H, W, Cout] or NULL (added in the epilogue: the `x + conv2(h) + b` join of
+ * ResnetBlock2D), y [N, H, W, Cout]; bf16 or f16, f32 accumulation; Cin % 32 == 0, Cout % 8 == 0.  stride = 2 and residual need
+ * Cout % 128 == 0 (UCE_ENOSYS otherwise). */
 int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const void* bias, void* y, int N, int H, int W,
-                         int Cin, int Cout, int upsample, int dtype, uce_stream_t stream);
+                         int Cin, int Cout, int upsample, int stride, const void* residual, int dtype, uce_stream_t stream);
+
+/* Linear layer with a fused epilogue (csrc/uce_gemm.hip) - every nn.Linear / 1x1 convolution under `pipe(...)` of
+ * evalscripts/generate-images-sd.py:37-42 (diffusers Attention.to_q/to_k/to_v/to_out, FeedForward, Transformer2DModel.proj_in /
+ * proj_out, ResnetBlock2D.conv_shortcut; the reference gets them from torch's GEMM library plus separate element-wise passes):
+ *   UCE_EPILOGUE_NONE :  y [M, N]   = x [M, K] w [N, K]^T (+ bias [N]) (+ residual [M, N])
+ *   UCE_EPILOGUE_GEGLU:  y [M, N/2] = (hidden + b_h) * gelu(gate + b_g), erf form (diffusers GEGLU); w / bias hold the hidden
+ *                        and gate rows INTERLEAVED per 32: row 32 t + r = hidden row 16 t + r (r < 16), gate row 16 t + r - 16
+ *                        (r >= 16); no residual.
+ * bf16 or f16 elements, f32 accumulation; ldx / ldr / ldy = row strides in elements (operands may be column slices of wider
+ * tensors).  K % 32 == 0, N % 4 == 0 (GEGLU: N % 32 == 0), ldx % 8 == 0, ldy % 4 == 0, ldr % 4 == 0; x, w 16-byte aligned, the
+ * others 8-byte aligned; bias / residual may be NULL. */
+enum { UCE_EPILOGUE_NONE = 0, UCE_EPILOGUE_GEGLU = 1 };
+int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr,
+                   void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream);
 
 /* e - the one exchange step of the multi-GPU generation path (broadcast of the edited weights from rank 0 over RCCL / xGMI;
  * generate-images-sd.py:17-19 loads the artifact on every process - here rank 0 loads it and the others receive it).

@@ -36,11 +36,19 @@ STEPS = 50
 PROBE_STEPS = (0, 1, 12, 25, 38, 50)          # U-Net calls whose input / output the fp32 run records
 
 
+class _Hip:
+    """_set_hip(False): every hand-written kernel off (tests/torch_twin.py patches the product's dispatch predicate)."""
+    ctx = None
+
+
 def _set_hip(on: bool):
-    from uce_amd.sd import unet as U
-    for name in ("USE_HIP_GROUPNORM", "USE_HIP_LAYERNORM", "USE_HIP_CONV3X3", "USE_HIP_SELF_ATTENTION",
-                 "USE_HIP_CROSS_ATTENTION"):
-        setattr(U, name, on)
+    from tests.torch_twin import torch_ops
+    if _Hip.ctx is not None:
+        _Hip.ctx.__exit__(None, None, None)
+        _Hip.ctx = None
+    if not on:
+        _Hip.ctx = torch_ops()
+        _Hip.ctx.__enter__()
 
 
 def _guided_eps(pipe, latents, t, ctx, scale=7.5):

@@ -1,0 +1,236 @@
+"""GPU parity of the linear-layer kernel with fused epilogues (uce_linear_fwd, csrc/uce_gemm.hip) through the C ABI, against
+fp64 evaluations of the same expressions: every tile form, bias / residual / GEGLU epilogues, strided operands, ragged
+shapes; and the U-Net pieces that ride on it (packed q|k|v attention, the hoisted time projections, conv_in)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import uce_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.bfloat16: 4e-3, torch.float16: 6e-4}      # one rounding of the output (2^-9 / 2^-12 relative per element)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from uce_amd import edit as E
+    return E.UceHandle.get("cuda:0")
+
+
+def _handle_with(env_name, value):
+    from uce_amd import edit as E
+    old = os.environ.get(env_name)
+    os.environ[env_name] = value
+    try:
+        return E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ[env_name]
+        else:
+            os.environ[env_name] = old
+
+
+def _rand(shape, g, dtype, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+@pytest.mark.parametrize("M,N,K,dtype,bias,res", [
+    (4096, 320, 320, torch.bfloat16, True, False),        # to_out at 64 x 64 (B = 1)
+    (1000, 640, 640, torch.bfloat16, False, True),        # ragged M, residual
+    (8192, 1280, 1280, torch.bfloat16, True, True),       # 128-row tiles (few 256-row tiles)
+    (333, 768, 768, torch.float16, True, True),           # 256-wide tiles (text-encoder widths), ragged M
+    (77, 1280, 768, torch.bfloat16, False, False),        # to_k on a context
+    (32, 1280, 320, torch.bfloat16, True, False),         # the time embedding
+    (2048, 512, 512, torch.bfloat16, True, True),         # the VAE attention's projections
+    (515, 128, 256, torch.bfloat16, True, False),         # 128-wide tiles
+    (300, 36, 64, torch.bfloat16, True, False),           # a ragged last column tile (N not a multiple of any tile)
+    (70000, 320, 64, torch.bfloat16, True, False),        # many row tiles, two k-tiles (conv_in's GEMM)
+])
+def test_linear_matches_fp64(H, M, N, K, dtype, bias, res):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _rand((M, K), g, dtype)
+    w = _rand((N, K), g, dtype, K ** -0.5)
+    w[0, 1] += 2.0                                        # asymmetric: a transposed operand cannot pass
+    b = _rand((N,), g, dtype) if bias else None
+    r = _rand((M, N), g, dtype) if res else None
+    y = H.linear(x, w, b, r)
+    want = x.double() @ w.double().T
+    if bias:
+        want = want + b.double()
+    if res:
+        want = want + r.double()
+    assert y.shape == (M, N) and y.dtype == dtype
+    assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[dtype]
+    assert torch.equal(y, H.linear(x, w, b, r))           # bit-repeatable
+
+
+@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128"])
+@pytest.mark.parametrize("M,N,K", [(700, 960, 320), (256, 640, 96)])
+def test_linear_every_tile_form_forced(tile, M, N, K):
+    """UCE_GEMM_TILE pins one tile form for every call (read at uce_create): each form on shapes with ragged row and column
+    tiles, with bias + residual."""
+    Hv = _handle_with("UCE_GEMM_TILE", tile)
+    g = torch.Generator().manual_seed(int(tile) + M)
+    x, w = _rand((M, K), g, torch.bfloat16), _rand((N, K), g, torch.bfloat16, K ** -0.5)
+    b, r = _rand((N,), g, torch.bfloat16), _rand((M, N), g, torch.bfloat16)
+    try:
+        y = Hv.linear(x, w, b, r)
+        torch.cuda.synchronize()
+    finally:
+        Hv.close()
+    want = x.double() @ w.double().T + b.double() + r.double()
+    assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("M,C,dtype", [(4096, 320, torch.bfloat16), (1000, 640, torch.bfloat16), (300, 1280, torch.float16),
+                                       (77, 64, torch.bfloat16)])
+def test_linear_geglu_epilogue(H, M, C, dtype):
+    """diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate) - formed on the accumulators from the interleaved
+    weight rows (sd.unet.geglu_interleave), against the fp64 expression on the ORIGINAL weight."""
+    from uce_amd.sd import unet as U
+    inner = 4 * C
+    g = torch.Generator().manual_seed(M + C)
+    x = _rand((M, C), g, dtype)
+    w = _rand((2 * inner, C), g, dtype, C ** -0.5)
+    b = _rand((2 * inner,), g, dtype)
+    wi, bi = U.geglu_interleave(w, b)
+    y = H.linear(x, wi, bi, geglu=True)
+    p = x.double() @ w.double().T + b.double()
+    want = p[:, :inner] * F.gelu(p[:, inner:])
+    assert y.shape == (M, inner)
+    assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[dtype]
+    # and without a bias
+    y0 = H.linear(x, wi, None, geglu=True)
+    p0 = x.double() @ w.double().T
+    assert O.rel_fro(y0.double().cpu(), (p0[:, :inner] * F.gelu(p0[:, inner:])).cpu()) < TOL[dtype]
+
+
+def test_linear_strided_operands(H):
+    """x, residual and out as column slices of wider tensors (row strides != widths): what the packed projections use."""
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 900, 320, 640
+    big_x = _rand((M, 3 * K), g, torch.bfloat16)
+    big_r = _rand((M, 2 * N), g, torch.bfloat16)
+    big_y = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device="cuda:0")
+    w, b = _rand((N, K), g, torch.bfloat16, K ** -0.5), _rand((N,), g, torch.bfloat16)
+    x, r, out = big_x[:, K:2 * K], big_r[:, N:], big_y[:, N:2 * N]
+    H.linear(x, w, b, r, out=out)
+    want = x.double() @ w.double().T + b.double() + r.double()
+    assert O.rel_fro(out.double().cpu(), want.cpu()) < TOL[torch.bfloat16]
+    assert float(big_y[:, :N].abs().max()) == 0.0 and float(big_y[:, 2 * N:].abs().max()) == 0.0   # neighbours untouched
+
+
+def test_linear_rejects_bad_arguments(H):
+    from uce_amd import lib as L
+    x = torch.zeros(8, 40, dtype=torch.bfloat16, device="cuda:0")          # K = 40 is not a multiple of 32
+    w = torch.zeros(64, 40, dtype=torch.bfloat16, device="cuda:0")
+    with pytest.raises(L.UceError):
+        H.linear(x, w)
+    x = torch.zeros(8, 64, dtype=torch.bfloat16, device="cuda:0")
+    w = torch.zeros(30, 64, dtype=torch.bfloat16, device="cuda:0")         # N = 30 is not a multiple of 4
+    with pytest.raises(L.UceError):
+        H.linear(x, w)
+    w = torch.zeros(48, 64, dtype=torch.bfloat16, device="cuda:0")         # GEGLU needs whole 32-row groups
+    with pytest.raises(L.UceError):
+        H.linear(x, w, geglu=True)
+
+
+# ------------------------------------------------------------------------------------ what rides on it in the U-Net
+
+@pytest.mark.parametrize("B,heads,L,dh,dtype", [(2, 8, 4096, 40, torch.bfloat16), (2, 8, 1024, 80, torch.bfloat16),
+                                                (3, 8, 256, 160, torch.bfloat16), (2, 8, 64, 160, torch.bfloat16),
+                                                (1, 5, 100, 64, torch.float16), (2, 2, 77, 16, torch.bfloat16)])
+def test_packed_self_attention(H, B, heads, L, dh, dtype):
+    """uce_sattn_packed_fwd on qkv [B, L, 3C] == uce_sattn_fwd on the three slices made contiguous, and both == fp64."""
+    C = heads * dh
+    g = torch.Generator().manual_seed(L + dh)
+    qkv = _rand((B, L, 3 * C), g, dtype)
+    q, k, v = (qkv[..., i * C:(i + 1) * C].contiguous() for i in range(3))
+    o = H.sattn_packed(qkv, heads)
+    assert torch.equal(o, H.sattn(q, k, v, heads))
+    sp = lambda t: t.double().view(B, L, heads, dh).transpose(1, 2)
+    ref = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * dh ** -0.5, dim=-1) @ sp(v)).transpose(1, 2).reshape(B, L, C)
+    assert O.rel_fro(o.double().cpu(), ref.cpu()) < (8e-3 if dtype == torch.bfloat16 else 1.5e-3)
+
+
+@pytest.mark.parametrize("vti", ["1", "2"])
+@pytest.mark.parametrize("B,heads,Lq,Lk,dh,dtype", [(2, 8, 1024, 1024, 40, torch.bfloat16), (1, 8, 300, 130, 40, torch.bfloat16),
+                                                    (2, 8, 512, 200, 80, torch.bfloat16), (1, 4, 200, 130, 128, torch.float16),
+                                                    (2, 8, 256, 256, 160, torch.bfloat16), (1, 7, 70, 191, 56, torch.bfloat16),
+                                                    (3, 2, 33, 1, 40, torch.bfloat16)])
+def test_self_attention_with_and_without_the_vt_prepass(vti, B, heads, Lq, Lk, dh, dtype):
+    """UCE_SATTN_VTI = 1: V^T transposed on the way into LDS at every length; 2: always the k_vt pre-pass (the by-rule default
+    switches at 1024 keys): both forms on ragged shapes, a head dim whose row of ones falls inside the padded tile (dh = 56),
+    and a single key."""
+    Hv = _handle_with("UCE_SATTN_VTI", vti)
+    C = heads * dh
+    g = torch.Generator().manual_seed(Lq + Lk + dh)
+    q, k, v = _rand((B, Lq, C), g, dtype), _rand((B, Lk, C), g, dtype), _rand((B, Lk, C), g, dtype)
+    try:
+        o = Hv.sattn(q, k, v, heads)
+        again = Hv.sattn(q, k, v, heads)
+        torch.cuda.synchronize()
+    finally:
+        Hv.close()
+    sp = lambda t, n: t.double().view(B, n, heads, dh).transpose(1, 2)
+    ref = (torch.softmax(sp(q, Lq) @ sp(k, Lk).transpose(-1, -2) * dh ** -0.5, dim=-1) @ sp(v, Lk)).transpose(1, 2).reshape(B, Lq, C)
+    assert torch.isfinite(o.float()).all()
+    assert O.rel_fro(o.double().cpu(), ref.cpu()) < (8e-3 if dtype == torch.bfloat16 else 1.5e-3)
+    assert torch.equal(o, again)
+    if Lk == 1:
+        assert torch.equal(o, v.expand(B, Lq, C))
+
+
+def test_transformer_block_matches_its_torch_twin():
+    """BasicTransformerBlock on the GPU (packed q|k|v + uce_sattn_packed_fwd, residual joins in the projections' epilogues,
+    GEGLU on the accumulators, uce_xattn_fwd) against the same weights through torch ops (tests/torch_twin.py)."""
+    from tests.torch_twin import torch_ops
+    from uce_amd.sd import unet as U
+    for C, heads, L in ((320, 8, 1024), (640, 8, 256), (1280, 8, 64)):
+        torch.manual_seed(C)
+        blk = U.BasicTransformerBlock(C, heads, C // heads, 768).to("cuda", torch.bfloat16)
+        g = torch.Generator().manual_seed(1)
+        x = _rand((2, L, C), g, torch.bfloat16)
+        ctx = _rand((2, 77, 768), g, torch.bfloat16)
+        a = blk(x, ctx).float()
+        with torch_ops():
+            b = blk(x, ctx).float()
+        ref = blk.float()(x.float(), ctx.float())
+        blk.to(torch.bfloat16)
+        ea, eb = O.rel_fro(a.cpu(), ref.cpu()), O.rel_fro(b.cpu(), ref.cpu())
+        assert ea < 1.5 * eb + 2e-3, (C, ea, eb)          # no further from fp32 than torch's own bf16 ops
+
+
+def test_unet_forward_matches_its_torch_twin_and_hoists_time_projections():
+    """The tiny U-Net on the GPU against the same weights through torch ops; the 22 time projections are ONE launch."""
+    from tests.torch_twin import torch_ops
+    from uce_amd import edit as E
+    from uce_amd.sd import pipeline as sdp
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.bfloat16, "cuda:0", synthetic=True, vae=False, seed=3)
+    g = torch.Generator().manual_seed(0)
+    x = _rand((2, 4, 8, 8), g, torch.bfloat16)
+    ctx = _rand((2, 77, 64), g, torch.bfloat16)
+    t = torch.tensor([500], device="cuda")
+    seen = []
+    orig = E.UceHandle.linear
+
+    def counted(self, x_, w, *a, **k):
+        seen.append((tuple(x_.shape), tuple(w.shape)))
+        return orig(self, x_, w, *a, **k)
+
+    E.UceHandle.linear = counted
+    try:
+        a = pipe.unet(x, t, ctx).float()
+    finally:
+        E.UceHandle.linear = orig
+    n_res = sum(1 for m in pipe.unet.modules() if m.__class__.__name__ == "ResnetBlock2D")
+    temb_dim = pipe.unet.cfg.block_out_channels[0] * 4
+    hoisted = [s for s in seen if s[0] == (2, temb_dim) and s[1][1] == temb_dim and s[1][0] > temb_dim]
+    assert n_res == 22 and len(hoisted) == 1                     # one stacked projection, not 22
+    assert any(s[1][1] == 64 and s[0][-1] == 64 and len(s[0]) == 2 and s[0][0] == 2 * 8 * 8 for s in seen)   # conv_in's GEMM
+    with torch_ops():
+        b = pipe.unet(x, t, ctx).float()
+    assert O.rel_fro(a.cpu(), b.cpu()) < 3e-2

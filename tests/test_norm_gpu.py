@@ -79,11 +79,9 @@ def test_unet_uses_the_kernel_and_matches_torch_groupnorm():
     finally:
         E.UceHandle.groupnorm_nhwc = orig
     assert calls["n"] == 61                     # 22 resnets x 2 + 16 transformer norms + conv_norm_out
-    U.USE_HIP_GROUPNORM = False
-    try:
+    from tests.torch_twin import torch_ops
+    with torch_ops("_hip_nhwc_ok"):
         b = pipe.unet(x, t, ctx).float()
-    finally:
-        U.USE_HIP_GROUPNORM = True
     assert O.rel_fro(a.cpu(), b.cpu()) < 3e-2
 
 
@@ -260,11 +258,9 @@ def test_transformer_block_with_hip_layernorm_matches_torch_ops():
     x = torch.randn(2, 256, 320, generator=g).bfloat16().cuda()
     ctx = torch.randn(2, 77, 768, generator=g).bfloat16().cuda()
     a = blk(x, ctx).float()
-    U.USE_HIP_LAYERNORM = False
-    try:
+    from tests.torch_twin import torch_ops
+    with torch_ops("_hip_ln_ok"):
         b = blk(x, ctx).float()
-    finally:
-        U.USE_HIP_LAYERNORM = True
     assert O.rel_fro(a.cpu(), b.cpu()) < 1e-2
 
 
@@ -296,3 +292,92 @@ def test_upsample_conv_matches_interpolate_then_conv(H):
     ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), up.conv.weight.float(), up.conv.bias.float(), padding=1)
     assert y.shape == (3, 64, 16, 16) and y.is_contiguous(memory_format=torch.channels_last)
     assert O.rel_fro(y.float().cpu(), ref.cpu()) < 6e-3
+
+
+# ------------------------------------------------------------------------------------ round 4: strides, residuals, tiles
+
+def test_groupnorm_addend_as_a_column_slice(H):
+    """The addend read in place from a wider tensor (row stride != C): a block's slice of the hoisted time projections."""
+    g = torch.Generator().manual_seed(4)
+    N, C, Hh = 3, 320, 16
+    x = torch.randn(N, C, Hh, Hh, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    wide = torch.randn(N, 3 * C + 64, generator=g).bfloat16().cuda()
+    w, b = torch.randn(C, generator=g).bfloat16().cuda(), torch.randn(C, generator=g).bfloat16().cuda()
+    ad = wide[:, 64 + C:64 + 2 * C]
+    assert not ad.is_contiguous()
+    y = H.groupnorm_nhwc(x, w, b, 32, 1e-5, True, ad)
+    assert torch.equal(y, H.groupnorm_nhwc(x, w, b, 32, 1e-5, True, ad.contiguous()))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,dtype,res", [
+    (2, 320, 320, 64, 64, torch.bfloat16, False),        # Downsample2D of down_blocks.0
+    (3, 640, 640, 32, 32, torch.bfloat16, False),
+    (2, 1280, 1280, 16, 16, torch.bfloat16, False),
+    (1, 64, 128, 10, 6, torch.float16, True),            # small ragged image, stride 2 + residual
+])
+def test_conv3x3_stride2_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, res):
+    """diffusers' Downsample2D (3x3, stride 2, pad 1) on the direct-to-LDS kernel."""
+    g = torch.Generator().manual_seed(Cin + Hh)
+    x = torch.randn(N, Cin, Hh, Ww, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, generator=g).to(dtype).cuda()
+    r = torch.randn(N, Cout, Hh // 2, Ww // 2, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last) if res else None
+    y = H.conv3x3_nhwc(x, w, b, stride=2, residual=r)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    if res:
+        ref = ref + r.double()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "128256", "256128", "128128"])
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(2, 64, 1280, 12, 10), (3, 96, 256, 16, 16)])
+def test_conv3x3_every_tile_form_with_residual(tile, N, Cin, Cout, Hh, Ww):
+    """UCE_CONV_TILE pins the tile of the direct-to-LDS convolution: every form (where it divides Cout), with bias and the
+    residual epilogue, ragged pixel tiles."""
+    import os
+    from uce_amd import edit as E
+    if tile != "0" and Cout % (int(tile) % 1000):
+        pytest.skip("tile width does not divide Cout")
+    old = os.environ.get("UCE_CONV_TILE")
+    os.environ["UCE_CONV_TILE"] = tile
+    try:
+        Hv = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_CONV_TILE"]
+        else:
+            os.environ["UCE_CONV_TILE"] = old
+    g = torch.Generator().manual_seed(Cin + Cout + int(tile))
+    x = torch.randn(N, Cin, Hh, Ww, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, generator=g).bfloat16().cuda()
+    r = torch.randn(N, Cout, Hh, Ww, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    try:
+        y = Hv.conv3x3_igemm(x, w, b, residual=r)
+        torch.cuda.synchronize()
+    finally:
+        Hv.close()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + r.double()
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("N,Cout,Hh,Ww,dtype", [(2, 320, 64, 64, torch.bfloat16), (3, 512, 9, 7, torch.float16), (1, 32, 8, 8, torch.bfloat16)])
+def test_conv_in_on_four_channels(H, N, Cout, Hh, Ww, dtype):
+    """conv_in on the latents: uce_im2col3x3_c4 (bit-exact patch matrix) + uce_linear_fwd, through the module dispatch."""
+    from uce_amd import lib as L
+    from uce_amd.sd import unet as U
+    g = torch.Generator().manual_seed(Cout + Hh)
+    conv = torch.nn.Conv2d(4, Cout, 3, padding=1).to("cuda", dtype)
+    x = torch.randn(N, 4, Hh, Ww, generator=g).to(dtype).cuda()
+    cols = torch.full((N * Hh * Ww, 64), 7.0, dtype=dtype, device="cuda:0")
+    xs = x.permute(0, 2, 3, 1).contiguous()
+    L.check(H.lib.uce_im2col3x3_c4(H._h, xs.data_ptr(), cols.data_ptr(), N, Hh, Ww, torch.cuda.current_stream().cuda_stream),
+            "uce_im2col3x3_c4")
+    xp = F.pad(xs, (0, 0, 1, 1, 1, 1))
+    want = torch.cat([xp[:, ky:ky + Hh, kx:kx + Ww, :] for ky in range(3) for kx in range(3)], dim=-1)
+    assert torch.equal(cols.view(N, Hh, Ww, 64)[..., :36], want) and float(cols[:, 36:].abs().max()) == 0.0
+    y = U.conv2d(conv, x)
+    ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    assert y.shape == ref.shape
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)

@@ -22,7 +22,8 @@ PUBLIC_HEADER = os.path.normpath(os.path.join(PKG, "..", "include", "uce_hip.h")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950 reads/writes them there directly).  Left to
 # its heuristics the compiler parks them in AGPRs and pays a v_accvgpr_read/write pair around every VALU
 # touch of an accumulator - 128 extra moves per key tile in the attention kernels' softmax.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS = list(BASE_FLAGS)
 if os.environ.get("UCE_CHAIN_DEBUG"):          # phase stamps of the rider chain (tools/dbg_chain.py); never in the product build
     FLAGS.append("-DUCE_CHAIN_DEBUG")
 FLAGS += os.environ.get("UCE_DEFINES", "").split()            # experiment switches (-DNAME=VALUE ...), empty in the product build
@@ -30,8 +31,7 @@ FLAGS += os.environ.get("UCE_DEFINES", "").split()            # experiment switc
 # Objects are only as fresh as the FLAGS they were compiled with: every flag set gets its own object directory, and a
 # build with debug / experiment flags links its own library file - the product libuce_hip.so is only ever made of
 # product objects (an mtime check alone would re-link a stale -DUCE_CHAIN_DEBUG object into it).
-_EXTRA = [f for f in FLAGS if f.startswith("-D")]
-VARIANT = "" if not _EXTRA else hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:10]
+VARIANT = "" if FLAGS == BASE_FLAGS else hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:10]   # ANY difference (-D, -O1, -g, -mllvm ...)
 OBJ_DIR = os.path.join(LIB_DIR, "obj", VARIANT or "product")
 LIB_PATH = os.path.join(LIB_DIR, "libuce_hip.so" if not VARIANT else f"libuce_hip.{VARIANT}.so")
 
@@ -74,6 +74,9 @@ def source_hash() -> str:
 
 def needs_build() -> bool:
     """True when the library is missing or older than ANY csrc/*.hip, csrc/*.h or the public header."""
+    flags_file = os.path.join(OBJ_DIR, ".flags")
+    if not os.path.exists(flags_file) or open(flags_file).read() != " ".join(FLAGS):
+        return True                            # the objects this library was linked from were compiled with other flags
     return _stale(LIB_PATH, sources() + headers())
 
 

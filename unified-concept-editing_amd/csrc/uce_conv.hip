@@ -13,6 +13,7 @@
 namespace {
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 
 // One workgroup per image row (n, y): thread j owns patch-row unit(s) j, j + 256, ... (unit = 16 bytes; tap t = j / C8,
 // channel octet c = j % C8, computed once) and walks the row's pixels - no per-element index divisions, stores
@@ -68,6 +69,34 @@ __global__ __launch_bounds__(256) void k_im2col3x3_flat(const uint4_t* __restric
   }
 }
 
+
+// Patch matrix of a 3x3 / pad 1 convolution with FOUR input channels (the U-Net's and the VAE decoder's conv_in on the latents):
+// x [N, H, W, 4] -> cols [N*H*W, 64], column (ky*3 + kx)*4 + c for the 36 real entries, zeros behind them (the GEMM kernel's
+// k-tile is 32 elements).  One thread per pixel: nine 8-byte loads, eight 16-byte stores (one whole 128-byte row).
+__global__ __launch_bounds__(256) void k_im2col3x3_c4(const uint2_t* __restrict__ x, uint4_t* __restrict__ cols, long M, int H,
+                                                      int W) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= M) return;
+  const int xw = (int)(p % W);
+  const long q = p / W;
+  const int y = (int)(q % H);
+  const long n = q / H;
+  unsigned d[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) d[i] = 0u;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = xw + t % 3 - 1;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const uint2_t v = x[(n * H + yy) * W + xx];
+      d[2 * t] = v[0];
+      d[2 * t + 1] = v[1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cols[p * 8 + j] = (uint4_t){d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
+}
+
 }  // namespace
 
 extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int N, int H, int W, int C, int upsample,
@@ -91,6 +120,16 @@ extern "C" int uce_im2col3x3_nhwc(uce_handle_t h, const void* x, void* cols, int
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_im2col3x3_flat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xs, cs, N, H, W, C8, up);
   }
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+extern "C" int uce_im2col3x3_c4(uce_handle_t h, const void* x, void* cols, int N, int H, int W, uce_stream_t stream) {
+  if (!h || !x || !cols || N <= 0 || H <= 0 || W <= 0) return UCE_EINVAL;
+  UCE_ENTER(h);
+  const long M = (long)N * H * W;
+  hipLaunchKernelGGL(k_im2col3x3_c4, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint2_t*)x,
+                     (uint4_t*)cols, M, H, W);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

@@ -33,7 +33,7 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int CD_BM = 256, CD_BK = 32, CD_NST = 4;
+constexpr int CD_BK = 32, CD_NST = 4;
 
 template <bool F16>
 __device__ __forceinline__ float16_t cd_mfma(uint4_t a, uint4_t b, float16_t c) {
@@ -54,21 +54,28 @@ __device__ __forceinline__ float cd_tof(unsigned short v) {
   else return __builtin_bit_cast(float, (unsigned)v << 16);
 }
 
-template <int BN>
-constexpr size_t cd_smem() { return (size_t)CD_NST * (CD_BM + BN) * CD_BK * 2; }
+template <int BM, int BN>
+constexpr size_t cd_smem() { return (size_t)CD_NST * (BM + BN) * CD_BK * 2; }
 
-// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 3, 4 or 5)
+// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 2 .. 5)
 __device__ __forceinline__ void cd_wait_two_tiles(int per) {
   if (per == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
   else if (per == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if (per == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 }
 
 template <int WGM, int WGN, int TM, int TN, bool F16>
 __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
-                                                     long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles) {
-  static_assert(WGM * WGN == 8 && 32 * TM * WGM == CD_BM, "eight waves, 256 pixels");
+                                                     long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
+                                                     int sd, const unsigned short* __restrict__ Rs) {
+  // sd: stride (1, or 2 = diffusers' Downsample2D: output pixel (y, x) reads source pixels (2y + dy, 2x + dx) of a [N, 2H, 2W, Cin]
+  // tensor, pad 1); Rs: optional residual [M, Cout] added in the epilogue (the ResnetBlock2D's `x + conv2(.) + b`)
+  static_assert(WGM * WGN == 8, "eight waves");
+  constexpr int CD_BM = 32 * TM * WGM;
+  static_assert(CD_BM == 128 || CD_BM == 256, "128 or 256 pixels");
+  constexpr int NA = CD_BM / 128;                                     // A wave instructions per wave and k-tile
   constexpr int BN = 32 * TN * WGN;
   constexpr int STAGE = (CD_BM + BN) * CD_BK * 2;
   constexpr int NB = BN / 16;                                         // wave instructions per B image (16 or 20)
@@ -85,17 +92,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   }
   const long m0 = (tile / ntiles) * CD_BM;
   const int n0 = (int)(tile % ntiles) * BN;
-  const int Hs = H >> up, Ws = W >> up;
+  const int Hi = H * sd, Wi = W * sd;                                 // the image the taps index (before the >> up of the fused upsample)
+  const int Hs = Hi >> up, Ws = Wi >> up;
   const int cch = Cin / CD_BK, NK = 9 * cch;
   const long K = 9L * Cin;
 
   // ---- staging coordinates (k-tile invariant).  A wave instruction fills 16 rows x 64 B; lane = (row r, piece p).
   const int r = lane >> 2, p = lane & 3;
   constexpr unsigned OOB = 0x80000000u;
-  int a_y[2], a_x[2];
+  int a_y[2], a_x[2];                                                  // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
   unsigned a_base[2];                                                  // byte offset of (image, channel piece); OOB: no pixel
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NA; ++j) {
     const int R = 16 * (8 * j + w) + r;
     const int c = p ^ ((R >> 2) & 3);
     const long m = m0 + R;
@@ -103,7 +111,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
       const long img = m / ((long)H * W);
       const int rem = (int)(m - img * (long)H * W);
       a_y[j] = rem / W;
-      a_x[j] = rem - a_y[j] * W;
+      a_x[j] = (rem - a_y[j] * W) * sd;
+      a_y[j] *= sd;
       a_base[j] = (unsigned)((img * (long)Hs * Ws * Cin + c * 8) * 2);
     } else {
       a_y[j] = -4;                                                     // every tap lands outside the image
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     const int c = p ^ ((R >> 2) & 3);
     b_base[j] = (g < NB && n0 + R < Cout) ? (unsigned)(((long)(n0 + R) * K + c * 8) * 2) : OOB;
   }
-  const int per = 2 + (w < NB ? 1 : 0) + (8 + w < NB ? 1 : 0) + (16 + w < NB ? 1 : 0);   // this wave's DMAs per k-tile (3, 4 or 5)
+  const int per = NA + (w < NB ? 1 : 0) + (8 + w < NB ? 1 : 0) + (16 + w < NB ? 1 : 0);  // this wave's DMAs per k-tile (2 .. 5)
   const long x_bytes = (M / ((long)H * W)) * (long)Hs * Ws * Cin * 2;
   const long w_bytes = (long)Cout * K * 2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
@@ -130,9 +139,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
     unsigned char* sbase = smem + st * STAGE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NA; ++j) {
       const int yy = a_y[j] + dy, xx = a_x[j] + dx;
-      const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const bool ok = (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
       const unsigned off = a_base[j] + (unsigned)((((yy >> up) * Ws + (xx >> up)) * Cin + c0) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16, ok ? off : OOB, 0, 0, 0);
     }
@@ -203,8 +212,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
       for (int b = 0; b < TM; ++b) {
         const long m = m0 + (wm * TM + b) * 32 + li;
         if (m < M && n < Cout) {
-          const uint2_t o = {cd_pack2<F16>(acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1]),
-                             cd_pack2<F16>(acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3])};
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (Rs) {
+            const uint2_t r2 = *(const uint2_t*)(Rs + m * Cout + n);
+            rv[0] = cd_tof<F16>((unsigned short)(r2[0] & 0xffffu));
+            rv[1] = cd_tof<F16>((unsigned short)(r2[0] >> 16));
+            rv[2] = cd_tof<F16>((unsigned short)(r2[1] & 0xffffu));
+            rv[3] = cd_tof<F16>((unsigned short)(r2[1] >> 16));
+          }
+          const uint2_t o = {cd_pack2<F16>(acc[a][b][4 * g] + bv[0] + rv[0], acc[a][b][4 * g + 1] + bv[1] + rv[1]),
+                             cd_pack2<F16>(acc[a][b][4 * g + 2] + bv[2] + rv[2], acc[a][b][4 * g + 3] + bv[3] + rv[3])};
           *(uint2_t*)(Y + m * Cout + n) = o;
         }
       }
@@ -213,13 +230,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
 
 template <int WGM, int WGN, int TM, int TN>
 int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
-               hipStream_t st) {
+               hipStream_t st, int sd, const void* res) {
+  constexpr int BM = 32 * TM * WGM;
   constexpr int BN = 32 * TN * WGN;
-  const long mtiles = (M + CD_BM - 1) / CD_BM;
+  const long mtiles = (M + BM - 1) / BM;
   const int ntiles = (Cout + BN - 1) / BN;
   const long nwg = mtiles * ntiles;
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
-  const size_t smem = cd_smem<BN>();
+  const size_t smem = cd_smem<BM, BN>();
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -229,24 +247,40 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
-                       (int)mtiles, ntiles);
+                       (int)mtiles, ntiles, sd, (const unsigned short*)res);
   else
     hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
-                       (int)mtiles, ntiles);
+                       (int)mtiles, ntiles, sd, (const unsigned short*)res);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
 }  // namespace
 
-// 0: this form does not take the shape (the caller falls back to the 128 x 128 kernel); 1: launched; < 0: error
+// 0: this form does not take the shape (the caller falls back to the 128 x 128 register-staged kernel); 1: launched; < 0: error.
+// Tile: output channels in 320- / 256- / 128-wide tiles (whichever tiles Cout exactly); 256 pixels per workgroup while that
+// still gives every CU a workgroup, else 128 pixels, else (the 8 x 8 layers: 2048 pixels at the generation batch) 128 x 128.
+// `force` (UCE_CONV_TILE = 1000 * BM + BN) pins one for measurements.
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
-                    int dtype, hipStream_t st, int* rc) {
+                    int dtype, hipStream_t st, int* rc, int sd, const void* res, int force) {
   *rc = UCE_OK;
   if (Cin % CD_BK || Cout % 4) return 0;
-  if (Cout % 320 == 0) { *rc = launch_dma<4, 2, 2, 5>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
-  if (Cout % 256 == 0) { *rc = launch_dma<2, 4, 4, 2>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
-  if (Cout % 128 == 0) { *rc = launch_dma<4, 2, 2, 2>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st); return 1; }
+  int bn = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : Cout % 128 == 0 ? 128 : 0;
+  if (!bn) return 0;
+  const long t256 = ((M + 255) / 256) * (Cout / bn), t128 = ((M + 127) / 128) * (Cout / bn);
+  int bm = 256;
+  if (t256 < 200) bm = 128;
+  if (bm == 128 && t128 < 200 && Cout % 128 == 0) bn = 128;
+  if (force > 0) { bm = force / 1000; bn = force % 1000; }
+  if (Cout % bn) return 0;
+#define UCE_CD(WGM, WGN, TM, TN) { *rc = launch_dma<WGM, WGN, TM, TN>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res); return 1; }
+  if (bm == 256 && bn == 320) UCE_CD(4, 2, 2, 5)
+  if (bm == 256 && bn == 256) UCE_CD(2, 4, 4, 2)
+  if (bm == 256 && bn == 128) UCE_CD(4, 2, 2, 2)
+  if (bm == 128 && bn == 320) UCE_CD(4, 2, 1, 5)
+  if (bm == 128 && bn == 256) UCE_CD(2, 4, 2, 2)
+  if (bm == 128 && bn == 128) UCE_CD(4, 2, 1, 2)
+#undef UCE_CD
   return 0;
 }

@@ -237,27 +237,32 @@ int launch_igemm(const void* x, const void* w, const void* bias, void* y, long M
 }  // namespace
 
 extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const void* bias, void* y, int N, int H,
-                                    int W, int Cin, int Cout, int upsample, int dtype, uce_stream_t stream) {
+                                    int W, int Cin, int Cout, int upsample, int stride, const void* residual, int dtype,
+                                    uce_stream_t stream) {
   if (!h || !x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UCE_EINVAL;
   UCE_ENTER(h);
-  if (Cin % CG_BK || Cout % 8) return UCE_EINVAL;
+  if (Cin % 32 || Cout % 8) return UCE_EINVAL;
   if (upsample && ((H | W) & 1)) return UCE_EINVAL;
+  if ((stride != 1 && stride != 2) || (stride == 2 && upsample)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const long M = (long)N * H * W;
   // 32-bit buffer offsets: the stored activation and the weight must each stay below 2 GB (SD-1.4 at batch 32: 84 MB;
   // a 16-image VAE decode at 512 x 512 x 128: 1.07 GB); the host walks larger batches in chunks
-  if ((long)N * (H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL)
-    return UCE_EINVAL;
+  const long src_h = upsample ? H >> 1 : (long)H * stride, src_w = upsample ? W >> 1 : (long)W * stride;
+  if ((long)N * src_h * src_w * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return UCE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  // 128 x 128 tiles (a ragged last output-channel tile is masked: Cout = 320 runs 3 tiles, 572 TF/s against 389 for the
-  // 256 x 64 form); 256 x 64 only where a 128-wide tile would be at least half empty (Cout <= 64)
   {
-    // wide outputs (multiples of 256 / 320 channels) with enough pixel tiles: the direct-to-LDS 256-pixel form
+    // outputs that are multiples of 128 / 256 / 320 channels: the direct-to-LDS form (uce_conv_dma.hip), which also carries the
+    // stride-2 taps and the residual epilogue
     int rc;                                                  // UCE_CONV_DMA=0 (read at uce_create): always the 128 x 128 kernel
-    if (h->sw.conv_dma != 0 && M >= 256 * 64 &&          // (fewer than 64 pixel tiles leave most of the 256 CUs idle)
-        launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc))
+    if (h->sw.conv_dma != 0 && launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual,
+                                               h->sw.conv_tile))
       return rc;
   }
+  if (stride != 1 || residual) return UCE_ENOSYS;            // only the direct-to-LDS form has them
+  if (Cin % CG_BK) return UCE_EINVAL;
+  // 128 x 128 tiles (a ragged last output-channel tile is masked: Cout = 320 runs 3 tiles, 572 TF/s against 389 for the
+  // 256 x 64 form); 256 x 64 only where a 128-wide tile would be at least half empty (Cout <= 64)
   const int rem = Cout % 128;
   if (Cout <= 64 && rem != 0) return launch_igemm<4, 1>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);
   return launch_igemm<2, 2>(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st);

@@ -1,0 +1,315 @@
+// Linear layers of the U-Net / VAE / text encoder at inference ("the rest of the U-Net step" under
+// `pipe(...)` of evalscripts/generate-images-sd.py:37-42 - diffusers' Attention.to_q/to_k/to_v/to_out, FeedForward (GEGLU
+// proj + out), Transformer2DModel.proj_in/proj_out, ResnetBlock2D.conv_shortcut, the time embedding):
+//
+//     Y [M, N] = X [M, K] Wt [N, K]^T  (+ bias[n])  (+ R [M, N])            16-bit in / out, f32 accumulate
+//     GEGLU:  Y [M, N/2] = (hidden + b_h) * gelu(gate + b_g)                 with the rows of Wt interleaved per 32 (below)
+//
+// The direct-to-LDS structure of uce_conv_dma.hip with a single tap: workgroup = BM rows x BN columns, 8 waves, f32
+// accumulators in registers (swapped product: a lane's accumulator column is ONE row of Y, its registers are 4 consecutive
+// columns -> the bias / residual / GEGLU epilogue is per lane); a k-tile = 32 contraction elements = one 64-byte segment per
+// row, moved by `buffer_load_dwordx4 ... lds` straight into LDS (rows >= M and weight rows >= N get an out-of-range offset
+// and land as zeros), bank swizzle on the SOURCE address, ring of four stages with three k-tiles in flight, counted
+// s_waitcnt vmcnt and raw s_barriers.  What the separate kernel buys over the GEMM library + element-wise passes:
+//   * the epilogue operands: `x + to_out(o)`, `x + ff(y)`, `x + proj_out(h) + b` never exist as separate passes, and the
+//     feed-forward's [M, 2*inner] projection is never written (hidden * gelu(gate) is formed on the accumulators);
+//   * strided operands (ldx / ldy / ldr): q / k / v read from one packed projection, outputs written into slices.
+// GEGLU weight layout (host: sd/unet.py geglu_interleave): row 32 t + r of Wt is hidden row 16 t + r for r < 16 and gate row
+// 16 t + (r - 16) for r >= 16, so that every 32-row MFMA tile holds 16 outputs' hidden AND gate values and a lane's
+// registers 0..7 (hidden) pair with its registers 8..15 (gate).
+#include "uce_common.h"
+
+namespace {
+
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int GD_BK = 32, GD_NST = 4;
+
+template <bool F16>
+__device__ __forceinline__ float16_t gd_mfma(uint4_t a, uint4_t b, float16_t c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned gd_pack2(float lo, float hi) {
+  const float2_t v = {lo, hi};
+  if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <bool F16>
+__device__ __forceinline__ float gd_tof(unsigned short v) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+template <bool F16>
+__device__ __forceinline__ void gd_unpack4(uint2_t v, float* f) {
+  f[0] = gd_tof<F16>((unsigned short)(v[0] & 0xffffu));
+  f[1] = gd_tof<F16>((unsigned short)(v[0] >> 16));
+  f[2] = gd_tof<F16>((unsigned short)(v[1] & 0xffffu));
+  f[3] = gd_tof<F16>((unsigned short)(v[1] >> 16));
+}
+
+// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 2 .. 5)
+__device__ __forceinline__ void gd_wait_two_tiles(int per) {
+  if (per == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+  else if (per == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if (per == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if (per == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+}
+
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU>
+__global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
+                                                  const unsigned short* __restrict__ Wt,
+                                                  const unsigned short* __restrict__ bias,
+                                                  const unsigned short* __restrict__ R, long ldr,
+                                                  unsigned short* __restrict__ Y, long ldy, long M, int N, int K,
+                                                  int mtiles, int ntiles) {
+  static_assert(WGM * WGN == 8, "eight waves");
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  static_assert(BM == 128 || BM == 256, "A image: one or two 16-row DMA instructions per wave");
+  constexpr int NA = BM / 128;                                         // A wave instructions per wave and k-tile
+  constexpr int NB = BN / 16;                                          // B wave instructions per k-tile (all waves)
+  constexpr int NBJ = (NB + 7) / 8;
+  constexpr int STAGE = (BM + BN) * GD_BK * 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w % WGM, wn = w / WGM;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // the column tiles of one row tile are consecutive on one XCD (they share the rows of X)
+  long tile = blockIdx.x;
+  {
+    const long T = (long)mtiles * ntiles;
+    if ((T & 7) == 0) tile = (long)(blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+  }
+  const long m0 = (tile / ntiles) * BM;
+  const int n0 = (int)(tile % ntiles) * BN;
+  const int NK = K / GD_BK;
+
+  // ---- staging coordinates (k-tile invariant).  A wave instruction fills 16 rows x 64 B; lane = (row r, piece p).
+  const int r = lane >> 2, p = lane & 3;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_base[2];          // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int Rr = 16 * (8 * j + w) + r;
+    const int c = p ^ ((Rr >> 2) & 3);
+    const long m = m0 + Rr;
+    a_base[j] = (m < M) ? (unsigned)((m * ldx + c * 8) * 2) : OOB;
+  }
+  unsigned b_base[3];
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int g = 8 * j + w;
+    const int Rr = 16 * g + r;
+    const int c = p ^ ((Rr >> 2) & 3);
+    b_base[j] = (g < NB && n0 + Rr < N) ? (unsigned)(((long)(n0 + Rr) * K + c * 8) * 2) : OOB;
+  }
+  int per = NA;
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) per += (8 * j + w < NB) ? 1 : 0;       // this wave's DMAs per k-tile
+  const long x_bytes = ((M - 1) * ldx + K) * 2;
+  const long w_bytes = (long)N * K * 2;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)w_bytes, 0x00020000);
+
+  auto stage = [&](int st, int kt) {
+    unsigned char* sbase = smem + st * STAGE;
+    const unsigned koff = (unsigned)(kt * GD_BK * 2);
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16,
+                                               a_base[j] == OOB ? OOB : a_base[j] + koff, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      if (8 * j + w < NB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + BM * 64 + (8 * j + w) * 1024), 16,
+                                                 b_base[j] == OOB ? OOB : b_base[j] + koff, 0, 0, 0);
+    }
+  };
+
+  float16_t acc[TN][TM];                                               // [column tile][row tile]
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  int arow[TM], brow[TN];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) arow[b] = (wm * TM + b) * 32 + li;
+#pragma unroll
+  for (int a = 0; a < TN; ++a) brow[a] = (wn * TN + a) * 32 + li;
+
+  const int last = NK - 1;                                             // (past the last tile the ring re-loads it: constant counts)
+  stage(0, 0);
+  stage(1, 1 < last ? 1 : last);
+  stage(2, 2 < last ? 2 : last);
+  gd_wait_two_tiles(per);
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < NK; ++kt) {
+    stage((kt + 3) & 3, kt + 3 < last ? kt + 3 : last);
+    const unsigned char* Ab = smem + (kt & 3) * STAGE;
+    const unsigned char* Bb = Ab + BM * 64;
+#pragma unroll
+    for (int s = 0; s < GD_BK / 16; ++s) {
+      const int c = 2 * s + lh;
+      uint4_t pf[TM], cf[TN];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * 64 + ((c ^ ((arow[b] >> 2) & 3)) << 4));
+#pragma unroll
+      for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * 64 + ((c ^ ((brow[a] >> 2) & 3)) << 4));
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = gd_mfma<F16>(cf[a], pf[b], acc[a][b]);   // rows = columns of Y, columns = rows of Y
+    }
+    gd_wait_two_tiles(per);                                            // this wave's part of tile kt + 1 has landed
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
+
+  // ---- epilogue.  Register 4 g + i of tile a = column n0 + (wn TN + a) 32 + 8 g + 4 lh + i, row m0 + (wm TM + b) 32 + li
+  if constexpr (GEGLU) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int nh = n0 + (wn * TN + a) * 32 + 8 * g + 4 * lh;       // hidden rows of the interleaved weight; gates at + 16
+        const int no = (n0 + (wn * TN + a) * 32) / 2 + 8 * g + 4 * lh; // output column
+        float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias && nh < N) {
+          gd_unpack4<F16>(*(const uint2_t*)(bias + nh), bh);
+          gd_unpack4<F16>(*(const uint2_t*)(bias + nh + 16), bg);
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const long m = m0 + (wm * TM + b) * 32 + li;
+          if (m < M && nh < N) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float hv = acc[a][b][4 * g + i] + bh[i];
+              const float gv = acc[a][b][4 * (g + 2) + i] + bg[i];
+              o[i] = hv * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
+            }
+            const uint2_t o2 = {gd_pack2<F16>(o[0], o[1]), gd_pack2<F16>(o[2], o[3])};
+            *(uint2_t*)(Y + m * ldy + no) = o2;
+          }
+        }
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * TN + a) * 32 + 8 * g + 4 * lh;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n < N) gd_unpack4<F16>(*(const uint2_t*)(bias + n), bv);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const long m = m0 + (wm * TM + b) * 32 + li;
+          if (m < M && n < N) {
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (R) gd_unpack4<F16>(*(const uint2_t*)(R + m * ldr + n), rv);
+            const uint2_t o = {gd_pack2<F16>(acc[a][b][4 * g] + bv[0] + rv[0], acc[a][b][4 * g + 1] + bv[1] + rv[1]),
+                               gd_pack2<F16>(acc[a][b][4 * g + 2] + bv[2] + rv[2], acc[a][b][4 * g + 3] + bv[3] + rv[3])};
+            *(uint2_t*)(Y + m * ldy + n) = o;
+          }
+        }
+      }
+  }
+}
+
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU>
+int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
+               int K, hipStream_t st) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  const long mtiles = (M + BM - 1) / BM;
+  const int ntiles = (N + BN - 1) / BN;
+  const long nwg = mtiles * ntiles;
+  if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
+  const size_t smem = (size_t)GD_NST * (BM + BN) * GD_BK * 2;
+  static PerDeviceOnce attr_once;
+  if (const int tok = attr_once.first()) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    attr_once.commit(tok);
+  }
+  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+                     ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
+                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+template <int WGM, int WGN, int TM, int TN>
+int launch_shape(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
+                 int K, int geglu, int dtype, hipStream_t st) {
+  if (dtype == UCE_DTYPE_F16)
+    return geglu ? launch_one<WGM, WGN, TM, TN, true, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
+                 : launch_one<WGM, WGN, TM, TN, true, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st);
+  return geglu ? launch_one<WGM, WGN, TM, TN, false, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
+               : launch_one<WGM, WGN, TM, TN, false, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st);
+}
+
+// padded MFMA work of an N-wide output on BN-wide tiles, relative
+inline long waste(int N, int BN) { return (long)((N + BN - 1) / BN) * BN; }
+
+}  // namespace
+
+// tile choice: the column width that wastes the fewest MFMAs on N (320 tiles SD's 320 / 640 / 1280 / 2560 ... exactly,
+// 256 the VAE's and the text encoder's widths), and 128-row tiles when 256-row tiles would leave CUs without a workgroup
+int launch_linear(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
+                  int K, int geglu, int dtype, hipStream_t st, int force_tile) {
+  const long w320 = waste(N, 320), w256 = waste(N, 256), w128 = waste(N, 128);
+  int bn = 320;
+  if (w256 < w320) bn = 256;
+  if (w128 < (bn == 320 ? w320 : w256)) bn = 128;
+  long tiles256 = ((M + 255) / 256) * ((N + bn - 1) / bn);
+  int bm = (tiles256 < 256 && M > 128) ? 128 : 256;
+  if (bn == 128) bm = 256;
+  if (force_tile > 0) { bm = force_tile / 1000; bn = force_tile % 1000; }
+  if (bm == 256 && bn == 320) return launch_shape<4, 2, 2, 5>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  if (bm == 256 && bn == 256) return launch_shape<2, 4, 4, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  if (bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  if (bm == 128 && bn == 256) return launch_shape<2, 4, 2, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  if (bm == 256 && bn == 128) return launch_shape<4, 2, 2, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  return UCE_EINVAL;
+}
+
+extern "C" int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual,
+                              long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream) {
+  if (!h || !x || !w || !y || M <= 0 || N <= 0 || K <= 0) return UCE_EINVAL;
+  UCE_ENTER(h);
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  if (epilogue != UCE_EPILOGUE_NONE && epilogue != UCE_EPILOGUE_GEGLU) return UCE_EINVAL;
+  const int geglu = epilogue == UCE_EPILOGUE_GEGLU;
+  // 64-byte k-tiles, 8-byte epilogue accesses, 16-byte DMA pieces
+  if (K % GD_BK || N % 4 || ldx < K || ldx % 8 || ldy % 4 || (residual && (ldr % 4 || geglu))) return UCE_EINVAL;
+  if (geglu && N % 32) return UCE_EINVAL;
+  if (ldy < (geglu ? N / 2 : N) || (residual && ldr < N)) return UCE_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)w) & 15) || (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 7)) return UCE_EINVAL;
+  // 32-bit buffer offsets: rows are walked in chunks whose X image stays under 2 GB
+  const long max_rows = ((1L << 31) - 1 - 2L * K) / (2 * ldx) + 1;
+  if ((long)N * K * 2 >= (1L << 31)) return UCE_EINVAL;
+  const int force = h->sw.gemm_tile;
+  for (long m0 = 0; m0 < M; m0 += max_rows) {
+    const long mb = (M - m0 < max_rows) ? M - m0 : max_rows;
+    const int rc = launch_linear((const unsigned short*)x + m0 * ldx, ldx, w, bias,
+                                 residual ? (const void*)((const unsigned short*)residual + m0 * ldr) : nullptr, ldr,
+                                 (unsigned short*)y + m0 * ldy, ldy, mb, N, K, geglu, dtype, (hipStream_t)stream, force);
+    if (rc != UCE_OK) return rc;
+  }
+  return UCE_OK;
+}

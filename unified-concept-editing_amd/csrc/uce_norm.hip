@@ -62,7 +62,7 @@ __host__ __device__ inline GnMap gn_map(int C) {
 // "h + time_emb_proj(...)[:, :, None, None]" and the bias of the convolution that produced x, folded in).
 template <bool F16>
 __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
-                                                  float* __restrict__ partial, int HW, int C, int G, int chunks) {
+                                                  float* __restrict__ partial, int HW, int C, int G, int chunks, long ald) {
   extern __shared__ __attribute__((aligned(16))) float red[];     // [RPI][C][2]
   const GnMap mp = gn_map(C);
   const int tpr = mp.active / mp.RPI;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
       const int oc = oc0 + j * tpr;
 #pragma unroll
       for (int i = 0; i < 8; ++i) ad[j][i] = 0.f;
-      if (addend && j < mp.NO && oc < mp.OC) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * C + oc * 8), ad[j]);
+      if (addend && j < mp.NO && oc < mp.OC) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * ald + oc * 8), ad[j]);
     }
     for (int p = p0 + prow; p < p1; p += mp.RPI) {
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
                                                   const unsigned short* __restrict__ gamma,
                                                   const unsigned short* __restrict__ beta, const float* __restrict__ partial,
                                                   unsigned short* __restrict__ y, int HW, int C, int G, int chunks,
-                                                  float eps, int silu) {
+                                                  float eps, int silu, long ald) {
   __shared__ float mean_s[64], rstd_s[64];
   const GnMap mp = gn_map(C);
   const int tpr = mp.active / mp.RPI;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
       float a8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) a8[i] = 0.f;
-      if (addend) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * C + oc * 8), a8);
+      if (addend) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * ald + oc * 8), a8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int grp = (oc * 8 + i) / cpg;
@@ -211,8 +211,10 @@ extern "C" int uce_groupnorm_chunks(int HW) {
 // ws: N * uce_groupnorm_chunks(HW) * G * 2 floats, owned by the caller
 extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, const void* gamma, const void* beta,
                                       void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
-                                      uce_stream_t stream) {
+                                      long addend_ld, uce_stream_t stream) {
   if (!h || !x || !gamma || !beta || !y || !ws || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64) return UCE_EINVAL;
+  const long ald = addend_ld > 0 ? addend_ld : C;
+  if (addend && (ald < C || ald % 8)) return UCE_EINVAL;
   UCE_ENTER(h);
   if (C % 8 || C % G || C > 8 * 256 * MAXO || N > 65535) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
@@ -224,16 +226,16 @@ extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void*
   hipStream_t st = (hipStream_t)stream;
   if (dtype == UCE_DTYPE_F16) {
     hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)addend, ws, HW,
-                       C, G, chunks);
+                       C, G, chunks, ald);
     hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)addend,
                        (const unsigned short*)gamma,
-                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu);
+                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu, ald);
   } else {
     hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)addend, ws, HW,
-                       C, G, chunks);
+                       C, G, chunks, ald);
     hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)addend,
                        (const unsigned short*)gamma,
-                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu);
+                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu, ald);
   }
   UCE_LAUNCH_CHECK();
   return UCE_OK;

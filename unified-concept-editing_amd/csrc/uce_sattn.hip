@@ -70,11 +70,10 @@ __device__ __forceinline__ void sattn_block(int& qx, int& h, int& b) {
 // ones_row >= 0: that (padding) row of V^T is set to 1.0 (`one`, in the element type) for the real keys, so the P V
 // product accumulates the softmax denominator in that output row for free (k_sattn's sum_mfma path).
 __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V, unsigned short* __restrict__ Vt, int H,
-                                            int Lk, int dh, int DVP, int LkP, int ones_row, unsigned short one) {
+                                            int Lk, int dh, int DVP, int LkP, int ones_row, unsigned short one, long ld) {
   __shared__ unsigned short tile[64][66];
   const int b = blockIdx.z / H, h = blockIdx.z % H;
   const int k0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-  const int C = H * dh;
   const int tid = threadIdx.x;
   {
     const int dv = tid & 63, kk = tid >> 6;          // coalesced along the head dims
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V
     for (int p = 0; p < 16; ++p) {
       const int key = k0 + kk + 4 * p;
       unsigned short v = 0;
-      if (key < Lk && d0 + dv < dh) v = V[((size_t)b * Lk + key) * C + (size_t)h * dh + d0 + dv];
+      if (key < Lk && d0 + dv < dh) v = V[((size_t)b * Lk + key) * ld + (size_t)h * dh + d0 + dv];
       if (key < Lk && d0 + dv == ones_row) v = one;
       tile[kk + 4 * p][dv] = v;
     }
@@ -102,10 +101,14 @@ __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V
 // accumulators of two tiles fit the register file at two waves per SIMD) every K / V^T fragment read from LDS feeds two
 // MFMAs and a key tile's barrier covers twice the flops - the 4096-token layers were bound by LDS fragment traffic and
 // barrier stalls (22 KB of LDS reads per wave and key tile at QT = 1), not by the matrix cores.
-template <int DHP, bool F16, int QT>
+// VTI: no V^T pre-pass - `Vt` is V itself ([B, Lk, ld] rows like K) and the tile is transposed on its way into LDS (16-byte
+// global loads, eight 2-byte LDS stores per load); the padding rows of the V^T image (and its row of ones) are written once.
+// ld: row stride (elements) of Q, K and V - H * dh for separate tensors, 3 * H * dh for one packed projection.
+template <int DHP, bool F16, int QT, bool VTI>
 __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
-                                               int H, int Lq, int Lk, int LkP, int dh, float scale_log2e) {
+                                               int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
+                                               unsigned short one) {
   constexpr int NDV = (DHP + 31) / 32;      // output row tiles (of O^T)
   constexpr int DVP = NDV * 32;
   constexpr int KLD = DHP + 8;              // K tile row stride (elements): odd multiple of 16 B
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   constexpr int KCH = DHP / 8;              // 16-byte chunks per key row
   constexpr int NKL = (KT * KCH + 255) / 256;     // K chunks per thread per tile
   constexpr int VCH = KT / 8;               // 16-byte chunks per V^T row (8)
-  constexpr int NVL = (DVP * VCH + 255) / 256;    // V^T chunks per thread per tile
+  constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;    // V^T chunks per thread per tile (VTI: chunks of V rows, like K)
   constexpr int BUF = KT * KLD + DVP * VLD;       // elements per buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // 2 buffers of BUF elements
   unsigned short* smem = (unsigned short*)smem_raw;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const long row = q0 + 32 * t + lq;
-    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * ld + (size_t)h * dh;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int dim = 16 * s + 8 * lh;
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
     }
   }
 
-  const unsigned short* kbase = K + (size_t)b * Lk * C + (size_t)h * dh;
-  const unsigned short* vbase = Vt + ((size_t)b * H + h) * DVP * LkP;
+  const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
+  const unsigned short* vbase = VTI ? Vt + (size_t)b * Lk * ld + (size_t)h * dh : Vt + ((size_t)b * H + h) * DVP * LkP;
   uint4_t rk[NKL], rv[NVL];
   auto g_load = [&](int t) {
     const int key0 = t * KT;
@@ -149,13 +152,19 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
       const int e = tid + 256 * i;
       const int key = e / KCH, dim = (e - key * KCH) * 8;
       rk[i] = (uint4_t){0u, 0u, 0u, 0u};
-      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * C + dim);
+      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
     }
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
-      if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+      if constexpr (VTI) {                     // 8 dims of one key (keys >= Lk: zeros, the padding keys carry P = 0)
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        rv[i] = (uint4_t){0u, 0u, 0u, 0u};
+        if (e < KT * KCH && key0 + key < Lk && dim < dh) rv[i] = *(const uint4_t*)(vbase + (size_t)(key0 + key) * ld + dim);
+      } else {
+        const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+        if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+      }
     }
   };
   auto s_store = [&](int buf) {
@@ -170,14 +179,33 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
-      if (e < DVP * VCH) {
-        // VLD * 2 bytes is a multiple of 8 but not of 16: two 8-byte stores
-        *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
-        *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+      if constexpr (VTI) {                     // transposed: element q of the chunk -> row dim + q, column key
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        if (e < KT * KCH && dim < dh) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Vs[(dim + 2 * q) * VLD + key] = (unsigned short)(rv[i][q] & 0xffffu);
+            Vs[(dim + 2 * q + 1) * VLD + key] = (unsigned short)(rv[i][q] >> 16);
+          }
+        }
+      } else {
+        const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+        if (e < DVP * VCH) {
+          // VLD * 2 bytes is a multiple of 8 but not of 16: two 8-byte stores
+          *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
+          *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+        }
       }
     }
   };
+  if constexpr (VTI) {
+    // rows dh .. DVP - 1 of both V^T images never change: zeros, and ones in the last row when it is a padding row
+    for (int e = tid; e < 2 * (DVP - 0) * KT; e += 256) {
+      const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
+      const int dv = rem / KT, key = rem - dv * KT;
+      if (dv >= dh) smem[buf * BUF + KT * KLD + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
+    }
+  }
 
   // dh < DVP: row DVP - 1 of V^T is all ones (k_vt), so O^T's last row IS the running softmax denominator - summed
   // by the matrix core, rescaled with the other rows - and the 32 VALU adds per tile go away.
@@ -326,10 +354,11 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 // ---------------------------------------------------------------------------------------------
 // (forced to three waves per SIMD at dh = 40 - 168 VGPRs, 22 spilled - it ran 2071 us against 1747 at two waves and 1580 for
 //  k_sattn with two query tiles per wave: measured in round 3, not adopted)
-template <int DHP, bool F16>
+template <int DHP, bool F16, bool VTI>
 __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
-                                                 int H, int Lq, int Lk, int LkP, int dh, float scale_log2e) {
+                                                 int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
+                                                 unsigned short one) {
   constexpr int NDV = (DHP + 31) / 32;
   constexpr int DVP = NDV * 32;
   constexpr int KLD = DHP + 8;
@@ -338,7 +367,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
   constexpr int KCH = DHP / 8;
   constexpr int NKL = (KT * KCH + 255) / 256;
   constexpr int VCH = KT / 8;
-  constexpr int NVL = (DVP * VCH + 255) / 256;
+  constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Kbuf = (unsigned short*)smem_raw;                  // [2][KT * KLD]
   unsigned short* Vbuf = Kbuf + 2 * KT * KLD;                        // [2][DVP * VLD]
@@ -352,15 +381,15 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 
   uint4_t qf[NS];
   {
-    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * ld + (size_t)h * dh;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int dim = 16 * s + 8 * lh;
       qf[s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
     }
   }
-  const unsigned short* kbase = K + (size_t)b * Lk * C + (size_t)h * dh;
-  const unsigned short* vbase = Vt + ((size_t)b * H + h) * DVP * LkP;
+  const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
+  const unsigned short* vbase = VTI ? Vt + (size_t)b * Lk * ld + (size_t)h * dh : Vt + ((size_t)b * H + h) * DVP * LkP;
   uint4_t rk[NKL], rv[NVL];
   auto g_load_k = [&](int t) {
     const int key0 = t * KT;
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
       const int e = tid + 256 * i;
       const int key = e / KCH, dim = (e - key * KCH) * 8;
       rk[i] = (uint4_t){0u, 0u, 0u, 0u};
-      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * C + dim);
+      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
     }
   };
   auto g_load_v = [&](int t) {
@@ -377,8 +406,14 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
-      if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+      if constexpr (VTI) {
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        rv[i] = (uint4_t){0u, 0u, 0u, 0u};
+        if (e < KT * KCH && key0 + key < Lk && dim < dh) rv[i] = *(const uint4_t*)(vbase + (size_t)(key0 + key) * ld + dim);
+      } else {
+        const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+        if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+      }
     }
   };
   auto s_store_k = [&](int buf) {
@@ -395,13 +430,31 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      const int dv = e / VCH, kc = (e - dv * VCH) * 8;
-      if (e < DVP * VCH) {
-        *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
-        *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+      if constexpr (VTI) {
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        if (e < KT * KCH && dim < dh) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Vs[(dim + 2 * q) * VLD + key] = (unsigned short)(rv[i][q] & 0xffffu);
+            Vs[(dim + 2 * q + 1) * VLD + key] = (unsigned short)(rv[i][q] >> 16);
+          }
+        }
+      } else {
+        const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+        if (e < DVP * VCH) {
+          *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
+          *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+        }
       }
     }
   };
+  if constexpr (VTI) {
+    for (int e = tid; e < 2 * DVP * KT; e += 256) {
+      const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
+      const int dv = rem / KT, key = rem - dv * KT;
+      if (dv >= dh) Vbuf[buf * DVP * VLD + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
+    }
+  }
   // S^T = K Q^T of the tile in K buffer `buf`
   auto qk = [&](int buf, float16_t (&sacc)[2]) {
     const unsigned short* Ks = Kbuf + buf * KT * KLD;
@@ -537,50 +590,76 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
     }
 }
 
-template <int DHP>
+template <int DHP, bool VTI>
 int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
-                 float scale, int dtype, hipStream_t st) {
+                 float scale, int dtype, hipStream_t st, long ld) {
   const dim3 grid((Lq + 127) / 128, H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, true, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, false, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn_p<DHP, true>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+    hipLaunchKernelGGL((k_sattn_p<DHP, true, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
   else
-    hipLaunchKernelGGL((k_sattn_p<DHP, false>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+    hipLaunchKernelGGL((k_sattn_p<DHP, false, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
-template <int DHP, int QT>
+template <int DHP, int QT, bool VTI>
 int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
-               float scale, int dtype, hipStream_t st) {
+               float scale, int dtype, hipStream_t st, long ld) {
   const dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn<DHP, true, QT>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+    hipLaunchKernelGGL((k_sattn<DHP, true, QT, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
   else
-    hipLaunchKernelGGL((k_sattn<DHP, false, QT>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2);
+    hipLaunchKernelGGL((k_sattn<DHP, false, QT, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
+}
+
+// the kernel for one shape, with (VTI) or without the V^T pre-pass already run
+template <bool VTI>
+int launch_body(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh, float scale,
+                int dtype, hipStream_t st, int qt_variant, long ld) {
+  // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
+  //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
+  //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
+  if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
+    return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if (dh <= 48) {
+    // two query tiles per wave once there are enough 256-row workgroups to fill the chip twice over
+    const long wg2 = (long)((Lq + 255) / 256) * H * B;
+    if (qt_variant != 1 && (qt_variant == 2 || wg2 >= 1024))
+      return launch_cfg<48, 2, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+    return launch_cfg<48, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  }
+  if (dh <= 64) return launch_cfg<64, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if (dh <= 80) return launch_cfg<80, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if (dh <= 96) return launch_cfg<96, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if (dh <= 128) return launch_cfg<128, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  return launch_cfg<160, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
 }
 
 }  // namespace
@@ -594,44 +673,59 @@ size_t sattn_vt_elems(int B, int H, int Lk, int dh) {
   return (size_t)B * H * sattn_dvp(dh) * ((Lk + KT - 1) / KT * KT);
 }
 
+// V^T by the pre-pass (k_vt: straight 16-byte tile copies in the key loop) or transposed on the way into LDS (no pre-pass, no
+// scratch): `vti` = UCE_SATTN_VTI (0: by rule - inline up to 1024 keys, where the pre-pass and its launch are a visible share
+// of a short kernel; 1: always inline; 2: always the pre-pass)
+bool sattn_inline_vt(int Lk, int vti) { return vti == 1 || (vti == 0 && Lk <= 1024); }
+
 // qt_variant (UCE_SATTN_QT, read at uce_create): 0 = measured best by shape, 1 = always k_sattn with one query tile per wave,
 // 2 = two query tiles wherever dh <= 48, 3 = the pipelined kernel wherever it exists (dh <= 48, 64 < dh <= 80)
+// ld: row stride (elements) of q, k and v; o rows are H * dh apart.
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st, int qt_variant) {
+                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti) {
   const int LkP = (Lk + KT - 1) / KT * KT;
+  if (ld <= 0) ld = (long)H * dh;
+  if (sattn_inline_vt(Lk, vti)) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   hipLaunchKernelGGL(k_vt, dim3(LkP / 64, (DVP + 63) / 64, B * H), dim3(256), 0, st, (const unsigned short*)v,
-                     (unsigned short*)vt, H, Lk, dh, DVP, LkP, ones_row, one);
+                     (unsigned short*)vt, H, Lk, dh, DVP, LkP, ones_row, one, ld);
   UCE_LAUNCH_CHECK();
-  // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
-  //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
-  //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
-  if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
-    return launch_cfg_p<80>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 48) {
-    // two query tiles per wave once there are enough 256-row workgroups to fill the chip twice over
-    const long wg2 = (long)((Lq + 255) / 256) * H * B;
-    if (qt_variant != 1 && (qt_variant == 2 || wg2 >= 1024)) return launch_cfg<48, 2>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-    return launch_cfg<48, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  }
-  if (dh <= 64) return launch_cfg<64, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 80) return launch_cfg<80, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 96) return launch_cfg<96, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  if (dh <= 128) return launch_cfg<128, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
-  return launch_cfg<160, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st);
+  return launch_body<false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld);
+}
+
+static int sattn_check(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
+                       int dtype) {
+  if (!h || !q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return UCE_EINVAL;
+  if (dh <= 0 || dh > 160 || (dh & 7)) return UCE_EINVAL;
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  if (B > 65535 || H > 65535 || (long)B * H > 65535) return UCE_EINVAL;
+  return UCE_OK;
 }
 
 extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                              int Lk, int dh, float scale, int dtype, uce_stream_t stream) {
-  if (!h || !q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return UCE_EINVAL;
+  if (const int rc = sattn_check(h, q, k, v, o, B, H, Lq, Lk, dh, dtype)) return rc;
   UCE_ENTER(h);
-  if (dh <= 0 || dh > 160 || (dh & 7)) return UCE_EINVAL;
-  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
-  if (B > 65535 || H > 65535 || (long)B * H > 65535) return UCE_EINVAL;
-  const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, Lk, dh));
-  if (rc) return rc;
-  return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt);
+  if (!sattn_inline_vt(Lk, h->sw.sattn_vti)) {
+    const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, Lk, dh));
+    if (rc) return rc;
+  }
+  return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, (long)H * dh,
+                      h->sw.sattn_vti);
+}
+
+extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, float scale, int dtype,
+                                    uce_stream_t stream) {
+  const unsigned short* p = (const unsigned short*)qkv;
+  const long C = (long)H * dh;
+  if (const int rc = sattn_check(h, p, p, p, o, B, H, L, L, dh, dtype)) return rc;
+  UCE_ENTER(h);
+  if (!sattn_inline_vt(L, h->sw.sattn_vti)) {
+    const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, L, dh));
+    if (rc) return rc;
+  }
+  return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
+                      h->sw.sattn_vti);
 }

@@ -243,6 +243,18 @@ class UceHandle:
                                           float(scale), dt, _stream_ptr(self.device)), "uce_sattn_fwd")
         return out
 
+    def sattn_packed(self, qkv: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+        """Self-attention on a packed projection qkv [B, L, 3 * C] (q | k | v columns) through uce_sattn_packed_fwd -> [B, L, C]."""
+        B, Lq, C3 = qkv.shape
+        Cc = C3 // 3
+        dh = Cc // heads
+        scale = dh ** -0.5 if scale is None else scale
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[qkv.dtype]
+        out = torch.empty(B, Lq, Cc, dtype=qkv.dtype, device=qkv.device)
+        _lib.check(self.lib.uce_sattn_packed_fwd(self._h, _ptr(qkv), _ptr(out), B, heads, Lq, dh, float(scale), dt,
+                                                 _stream_ptr(self.device)), "uce_sattn_packed_fwd")
+        return out
+
     def groupnorm_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float,
                        silu: bool, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
         """GroupNorm (+ SiLU) of a channels-last [N, C, H, W] tensor through uce_groupnorm_nhwc_fwd; `addend` [N, C]
@@ -252,8 +264,13 @@ class UceHandle:
         y = torch.empty_like(x)                                    # keeps the channels_last strides
         ws = torch.empty(N * self.lib.uce_groupnorm_chunks(hw) * groups * 2, dtype=torch.float32, device=x.device)
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        ald = 0
+        if addend is not None:
+            if addend.dim() != 2 or addend.stride(1) != 1 or addend.stride(0) % 8 or addend.data_ptr() % 16:
+                addend = addend.contiguous()
+            ald = addend.stride(0)
         _lib.check(self.lib.uce_groupnorm_nhwc_fwd(self._h, _ptr(x), _ptr(addend), _ptr(weight), _ptr(bias), _ptr(y),
-                                                   _ptr(ws), N, hw, Cc, groups, float(eps), int(silu), dt,
+                                                   _ptr(ws), N, hw, Cc, groups, float(eps), int(silu), dt, ald,
                                                    _stream_ptr(self.device)), "uce_groupnorm_nhwc_fwd")
         return y
 
@@ -267,34 +284,45 @@ class UceHandle:
         return y
 
     def conv3x3_igemm(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                      upsample: bool = False) -> torch.Tensor:
-        """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor as ONE implicit-GEMM launch
-        (uce_conv3x3_nhwc_fwd): no patch matrix.  Cin % 64 == 0, Cout % 8 == 0, channels-last weight."""
+                      upsample: bool = False, stride: int = 1, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """3x3 / pad 1 convolution of a channels-last [N, C, H, W] tensor as ONE implicit-GEMM launch (uce_conv3x3_nhwc_fwd): no
+        patch matrix.  Cin % 32 == 0, Cout % 8 == 0, channels-last weight.  stride 2 = Downsample2D; `residual` (channels-last,
+        the output's shape) is added in the epilogue; both need Cout % 128 == 0."""
         N, Cc, Hs, Ws = x.shape
-        Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        Hh, Ww = (2 * Hs, 2 * Ws) if upsample else ((Hs - 1) // stride + 1, (Ws - 1) // stride + 1)
+        if stride == 2 and ((Hs | Ws) & 1):
+            raise ValueError("stride-2 convolution of an odd-sized image")
         Cout = weight.shape[0]
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
         xs, ys = x.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)            # NHWC views of the same storage
+        rs = None
+        if residual is not None:
+            if residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous(memory_format=torch.channels_last):
+                raise ValueError("residual must be a channels-last tensor of the output's shape and dtype")
+            rs = residual.permute(0, 2, 3, 1)
         step = even_chunk(N, max(1, ((1 << 31) - 1) // max(1, Hs * Ws * Cc * x.element_size() + 1)))   # < 2 GB per launch
         for n0 in range(0, N, step):
             nb = min(step, N - n0)
             _lib.check(self.lib.uce_conv3x3_nhwc_fwd(self._h, xs[n0].data_ptr(), _ptr(weight), _ptr(bias), ys[n0].data_ptr(),
-                                                     nb, Hh, Ww, Cc, Cout, int(upsample), dt, _stream_ptr(self.device)),
+                                                     nb, Hh, Ww, Cc, Cout, int(upsample), int(stride),
+                                                     None if rs is None else rs[n0].data_ptr(), dt, _stream_ptr(self.device)),
                        "uce_conv3x3_nhwc_fwd")
         return y
 
     def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                     max_cols_bytes: int = CONV_COLS_BYTES, upsample: bool = False) -> torch.Tensor:
-        """3x3 / stride 1 / pad 1 convolution of a channels-last [N, C, H, W] tensor: patch matrix through
-        uce_im2col3x3_nhwc, then ONE library GEMM (F.linear -> hipBLASLt) against the channels-last weight viewed as
-        [Cout, 9*C].  The batch is walked in evenly sized chunks whose patch matrix stays under `max_cols_bytes`.
+                     max_cols_bytes: int = CONV_COLS_BYTES, upsample: bool = False, stride: int = 1,
+                     residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """3x3 / pad 1 convolution of a channels-last [N, C, H, W] tensor: the implicit-GEMM kernels where the measured rule
+        (sd.conv_dispatch) or the request (stride 2, a residual epilogue) says so, else patch matrix through uce_im2col3x3_nhwc +
+        ONE GEMM (uce_linear_fwd) against the channels-last weight viewed as [Cout, 9*C]; the batch is walked in evenly sized
+        chunks whose patch matrix stays under `max_cols_bytes`.
         upsample: convolve the 2x nearest-neighbour upsampling of x (output [N, Cout, 2H, 2W]) without materialising it."""
         N, Cc, Hs, Ws = x.shape
-        Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs // stride, Ws // stride)
         Cout = weight.shape[0]
-        if conv_prefers_igemm(Hh, Ww, Cc, Cout, N):
-            return self.conv3x3_igemm(x, weight, bias, upsample=upsample)
+        if stride != 1 or residual is not None or conv_prefers_igemm(Hh, Ww, Cc, Cout, N):
+            return self.conv3x3_igemm(x, weight, bias, upsample=upsample, stride=stride, residual=residual)
         wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         y_rows = y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout)     # NHWC view of the same storage
@@ -307,8 +335,21 @@ class UceHandle:
             _lib.check(self.lib.uce_im2col3x3_nhwc(self._h, xs[n0].data_ptr(), _ptr(cols), nb, Hh, Ww, Cc, int(upsample),
                                                    _stream_ptr(self.device)), "uce_im2col3x3_nhwc")
             rows = nb * Hh * Ww
-            torch.addmm(bias, cols[:rows], wmat.t(), out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows]) if bias is not None \
-                else torch.mm(cols[:rows], wmat.t(), out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows])
+            self.linear(cols[:rows], wmat, bias, out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows])
+        return y
+
+    def conv3x3_c4(self, x: torch.Tensor, wmat: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+        """3x3 / pad 1 convolution of a channels-last [N, 4, H, W] tensor (conv_in on the latents): uce_im2col3x3_c4 + one
+        uce_linear_fwd against `wmat` [Cout, 64] (sd.unet.conv_c4_weight: the 36 taps x channels, zero-padded)."""
+        N, Cc, Hh, Ww = x.shape
+        assert Cc == 4 and wmat.shape[1] == 64
+        Cout = wmat.shape[0]
+        cols = torch.empty((N * Hh * Ww, 64), dtype=x.dtype, device=x.device)
+        xs = x.permute(0, 2, 3, 1)
+        xs = xs if xs.is_contiguous() else xs.contiguous()
+        _lib.check(self.lib.uce_im2col3x3_c4(self._h, _ptr(xs), _ptr(cols), N, Hh, Ww, _stream_ptr(self.device)), "uce_im2col3x3_c4")
+        y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        self.linear(cols, wmat, bias, out=y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout))
         return y
 
     def layernorm(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
@@ -337,6 +378,38 @@ class UceHandle:
                                               w, _ptr(sample), float(cs), float(ce), _ptr(eps_out), _ptr(prev), n, dt,
                                               _stream_ptr(self.device)), "uce_cfg_pndm_step")
         return eps_out, prev
+
+    def linear(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, geglu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`x @ weight.T (+ bias) (+ residual)` over the last dim of x through uce_linear_fwd (16-bit, f32 accumulate); with
+        `geglu`, weight / bias are the interleaved rows of a GEGLU projection (sd.unet.geglu_interleave) and the result is
+        `hidden * gelu(gate)` with half as many columns.  x / residual / out may be row-strided 2-D views (last dim
+        contiguous): slices of wider tensors are read and written in place."""
+        K = x.shape[-1]
+        N = weight.shape[0]
+        n_out = N // 2 if geglu else N
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+
+        def rows2d(t: torch.Tensor, cols: int):
+            """(tensor, row stride) of a [..., cols] tensor as M rows: contiguous, or a 2-D view with a contiguous last dim"""
+            if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= cols:
+                return t, t.stride(0)
+            t = t.contiguous()
+            return t, cols
+
+        x2, ldx = rows2d(x, K)
+        M = x.numel() // K
+        if out is None:
+            y = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
+            ldy = n_out
+        else:
+            y, ldy = out, (out.stride(0) if out.dim() == 2 else n_out)
+        r2, ldr = (None, 0) if residual is None else rows2d(residual, N)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        _lib.check(self.lib.uce_linear_fwd(self._h, _ptr(x2), ldx, _ptr(w), _ptr(bias), _ptr(r2), ldr, _ptr(y), ldy, M, N, K,
+                                           _lib.EPILOGUE_GEGLU if geglu else _lib.EPILOGUE_NONE, dt, _stream_ptr(self.device)),
+                   "uce_linear_fwd")
+        return y
 
     def geglu(self, x: torch.Tensor) -> torch.Tensor:
         """x [..., 2*inner] -> x[..., :inner] * gelu(x[..., inner:]) through uce_geglu_fwd."""

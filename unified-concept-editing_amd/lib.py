@@ -11,6 +11,7 @@ from . import build as _build
 OK, EINVAL, ENOMEM, EDOM, ENOSYS, ECOMM = 0, -22, -12, -33, -38, -70
 ALGO_AUTO, ALGO_PRIMAL, ALGO_DUAL = 0, 1, 2
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
+EPILOGUE_NONE, EPILOGUE_GEGLU = 0, 1
 
 _vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -41,13 +42,16 @@ SIGNATURES = {
     "uce_cast_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
     "uce_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "uce_sattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "uce_sattn_packed_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "uce_groupnorm_chunks": (_i, [_i]),
-    "uce_groupnorm_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "uce_groupnorm_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _l, _vp]),
     "uce_add_bias_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "uce_cfg_pndm_step": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, C.POINTER(_f), _vp, _f, _f, _vp, _vp, _l, _i, _vp]),
     "uce_geglu_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "uce_im2col3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "uce_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "uce_im2col3x3_c4": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "uce_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "uce_linear_fwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp]),
     "uce_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
 }
 

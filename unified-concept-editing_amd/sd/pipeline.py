@@ -27,7 +27,7 @@ from .scheduler import EulerDiscreteScheduler, PNDMScheduler
 # ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
 # batch 2 (48 ms average over 384 calls in profiles/r01), far more at larger batches.  It never wins.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
-from .unet import UNet2DConditionModel, UNetConfig, conv2d, group_norm_act, upsample2x_conv
+from .unet import UNet2DConditionModel, UNetConfig, conv2d, group_norm_act, linear, upsample2x_conv
 
 MAX_LEN = 77
 BOS, EOS = 49406, 49407
@@ -101,8 +101,10 @@ class _VaeResnet(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x):
-        h = conv2d(self.conv2, group_norm_act(self.norm2, conv2d(self.conv1, group_norm_act(self.norm1, x, True)), True))
-        return (x if self.conv_shortcut is None else conv2d(self.conv_shortcut, x)) + h
+        xs = x if self.conv_shortcut is None else conv2d(self.conv_shortcut, x)
+        # the residual join rides in conv2's epilogue
+        return conv2d(self.conv2, group_norm_act(self.norm2, conv2d(self.conv1, group_norm_act(self.norm1, x, True)), True),
+                      residual=xs)
 
 
 class _VaeAttention(nn.Module):
@@ -114,9 +116,11 @@ class _VaeAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        h = self.group_norm(x).view(B, C, H * W).transpose(1, 2)
-        o = F.scaled_dot_product_attention(self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None])[:, 0]
-        return x + self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W)
+        h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        o = F.scaled_dot_product_attention(linear(self.to_q, h)[:, None], linear(self.to_k, h)[:, None],
+                                           linear(self.to_v, h)[:, None])[:, 0]
+        xr = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        return linear(self.to_out[0], o, residual=xr).reshape(B, H, W, C).permute(0, 3, 1, 2)
 
 
 class _VaeUp(nn.Module):
@@ -165,7 +169,7 @@ class _Decoder(nn.Module):
         self.conv_out = nn.Conv2d(ch[0], 3, 3, padding=1)
 
     def forward(self, z):
-        x = self.mid_block(self.conv_in(z))
+        x = self.mid_block(conv2d(self.conv_in, z))
         for u in self.up_blocks:
             x = u(x)
         return conv2d(self.conv_out, group_norm_act(self.conv_norm_out, x, True))
@@ -182,7 +186,7 @@ class VaeDecoder(nn.Module):
         self.decoder = _Decoder(ch)
 
     def decode(self, latents):
-        return self.decoder(self.post_quant_conv(latents / self.scaling_factor))
+        return self.decoder(conv2d(self.post_quant_conv, latents / self.scaling_factor))
 
 
 # ------------------------------------------------------------------------------------ pipeline
@@ -623,6 +627,7 @@ def patch_unet(pipe, state: Dict[str, torch.Tensor]) -> List[str]:
     params = dict(pipe.unet.named_parameters())
     handle = None
     loaded = []
+    stale = False
     for k, v in state.items():
         p = params.get(k)
         if p is None:                     # strict=False: keys the U-Net does not have are ignored
@@ -636,16 +641,14 @@ def patch_unet(pipe, state: Dict[str, torch.Tensor]) -> List[str]:
             handle.cast_bf16(v.to(p.device).contiguous(), p.data)
         else:
             p.data.copy_(v.to(device=p.device, dtype=p.dtype))
-        # both writes above go around the tensor's version counter: drop what was derived from the old values (the
-        # zero-padded copy of a narrow convolution weight, sd/unet.py) - a captured step that holds such a copy's
-        # address is stale too
-        mod_name = k.rsplit(".", 1)[0]
-        try:
-            mod = pipe.unet.get_submodule(mod_name)
-        except AttributeError:
-            mod = None
-        if mod is not None and hasattr(mod, "_uce_pad8"):
-            del mod._uce_pad8
-            if hasattr(pipe, "_graphs"):
-                pipe._graphs.clear()
+        # both writes above go around the tensor's version counter: tensors derived from the old values (packed q|k|v rows,
+        # interleaved GEGLU rows, the stacked time projections, zero-padded narrow weights - sd/unet.py `derived`) are stale,
+        # and so is a captured step that holds their addresses.  The edited projections themselves (attn2.to_k / to_v) have
+        # nothing derived from them: the usual patch keeps the captured graphs.
+        if not (".attn2.to_k." in "." + k or ".attn2.to_v." in "." + k):
+            stale = True
+    if stale:
+        from .unet import clear_derived
+        if clear_derived(pipe.unet) and hasattr(pipe, "_graphs"):
+            pipe._graphs.clear()
     return loaded

@@ -98,15 +98,18 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(dim, dim)
 
     def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
+        return linear(self.linear_2, F.silu(linear(self.linear_1, x)))
 
 
-USE_HIP_GROUPNORM = True          # GroupNorm(+SiLU) of channels-last 16-bit activations through the HIP kernel
+def hip16(x: torch.Tensor) -> bool:
+    """The tensors the hand-written kernels take: 16-bit activations on a GPU.  Everything else (CPU tensors of the tiny
+    test models, the fp32 comparison runs) goes through plain torch ops.  Tests that need the all-torch twin of a 16-bit GPU
+    model patch THIS predicate (tests/torch_twin.py); the product has no switch."""
+    return x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
 
 
 def _hip_nhwc_ok(x: torch.Tensor) -> bool:
-    return (USE_HIP_GROUPNORM and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
-            and x.shape[1] % 8 == 0 and 1 < x.shape[1] <= 4096 and x.shape[0] <= 65535
+    return (hip16(x) and x.dim() == 4 and x.shape[1] % 8 == 0 and 1 < x.shape[1] <= 4096 and x.shape[0] <= 65535
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -116,7 +119,7 @@ def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Opti
     GroupNorm kernels and SiLU pass."""
     if _hip_nhwc_ok(x) and norm.num_groups <= 64 and norm.weight is not None and norm.weight.dtype == x.dtype:
         from .. import edit as _edit
-        ad = None if addend is None else addend.to(x.dtype).contiguous()
+        ad = None if addend is None else addend.to(x.dtype)          # (a strided column slice is read in place)
         return _edit.UceHandle.get(x.device).groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, ad)
     if addend is not None:
         x = x + addend[:, :, None, None].to(x.dtype)
@@ -124,11 +127,8 @@ def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Opti
     return F.silu(y) if silu else y
 
 
-USE_HIP_LAYERNORM = True          # LayerNorm (+ the residual join in front of it) of the transformer blocks
-
-
 def _hip_ln_ok(norm: nn.LayerNorm, x: torch.Tensor) -> bool:
-    return (USE_HIP_LAYERNORM and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+    return (hip16(x) and x.is_contiguous()
             and norm.elementwise_affine and norm.bias is not None and norm.weight.dtype == x.dtype
             and len(norm.normalized_shape) == 1 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2560)
 
@@ -151,17 +151,34 @@ def add_layer_norm(norm: nn.LayerNorm, a: torch.Tensor, x: torch.Tensor):
     return s, norm(s)
 
 
-USE_HIP_CONV3X3 = True            # 3x3 / stride 1 / pad 1 convolutions as im2col (HIP) + one hipBLASLt GEMM
-
-
 def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
-    return (USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+    return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels >= 4
+            and conv.in_channels % 32 == 0 and conv.out_channels % 8 == 0
             and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
 
 
+def _conv3x3_epilogue_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    """the direct-to-LDS kernel takes the layer (stride 2 and the residual epilogue exist only there)"""
+    return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 128 == 0
+            and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv_c4_weight(conv: nn.Conv2d):
+    """[Cout, 64] GEMM weight of a 3x3 convolution with 4 input channels: column (ky*3 + kx)*4 + c, zero-padded (the layout
+    uce_im2col3x3_c4 writes); cached on the module."""
+    w = conv.weight
+
+    def build():
+        m = torch.zeros(w.shape[0], 64, dtype=w.dtype, device=w.device)
+        m[:, :36] = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 36)
+        return m
+    return derived(conv, "c4", _pkey(w), build)
+
+
 def _conv3x3_narrow_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
-    return (USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+    return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels < 8
             and conv.in_channels % 64 == 0 and conv.weight.dtype == x.dtype
             and x.shape[0] * x.shape[2] * x.shape[3] >= 128 * 1024)
@@ -185,13 +202,26 @@ def _padded_out_channels(conv: nn.Conv2d):
     return cached[1], cached[2]
 
 
-def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Tensor:
-    """`conv(x)`.  3x3 / stride 1 / pad 1 convolutions of channels-last 16-bit activations on a GPU go through
-    uce_im2col3x3_nhwc + one library GEMM (1.7-2.3x MIOpen's implicit GEMM on an MI355X); everything else is MIOpen."""
+def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`conv(x)` (+ residual).  Channels-last 16-bit activations on a GPU: 3x3 / pad 1 convolutions (stride 1, stride 2 of
+    Downsample2D, the 4-channel conv_in) go through uce_conv3x3_nhwc_fwd / uce_im2col3x3_nhwc, 1x1 convolutions through
+    uce_linear_fwd on the pixel rows; everything else (CPU, fp32) is torch."""
     bias = conv.bias if with_bias else None
+    if (residual is not None or conv.stride == (2, 2)) and conv.stride in ((1, 1), (2, 2)) and _conv3x3_epilogue_ok(conv, x) \
+            and (x.shape[2] % conv.stride[0] == 0 and x.shape[3] % conv.stride[1] == 0):
+        from .. import edit as _edit
+        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias, stride=conv.stride[0], residual=residual)
     if _conv3x3_fast_ok(conv, x):
         from .. import edit as _edit
-        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias)
+        y = _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias)
+        return y if residual is None else add_bias(y, residual, None)
+    if hip16(x) and x.dim() == 4 and conv.in_channels == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) \
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels % 4 == 0 \
+            and conv.weight.dtype == x.dtype and x.shape[0] <= 65535:
+        # conv_in on the 4-channel latents: a 64-wide patch matrix + one linear launch
+        from .. import edit as _edit
+        y = _edit.UceHandle.get(x.device).conv3x3_c4(x, conv_c4_weight(conv), bias)
+        return y if residual is None else add_bias(y, residual, None)
     if _conv3x3_narrow_ok(conv, x):
         # a 3- / 4-channel output (the VAE's conv_out): the implicit-GEMM kernel on the weight zero-padded to 8 output
         # channels (its 16-byte store granule), result sliced back - 0.9 ms against 2.6 ms for the library's direct kernel
@@ -199,14 +229,84 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True) -> torch.Te
         from .. import edit as _edit
         w8, b8 = _padded_out_channels(conv)
         y8 = _edit.UceHandle.get(x.device).conv3x3_igemm(x, w8, b8 if with_bias else None)
-        return y8[:, :conv.out_channels]
-    if USE_HIP_CONV3X3 and _hip_nhwc_ok(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) \
-            and conv.padding == (0, 0) and conv.groups == 1 and conv.weight.dtype == x.dtype:
-        # a 1x1 convolution of a channels-last tensor IS a GEMM over the pixel rows: hand it to the GEMM library
+        y = y8[:, :conv.out_channels]
+        return y if residual is None else y + residual
+    if _hip_nhwc_ok(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) \
+            and conv.groups == 1 and conv.weight.dtype == x.dtype and conv.in_channels % 32 == 0 and conv.out_channels % 4 == 0:
+        # a 1x1 convolution of a channels-last tensor IS a linear layer over the pixel rows
         N, Cin, Hh, Ww = x.shape
-        y = F.linear(x.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cin), conv.weight.reshape(conv.out_channels, Cin), bias)
+        rows = x.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cin)
+        res = None if residual is None else _nhwc_rows(residual)
+        y = linear_w(rows, conv.weight.reshape(conv.out_channels, Cin), bias, res)
         return y.view(N, Hh, Ww, conv.out_channels).permute(0, 3, 1, 2)
-    return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    y = F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return y if residual is None else y + residual
+
+
+def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, H, W] -> [N*H*W, C] rows (a view for channels-last tensors)."""
+    N, Cc, Hh, Ww = x.shape
+    return x.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cc)
+
+
+# ------------------------------------------------------------------------------------ linear layers
+
+def _hip_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    return (hip16(x) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0)
+
+
+def linear_w(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`x @ weight.T (+ bias) (+ residual)`: uce_linear_fwd (one launch, the residual join in its epilogue) for 16-bit
+    activations on a GPU, torch ops otherwise."""
+    if _hip_linear_ok(x, weight, bias):
+        from .. import edit as _edit
+        return _edit.UceHandle.get(x.device).linear(x, weight, bias, residual)
+    y = F.linear(x, weight, bias)
+    return y if residual is None else y + residual
+
+
+def linear(lin: nn.Linear, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return linear_w(x, lin.weight, lin.bias, residual)
+
+
+def _pkey(*params) -> tuple:
+    return tuple((p.data_ptr(), p._version, p.dtype) for p in params if p is not None)
+
+
+def derived(mod: nn.Module, name: str, key: tuple, build):
+    """A tensor derived from a module's parameters (packed q|k|v rows, interleaved GEGLU rows, concatenated time projections),
+    cached on the module and rebuilt when `key` (storage + version of the sources) changes.  Writers that go around the version
+    counter (sd.pipeline.patch_unet) call clear_derived."""
+    cache = mod.__dict__.setdefault("_uce_derived", {})
+    ent = cache.get(name)
+    if ent is None or ent[0] != key:
+        ent = (key, build())
+        cache[name] = ent
+    return ent[1]
+
+
+def clear_derived(root: nn.Module) -> bool:
+    """Drop every cached derived tensor under `root`; True if there was one (captured graphs holding their addresses are stale)."""
+    found = False
+    for m in root.modules():
+        for attr in ("_uce_derived", "_uce_pad8"):
+            if attr in m.__dict__:
+                del m.__dict__[attr]
+                found = True
+    return found
+
+
+def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Rows of a GEGLU projection ([2 * inner, C]: hidden rows, then gate rows) in the order uce_linear_fwd's GEGLU epilogue
+    reads them: per 32 rows, 16 hidden rows followed by their 16 gate rows (csrc/uce_gemm.hip)."""
+    inner = weight.shape[0] // 2
+    w = torch.cat([weight[:inner].reshape(inner // 16, 16, -1), weight[inner:].reshape(inner // 16, 16, -1)], dim=1)
+    b = None
+    if bias is not None:
+        b = torch.cat([bias[:inner].reshape(inner // 16, 16), bias[inner:].reshape(inner // 16, 16)], dim=1).reshape(-1).contiguous()
+    return w.reshape(2 * inner, -1).contiguous(), b
 
 
 def upsample2x_conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
@@ -242,21 +342,21 @@ class ResnetBlock2D(nn.Module):
         self.norm2 = nn.GroupNorm(groups, cout, eps=1e-5)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+        self.temb_addend: Optional[torch.Tensor] = None      # this block's slice of the U-Net's hoisted time projections
 
     def forward(self, x, temb):
         # conv biases and the time-embedding add ride in the fused kernels: norm2 sees conv1(.) + (b1 + temb_c),
         # the residual join adds b2 (+ the shortcut's bias) in the same pass
         h = conv_nobias(self.conv1, group_norm_act(self.norm1, x, True))
-        ad = self.time_emb_proj(F.silu(temb))
-        if self.conv1.bias is not None:
-            ad = ad + self.conv1.bias[None, :]
-        h = conv_nobias(self.conv2, group_norm_act(self.norm2, h, True, addend=ad))
-        bias = self.conv2.bias
+        ad = self.temb_addend
+        if ad is None:
+            ad = linear(self.time_emb_proj, F.silu(temb))
+            if self.conv1.bias is not None:
+                ad = ad + self.conv1.bias[None, :]
         if self.conv_shortcut is not None:
-            x = conv_nobias(self.conv_shortcut, x)
-            if self.conv_shortcut.bias is not None:
-                bias = self.conv_shortcut.bias if bias is None else bias + self.conv_shortcut.bias
-        return add_bias(x, h, bias)
+            x = conv2d(self.conv_shortcut, x)                      # 1x1: a linear layer over the pixel rows, bias in its epilogue
+        # x + conv2(.) + b2: the residual join rides in conv2's epilogue
+        return conv2d(self.conv2, group_norm_act(self.norm2, h, True, addend=ad), residual=x)
 
 
 class Attention(nn.Module):
@@ -274,44 +374,44 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
         self.kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None   # hoisted K/V of a constant context
 
-    def forward(self, x, context=None):
+    def forward(self, x, context=None, residual=None):
+        """`to_out(attention(to_q(x), to_k(ctx), to_v(ctx)))` (+ residual, in the output projection's epilogue)."""
+        if not self.is_cross and x.dim() == 3 and _hip_linear_ok(x, self.to_q.weight, None) and _hip_attention_ok(x, self.heads):
+            # attn1 on a GPU: ONE projection launch for q | k | v (the three weights stacked along their rows) and the
+            # attention kernel reads the packed result in place
+            from .. import edit as _edit
+            wq, wk, wv = self.to_q.weight, self.to_k.weight, self.to_v.weight
+            wqkv = derived(self, "qkv", _pkey(wq, wk, wv), lambda: torch.cat([wq.detach(), wk.detach(), wv.detach()]).contiguous())
+            o = _edit.UceHandle.get(x.device).sattn_packed(linear_w(x.contiguous(), wqkv), self.heads)
+            return linear(self.to_out[0], o, residual)
         ctx = x if context is None else context
-        q = self.to_q(x)
+        q = linear(self.to_q, x)
         if self.is_cross and self.kv_cache is not None:
             k, v = self.kv_cache
         else:
-            k, v = self.to_k(ctx), self.to_v(ctx)
+            k, v = linear(self.to_k, ctx), linear(self.to_v, ctx)
         o = _attention_core(q, k, v, self.heads, self.is_cross)
-        return self.to_out[0](o)
+        return linear(self.to_out[0], o, residual)
 
 
-USE_HIP_SELF_ATTENTION = True     # attn1 through uce_sattn_fwd on a GPU in bf16/f16 (False: torch SDPA)
-USE_HIP_CROSS_ATTENTION = True    # attn2 through uce_xattn_fwd (False: torch SDPA; comparison runs only)
-
-
-def sattn_prefers_hip(Lk: int) -> bool:
-    """Measured rule (bench.py's `sattn` rows, MI355X, generation batch): uce_sattn_fwd streams key tiles behind a V^T
-    pre-pass - ahead of torch's SDPA from 1024 keys up (the 4096- and 1024-token layers: 97 % of the attn1 time), 10 %
-    behind it at the 256- and 64-token layers, where the pre-pass and the prologue are a fifth of the launch.  SDPA on the
-    [B, L, H, dh] views returns that layout, so the hand-back to [B, L, C] is a view either way."""
-    return Lk > SATTN_HIP_MIN_KEYS
-
-
-SATTN_HIP_MIN_KEYS = int(os.environ.get("UCE_SATTN_MIN_KEYS", "256"))     # (A/B runs only)
+def _hip_attention_ok(q: torch.Tensor, heads: int) -> bool:
+    dh = q.shape[-1] // heads
+    return hip16(q) and dh % 8 == 0 and dh <= 160 and q.shape[0] * heads <= 65535
 
 
 def _attention_core(q, k, v, heads: int, is_cross: bool):
-    """[B, L, C] in / out.  On a GPU in bf16/f16: cross-attention -> uce_xattn_fwd, self-attention -> uce_sattn_fwd;
-    otherwise torch SDPA."""
-    dh = q.shape[2] // heads
-    if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and dh % 8 == 0 and dh <= 160 \
-            and q.shape[0] * heads <= 65535:
+    """[B, L, C] in / out.  16-bit tensors on a GPU: cross-attention against <= 128 keys -> uce_xattn_fwd, everything else ->
+    uce_sattn_fwd (every attn1 layer, whatever its length); a head layout those kernels do not take RAISES - there is no
+    library attention behind the product path.  CPU / fp32 tensors (tests, comparison runs): torch SDPA."""
+    if hip16(q):
+        if not _hip_attention_ok(q, heads):
+            raise RuntimeError(f"attention with {heads} heads of {q.shape[-1] // heads} dims at batch {q.shape[0]} has no HIP kernel "
+                               "(head dim: a multiple of 8 up to 160; batch x heads <= 65535)")
         from .. import edit as _edit
         handle = _edit.UceHandle.get(q.device)
-        if is_cross and k.shape[1] <= 128 and USE_HIP_CROSS_ATTENTION:
+        if is_cross and k.shape[1] <= 128:
             return handle.xattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
-        if USE_HIP_SELF_ATTENTION and (USE_HIP_CROSS_ATTENTION or not is_cross) and sattn_prefers_hip(k.shape[1]):
-            return handle.sattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+        return handle.sattn(q.contiguous(), k.contiguous(), v.contiguous(), heads)
     B, Lq, C = q.shape
     dh = C // heads
 
@@ -328,9 +428,15 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim, inner * 2)
 
     def forward(self, x):
-        p = self.proj(x)
-        if USE_HIP_GROUPNORM and p.is_cuda and p.dtype in (torch.bfloat16, torch.float16) and p.is_contiguous() \
-                and (p.shape[-1] // 2) % 8 == 0:
+        w, b = self.proj.weight, self.proj.bias
+        inner = w.shape[0] // 2
+        if _hip_linear_ok(x, w, b) and inner % 16 == 0:
+            # hidden * gelu(gate) formed on the accumulators of the projection: the [rows, 2 * inner] tensor is never written
+            from .. import edit as _edit
+            wi, bi = derived(self, "geglu", _pkey(w, b), lambda: geglu_interleave(w.detach(), None if b is None else b.detach()))
+            return _edit.UceHandle.get(x.device).linear(x, wi, bi, geglu=True)
+        p = linear(self.proj, x)
+        if hip16(p) and p.is_contiguous() and inner % 8 == 0:
             from .. import edit as _edit
             return _edit.UceHandle.get(p.device).geglu(p)          # one pass instead of a strided gelu + multiply
         h, gate = p.chunk(2, dim=-1)
@@ -342,8 +448,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
 
-    def forward(self, x):
-        return self.net[2](self.net[0](x))
+    def forward(self, x, residual=None):
+        return linear(self.net[2], self.net[0](x), residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -357,10 +463,10 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        y = layer_norm(self.norm1, x)
-        x, y = add_layer_norm(self.norm2, self.attn1(y), x)          # x <- x + attn1(...), y = norm2(x)
-        x, y = add_layer_norm(self.norm3, self.attn2(y, context), x)
-        return x + self.ff(y)
+        # every residual join rides in the epilogue of the projection that produces its summand
+        x = self.attn1(layer_norm(self.norm1, x), residual=x)
+        x = self.attn2(layer_norm(self.norm2, x), context, residual=x)
+        return self.ff(layer_norm(self.norm3, x), residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -376,19 +482,20 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         B, C, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1).reshape(B, H * W, C)           # the residual as sequence rows (a view when channels-last)
         if self.linear_proj:
             h = group_norm_act(self.norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
-            h = self.proj_in(h)
+            h = linear(self.proj_in, h)
             for blk in self.transformer_blocks:
                 h = blk(h, context)
-            h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
-            return add_bias(x, h, None)
+            return linear(self.proj_out, h, residual=xr).reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = conv2d(self.proj_in, group_norm_act(self.norm, x, False))
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-        return add_bias(x, conv_nobias(self.proj_out, h), self.proj_out.bias)
+        return conv2d(self.proj_out, h, residual=x)
+
 
 
 class Downsample2D(nn.Module):
@@ -397,7 +504,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv2d(self.conv, x)
 
 
 class Upsample2D(nn.Module):
@@ -515,6 +622,37 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, Attention) and m.is_cross:
                 m.kv_cache = None if context is None else (m.to_k(context), m.to_v(context))
 
+    # -- the 22 (SDXL: 17 + ...) time projections of the ResnetBlock2Ds read the same `silu(temb)`: ONE linear launch over
+    #    their weights stacked along the rows (bias = time_emb_proj.bias + conv1.bias, the addend norm2's kernel takes),
+    #    each block then reads its column slice in place
+    def _hoist_time_projections(self, temb: torch.Tensor) -> None:
+        res = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        w0 = res[0].time_emb_proj.weight
+        if not (_hip_linear_ok(temb, w0, res[0].time_emb_proj.bias) and all(r.time_emb_proj.weight.shape[0] % 8 == 0 for r in res)):
+            for r in res:
+                r.temb_addend = None
+            return
+        params = [q for r in res for q in (r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias)]
+
+        def build():
+            W = torch.cat([r.time_emb_proj.weight.detach() for r in res]).contiguous()
+            bs = []
+            for r in res:
+                b = torch.zeros(r.time_emb_proj.weight.shape[0], dtype=torch.float32, device=W.device)
+                for t in (r.time_emb_proj.bias, r.conv1.bias):
+                    if t is not None:
+                        b = b + t.detach().float()
+                bs.append(b)
+            return W, torch.cat(bs).to(W.dtype).contiguous()
+
+        W, b = derived(self, "temb_cat", _pkey(*params), build)
+        ad = linear_w(F.silu(temb), W, b)
+        o = 0
+        for r in res:
+            c = r.time_emb_proj.weight.shape[0]
+            r.temb_addend = ad[:, o:o + c]
+            o += c
+
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
         t = timestep
         if not torch.is_tensor(t):
@@ -526,7 +664,8 @@ class UNet2DConditionModel(nn.Module):
             text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
             tid = timestep_embedding(time_ids.flatten(), self.cfg.addition_time_embed_dim).reshape(text_embeds.shape[0], -1)
             temb = temb + self.add_embedding(torch.cat([text_embeds, tid.to(text_embeds.dtype)], dim=-1).to(sample.dtype))
-        x = self.conv_in(sample)
+        self._hoist_time_projections(temb)
+        x = conv2d(self.conv_in, sample)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk(x, temb, encoder_hidden_states)
