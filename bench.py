@@ -634,7 +634,7 @@ def main() -> None:
     ap.add_argument("--gen-batch", type=int, default=16, help="prompts denoised per U-Net call")
     ap.add_argument("--gen-steps", type=int, default=50)
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs")
-    ap.add_argument("--only", default="", choices=["", "edit", "xattn", "sattn"],
+    ap.add_argument("--only", default="", choices=["", "edit", "xattn", "sattn", "generate"],
                     help="profiling runs (tools/prof_round.sh): only the edit timed region / only one attention leg, few launches")
     args = ap.parse_args()
 
@@ -669,6 +669,11 @@ def main() -> None:
         return
     if args.only == "sattn":
         print(json.dumps(sattn_leg(device, gb, iters=4, with_torch=False)), flush=True)
+        return
+    if args.only == "generate":         # the images/s leg alone (unedited synthetic weights), for A/B runs
+        g = generation_leg(device, world, args.gen_images, args.gen_steps, None, args.gen_batch)
+        if rank == 0:
+            print(json.dumps(g), flush=True)
         return
 
     r = run_edit(H, args.workload, device, args.steps, args.warmup, algo, world, breakdown=(rank == 0))

@@ -203,6 +203,11 @@ int uce_cfg_pndm_step(uce_handle_t h, const void* eps, int cfg, float guidance, 
  * x[:, :inner] * gelu(x[:, inner:]), bf16 or f16, inner % 8 == 0. */
 int uce_geglu_fwd(uce_handle_t h, const void* x, void* y, long rows, int inner, int dtype, uce_stream_t stream);
 
+/* Row softmax ahead of a P V product: p [rows, L] (bf16 / f16) = softmax(scale * s [rows, L]) with s in f32 - the middle step of
+ * the single-head, 512-dim attention of the VAE decoder's mid block (diffusers AutoencoderKL; too wide for the register-resident
+ * attention kernels), whose two products run on uce_linear_fwd.  L % 8 == 0, L <= 16384. */
+int uce_softmax_rows(uce_handle_t h, const float* s, void* p, long rows, int L, float scale, int dtype, uce_stream_t stream);
+
 /* LayerNorm over the last dim of [rows, C] (bf16 or f16, C % 8 == 0, C <= 2560; gamma / beta [C] in the same dtype;
  * f32 statistics) - the norm1/2/3 of diffusers' BasicTransformerBlock - optionally fused with the residual join in
  * front of it: when `residual` is given, s = x + residual is rounded to the element type, written to `sum_out`
@@ -239,10 +244,11 @@ int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const voi
  *   UCE_EPILOGUE_GEGLU:  y [M, N/2] = (hidden + b_h) * gelu(gate + b_g), erf form (diffusers GEGLU); w / bias hold the hidden
  *                        and gate rows INTERLEAVED per 32: row 32 t + r = hidden row 16 t + r (r < 16), gate row 16 t + r - 16
  *                        (r >= 16); no residual.
+ *   UCE_EPILOGUE_F32  :  as NONE with y [M, N] in f32 (16-byte aligned): attention scores ahead of uce_softmax_rows.
  * bf16 or f16 elements, f32 accumulation; ldx / ldr / ldy = row strides in elements (operands may be column slices of wider
  * tensors).  K % 32 == 0, N % 4 == 0 (GEGLU: N % 32 == 0), ldx % 8 == 0, ldy % 4 == 0, ldr % 4 == 0; x, w 16-byte aligned, the
  * others 8-byte aligned; bias / residual may be NULL. */
-enum { UCE_EPILOGUE_NONE = 0, UCE_EPILOGUE_GEGLU = 1 };
+enum { UCE_EPILOGUE_NONE = 0, UCE_EPILOGUE_GEGLU = 1, UCE_EPILOGUE_F32 = 2 };
 int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr,
                    void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream);
 

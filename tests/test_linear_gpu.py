@@ -67,22 +67,27 @@ def test_linear_matches_fp64(H, M, N, K, dtype, bias, res):
     assert torch.equal(y, H.linear(x, w, b, r))           # bit-repeatable
 
 
-@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128"])
+@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128", "2128320", "3128256", "3256128"])
 @pytest.mark.parametrize("M,N,K", [(700, 960, 320), (256, 640, 96)])
 def test_linear_every_tile_form_forced(tile, M, N, K):
-    """UCE_GEMM_TILE pins one tile form for every call (read at uce_create): each form on shapes with ragged row and column
-    tiles, with bias + residual."""
+    """UCE_GEMM_TILE pins one tile form for every call (read at uce_create): each form - the last three are the shallow rings
+    that put two workgroups on a CU - on shapes with ragged row and column tiles, with bias + residual, and with the GEGLU
+    epilogue."""
     Hv = _handle_with("UCE_GEMM_TILE", tile)
     g = torch.Generator().manual_seed(int(tile) + M)
     x, w = _rand((M, K), g, torch.bfloat16), _rand((N, K), g, torch.bfloat16, K ** -0.5)
     b, r = _rand((N,), g, torch.bfloat16), _rand((M, N), g, torch.bfloat16)
+    from uce_amd.sd import unet as U
+    wi, bi = U.geglu_interleave(w, b)
     try:
         y = Hv.linear(x, w, b, r)
+        yg = Hv.linear(x, wi, bi, geglu=True)
         torch.cuda.synchronize()
     finally:
         Hv.close()
-    want = x.double() @ w.double().T + b.double() + r.double()
-    assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[torch.bfloat16]
+    p = x.double() @ w.double().T + b.double()
+    assert O.rel_fro(y.double().cpu(), (p + r.double()).cpu()) < TOL[torch.bfloat16]
+    assert O.rel_fro(yg.double().cpu(), (p[:, :N // 2] * F.gelu(p[:, N // 2:])).cpu()) < TOL[torch.bfloat16]
 
 
 @pytest.mark.parametrize("M,C,dtype", [(4096, 320, torch.bfloat16), (1000, 640, torch.bfloat16), (300, 1280, torch.float16),
@@ -234,3 +239,27 @@ def test_unet_forward_matches_its_torch_twin_and_hoists_time_projections():
     with torch_ops():
         b = pipe.unet(x, t, ctx).float()
     assert O.rel_fro(a.cpu(), b.cpu()) < 3e-2
+
+
+def test_vae_attention_on_the_linear_kernel_matches_its_torch_twin(H):
+    """The VAE mid-block attention (one head, 512 dims): q k^T (f32 scores) -> uce_softmax_rows -> P v on uce_linear_fwd, against
+    the same module through torch's SDPA; and the row softmax alone against fp64."""
+    from tests.torch_twin import torch_ops
+    from uce_amd.sd import pipeline as sdp
+    torch.manual_seed(5)
+    att = sdp._VaeAttention(512).to("cuda", torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    x = _rand((2, 512, 32, 32), g, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    a = att(x).float()
+    with torch_ops():
+        b = att(x).float()
+    ref = att.float()(x.float())
+    ea, eb = O.rel_fro(a.cpu(), ref.cpu()), O.rel_fro(b.cpu(), ref.cpu())
+    assert ea < 1.5 * eb + 2e-3, (ea, eb)
+    s = _rand((300, 4096), g, torch.float32, 3.0)
+    p = H.softmax_rows(s, 0.25, torch.bfloat16)
+    want = torch.softmax(s.double() * 0.25, dim=-1)
+    assert O.rel_fro(p.double().cpu(), want.cpu()) < 4e-3
+    y = H.linear_f32(x.permute(0, 2, 3, 1).reshape(-1, 512)[:700], att.to_q.weight.to(torch.bfloat16))
+    assert y.dtype == torch.float32
+    assert O.rel_fro(y.double().cpu(), (x.permute(0, 2, 3, 1).reshape(-1, 512)[:700].double() @ att.to_q.weight.double().T).cpu()) < 1e-5

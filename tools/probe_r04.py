@@ -59,9 +59,11 @@ def gemm():
         if tag == "ff_proj":
             ent["torch_geglu_us"] = timeit(lambda: H0.geglu(F.linear(x, w, b)))
             ent["own_geglu_us"] = timeit(lambda: H0.linear(x, w, b, geglu=True))
-        for tile in (256320, 128320, 256256, 128256):
+        for tile in (256320, 128320, 256256, 128256, 2128320, 3128256, 3256128):
             Hv = handle(UCE_GEMM_TILE=tile)
             ent[f"t{tile}_us"] = timeit(lambda: Hv.linear(x, w, b))
+            if tag == "ff_proj":
+                ent[f"g{tile}_us"] = timeit(lambda: Hv.linear(x, w, b, geglu=True))
             torch.cuda.synchronize()
             Hv.close()
         ent["own_TFs"] = ent["gflop"] / ent["own_us"] * 1e-3

@@ -72,12 +72,13 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_SATTN_VTI       0: V^T of the self-attention transposed on the way into LDS up to 1024 keys, by the k_vt pre-pass beyond |
 //                       1: always inline | 2: always the pre-pass
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
+//   UCE_WIDE_EPILOGUE   1: GEMM / convolution tiles leave through LDS in whole rows | 0: 8 bytes per lane from the accumulators
 //   UCE_GEMM_TILE       0: tile of uce_linear_fwd by rule | 1000 * BM + BN (256320, 256256, 128320, 128256, 256128): forced
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile;
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -180,7 +181,7 @@ int uce_ensure(uce_ctx* h, int d, int n);
 // uce_conv_dma.hip: 1 = launched (*rc = status), 0 = shape not taken by the direct-to-LDS form
 // (the caller decides by UceSwitches::conv_dma whether to ask)
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
-                    int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0);
+                    int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0, int wide = 1);
 
 int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
                        int d, float lamb, double* A, double* Bt, hipStream_t st, int which = 0);

@@ -21,6 +21,7 @@
 //     before the first read); a stage is re-filled only after the barrier that follows its last read.
 // Measured against the register-staged 128 x 128 kernel in tools/probe_igemm.py; DESIGN.md section 4.
 #include "uce_common.h"
+#include "uce_epilogue.h"
 
 namespace {
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ void cd_wait_two_tiles(int per) {
   else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16>
+template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE>
 __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                      long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
@@ -194,7 +195,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
 
-  // ---- epilogue: + bias, convert, 8-byte stores (a lane holds 4 consecutive output channels of one pixel)
+  // ---- epilogue: + bias (+ residual), convert; whole rows through LDS (uce_epilogue.h) or 8-byte stores (a lane holds 4
+  //      consecutive output channels of one pixel)
+  if constexpr (WIDE) {
+    __builtin_amdgcn_s_barrier();                                      // every wave's tail re-loads have landed: the ring is free
+    uce_epi::store_rows<TM, TN, F16, false>(acc, smem + w * uce_epi::wave_bytes<TN, false>(), bias, Rs, (long)Cout, Y, (long)Cout,
+                                            m0 + wm * TM * 32, n0 + wn * TN * 32, M, Cout, lane);
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     }
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, bool WIDE>
 int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
                hipStream_t st, int sd, const void* res) {
   constexpr int BM = 32 * TM * WGM;
@@ -240,16 +248,16 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
   const size_t smem = cd_smem<BM, BN>();
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
                        (int)mtiles, ntiles, sd, (const unsigned short*)res);
   else
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
                        (int)mtiles, ntiles, sd, (const unsigned short*)res);
   UCE_LAUNCH_CHECK();
@@ -263,7 +271,7 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
 // still gives every CU a workgroup, else 128 pixels, else (the 8 x 8 layers: 2048 pixels at the generation batch) 128 x 128.
 // `force` (UCE_CONV_TILE = 1000 * BM + BN) pins one for measurements.
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
-                    int dtype, hipStream_t st, int* rc, int sd, const void* res, int force) {
+                    int dtype, hipStream_t st, int* rc, int sd, const void* res, int force, int wide) {
   *rc = UCE_OK;
   if (Cin % CD_BK || Cout % 4) return 0;
   int bn = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : Cout % 128 == 0 ? 128 : 0;
@@ -274,7 +282,13 @@ int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, lon
   if (bm == 128 && t128 < 200 && Cout % 128 == 0) bn = 128;
   if (force > 0) { bm = force / 1000; bn = force % 1000; }
   if (Cout % bn) return 0;
-#define UCE_CD(WGM, WGN, TM, TN) { *rc = launch_dma<WGM, WGN, TM, TN>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res); return 1; }
+  const bool wide_ok = wide && Cout % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)res & 15);
+#define UCE_CD(WGM, WGN, TM, TN)                                                                                             \
+  {                                                                                                                          \
+    *rc = wide_ok ? launch_dma<WGM, WGN, TM, TN, true>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res)            \
+                  : launch_dma<WGM, WGN, TM, TN, false>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res);          \
+    return 1;                                                                                                                \
+  }
   if (bm == 256 && bn == 320) UCE_CD(4, 2, 2, 5)
   if (bm == 256 && bn == 256) UCE_CD(2, 4, 4, 2)
   if (bm == 256 && bn == 128) UCE_CD(4, 2, 2, 2)

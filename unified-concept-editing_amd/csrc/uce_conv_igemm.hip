@@ -256,7 +256,7 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
     // stride-2 taps and the residual epilogue
     int rc;                                                  // UCE_CONV_DMA=0 (read at uce_create): always the 128 x 128 kernel
     if (h->sw.conv_dma != 0 && launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual,
-                                               h->sw.conv_tile))
+                                               h->sw.conv_tile, h->sw.wide_epilogue))
       return rc;
   }
   if (stride != 1 || residual) return UCE_ENOSYS;            // only the direct-to-LDS form has them

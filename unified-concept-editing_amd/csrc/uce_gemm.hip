@@ -18,6 +18,7 @@
 // 16 t + (r - 16) for r >= 16, so that every 32-row MFMA tile holds 16 outputs' hidden AND gate values and a lane's
 // registers 0..7 (hidden) pair with its registers 8..15 (gate).
 #include "uce_common.h"
+#include "uce_epilogue.h"
 
 namespace {
 
@@ -30,7 +31,7 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int GD_BK = 32, GD_NST = 4;
+constexpr int GD_BK = 32;
 
 template <bool F16>
 __device__ __forceinline__ float16_t gd_mfma(uint4_t a, uint4_t b, float16_t c) {
@@ -58,22 +59,30 @@ __device__ __forceinline__ void gd_unpack4(uint2_t v, float* f) {
   f[3] = gd_tof<F16>((unsigned short)(v[1] >> 16));
 }
 
-// waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 2 .. 5)
-__device__ __forceinline__ void gd_wait_two_tiles(int per) {
-  if (per == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-  else if (per == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  else if (per == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-  else if (per == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+// waits until at most `n` of this wave's LDS-DMAs are outstanding (n = tiles left in flight x its DMAs per k-tile, 2 .. 5)
+__device__ __forceinline__ void gd_wait_dma(int n) {
+  if (n >= 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+  else if (n == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if (n == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU>
-__global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
+// WIDE: the tile leaves through LDS in whole rows (uce_epilogue.h; needs 16-byte aligned rows of y / residual and N % 8 == 0),
+// else 8 bytes per lane straight from the accumulators
+// NST: LDS stages of the ring (NST - 1 k-tiles in flight).  4 = one workgroup per CU with a deep ring; 2 / 3 = a ring shallow
+// enough (<= 80 KB with the epilogue's slabs) that TWO workgroups share a CU - one's prologue / epilogue under the other's main
+// loop, what the short contractions (K = 320: ten k-tiles per output tile) need.
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST>
+__global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
                                                   const unsigned short* __restrict__ Wt,
                                                   const unsigned short* __restrict__ bias,
                                                   const unsigned short* __restrict__ R, long ldr,
                                                   unsigned short* __restrict__ Y, long ldy, long M, int N, int K,
-                                                  int mtiles, int ntiles) {
+                                                  int mtiles, int ntiles, int outf32) {
   static_assert(WGM * WGN == 8, "eight waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(BM == 128 || BM == 256, "A image: one or two 16-row DMA instructions per wave");
@@ -152,14 +161,15 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restri
   for (int a = 0; a < TN; ++a) brow[a] = (wn * TN + a) * 32 + li;
 
   const int last = NK - 1;                                             // (past the last tile the ring re-loads it: constant counts)
-  stage(0, 0);
-  stage(1, 1 < last ? 1 : last);
-  stage(2, 2 < last ? 2 : last);
-  gd_wait_two_tiles(per);
+  constexpr int AHEAD = NST - 1;                                       // k-tiles in flight
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) stage(i, i < last ? i : last);
+  gd_wait_dma((AHEAD - 1) * per);
   __builtin_amdgcn_s_barrier();
+  int slot = 0, fill = AHEAD;                                          // ring positions of tile kt and of tile kt + AHEAD
   for (int kt = 0; kt < NK; ++kt) {
-    stage((kt + 3) & 3, kt + 3 < last ? kt + 3 : last);
-    const unsigned char* Ab = smem + (kt & 3) * STAGE;
+    stage(fill, kt + AHEAD < last ? kt + AHEAD : last);
+    const unsigned char* Ab = smem + slot * STAGE;
     const unsigned char* Bb = Ab + BM * 64;
 #pragma unroll
     for (int s = 0; s < GD_BK / 16; ++s) {
@@ -174,13 +184,20 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restri
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = gd_mfma<F16>(cf[a], pf[b], acc[a][b]);   // rows = columns of Y, columns = rows of Y
     }
-    gd_wait_two_tiles(per);                                            // this wave's part of tile kt + 1 has landed
+    gd_wait_dma((AHEAD - 1) * per);                                    // this wave's part of tile kt + 1 has landed
     __builtin_amdgcn_s_barrier();
+    slot = slot + 1 == NST ? 0 : slot + 1;
+    fill = fill + 1 == NST ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
 
   // ---- epilogue.  Register 4 g + i of tile a = column n0 + (wn TN + a) 32 + 8 g + 4 lh + i, row m0 + (wm TM + b) 32 + li
-  if constexpr (GEGLU) {
+  if constexpr (WIDE) {
+    __builtin_amdgcn_s_barrier();                                      // every wave's tail re-loads have landed: the ring is free
+    constexpr int CH = (NST == 4 || TN < 2) ? TN : 2;                  // (shallow ring: the slabs must fit the smaller allocation)
+    uce_epi::store_rows<TM, TN, F16, GEGLU, CH>(acc, smem + w * uce_epi::wave_bytes<CH, GEGLU>(), bias, R, ldr, Y, ldy,
+                                                m0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane);
+  } else if constexpr (GEGLU) {
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restri
             for (int i = 0; i < 4; ++i) {
               const float hv = acc[a][b][4 * g + i] + bh[i];
               const float gv = acc[a][b][4 * (g + 2) + i] + bg[i];
-              o[i] = hv * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
+              o[i] = hv * uce_epi::gelu_erf(gv);
             }
             const uint2_t o2 = {gd_pack2<F16>(o[0], o[1]), gd_pack2<F16>(o[2], o[3])};
             *(uint2_t*)(Y + m * ldy + no) = o2;
@@ -222,6 +239,11 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restri
           if (m < M && n < N) {
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (R) gd_unpack4<F16>(*(const uint2_t*)(R + m * ldr + n), rv);
+            if (outf32) {                                                // f32 result (attention scores ahead of a softmax)
+              *(float4_t*)((float*)Y + m * ldy + n) = (float4_t){acc[a][b][4 * g] + bv[0] + rv[0], acc[a][b][4 * g + 1] + bv[1] + rv[1],
+                                                                 acc[a][b][4 * g + 2] + bv[2] + rv[2], acc[a][b][4 * g + 3] + bv[3] + rv[3]};
+              continue;
+            }
             const uint2_t o = {gd_pack2<F16>(acc[a][b][4 * g] + bv[0] + rv[0], acc[a][b][4 * g + 1] + bv[1] + rv[1]),
                                gd_pack2<F16>(acc[a][b][4 * g + 2] + bv[2] + rv[2], acc[a][b][4 * g + 3] + bv[3] + rv[3])};
             *(uint2_t*)(Y + m * ldy + n) = o;
@@ -231,36 +253,40 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const unsigned short* __restri
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU>
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST>
 int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
-               int K, hipStream_t st) {
+               int K, hipStream_t st, int outf32 = 0) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  static_assert(NST == 4 || WIDE, "the shallow rings exist with the whole-row epilogue only");
   const long mtiles = (M + BM - 1) / BM;
   const int ntiles = (N + BN - 1) / BN;
   const long nwg = mtiles * ntiles;
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
-  const size_t smem = (size_t)GD_NST * (BM + BN) * GD_BK * 2;
+  constexpr size_t ring = (size_t)NST * (BM + BN) * GD_BK * 2;
+  constexpr size_t slabs = WIDE ? (size_t)8 * uce_epi::wave_bytes<(NST == 4 || TN < 2) ? TN : 2, GEGLU>() : 0;
+  constexpr size_t smem = ring > slabs ? ring : slabs;
+  static_assert(NST == 4 || smem <= 80 * 1024, "two workgroups per CU");
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
     attr_once.commit(tok);
   }
-  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                      ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
-                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles);
+                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4>
 int launch_shape(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
-                 int K, int geglu, int dtype, hipStream_t st) {
+                 int K, int geglu, int dtype, hipStream_t st, int outf32 = 0) {
   if (dtype == UCE_DTYPE_F16)
-    return geglu ? launch_one<WGM, WGN, TM, TN, true, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-                 : launch_one<WGM, WGN, TM, TN, true, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st);
-  return geglu ? launch_one<WGM, WGN, TM, TN, false, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-               : launch_one<WGM, WGN, TM, TN, false, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st);
+    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
+                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32);
+  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
+               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32);
 }
 
 // padded MFMA work of an N-wide output on BN-wide tiles, relative
@@ -271,7 +297,7 @@ inline long waste(int N, int BN) { return (long)((N + BN - 1) / BN) * BN; }
 // tile choice: the column width that wastes the fewest MFMAs on N (320 tiles SD's 320 / 640 / 1280 / 2560 ... exactly,
 // 256 the VAE's and the text encoder's widths), and 128-row tiles when 256-row tiles would leave CUs without a workgroup
 int launch_linear(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
-                  int K, int geglu, int dtype, hipStream_t st, int force_tile) {
+                  int K, int geglu, int dtype, hipStream_t st, int force_tile, int wide, int outf32) {
   const long w320 = waste(N, 320), w256 = waste(N, 256), w128 = waste(N, 128);
   int bn = 320;
   if (w256 < w320) bn = 256;
@@ -279,12 +305,25 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   long tiles256 = ((M + 255) / 256) * ((N + bn - 1) / bn);
   int bm = (tiles256 < 256 && M > 128) ? 128 : 256;
   if (bn == 128) bm = 256;
-  if (force_tile > 0) { bm = force_tile / 1000; bn = force_tile % 1000; }
-  if (bm == 256 && bn == 320) return launch_shape<4, 2, 2, 5>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
-  if (bm == 256 && bn == 256) return launch_shape<2, 4, 4, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
-  if (bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
-  if (bm == 128 && bn == 256) return launch_shape<2, 4, 2, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
-  if (bm == 256 && bn == 128) return launch_shape<4, 2, 2, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  int nst = 4;
+  if (force_tile > 0) { nst = force_tile >= 1000000 ? force_tile / 1000000 : 4; bm = (force_tile / 1000) % 1000; bn = force_tile % 1000; }
+  // whole-row epilogue where the rows allow 16-byte accesses (every layer of the U-Net); `wide` = 0 keeps the per-lane stores
+  const int nout = geglu ? N / 2 : N;
+  const bool wide_ok = wide && !outf32 && nout % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && (!res || (ldr % 8 == 0 && !((uintptr_t)res & 15)));
+  if (!wide_ok) nst = 4;
+  // two workgroups per CU (shallow ring): UCE_GEMM_TILE = 2128320 / 3128256 / 3256128
+  if (nst == 2 && bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  if (nst == 3 && bm == 128 && bn == 256) return launch_shape<2, 4, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  if (nst == 3 && bm == 256 && bn == 128) return launch_shape<4, 2, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+#define UCE_GD(WGM, WGN, TM, TN)                                                                                                  \
+  return wide_ok ? launch_shape<WGM, WGN, TM, TN, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st)            \
+                 : launch_shape<WGM, WGN, TM, TN, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, outf32);
+  if (bm == 256 && bn == 320) { UCE_GD(4, 2, 2, 5) }
+  if (bm == 256 && bn == 256) { UCE_GD(2, 4, 4, 2) }
+  if (bm == 128 && bn == 320) { UCE_GD(4, 2, 1, 5) }
+  if (bm == 128 && bn == 256) { UCE_GD(2, 4, 2, 2) }
+  if (bm == 256 && bn == 128) { UCE_GD(4, 2, 2, 2) }
+#undef UCE_GD
   return UCE_EINVAL;
 }
 
@@ -293,22 +332,25 @@ extern "C" int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const voi
   if (!h || !x || !w || !y || M <= 0 || N <= 0 || K <= 0) return UCE_EINVAL;
   UCE_ENTER(h);
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
-  if (epilogue != UCE_EPILOGUE_NONE && epilogue != UCE_EPILOGUE_GEGLU) return UCE_EINVAL;
-  const int geglu = epilogue == UCE_EPILOGUE_GEGLU;
+  if (epilogue != UCE_EPILOGUE_NONE && epilogue != UCE_EPILOGUE_GEGLU && epilogue != UCE_EPILOGUE_F32) return UCE_EINVAL;
+  const int geglu = epilogue == UCE_EPILOGUE_GEGLU, outf32 = epilogue == UCE_EPILOGUE_F32;
   // 64-byte k-tiles, 8-byte epilogue accesses, 16-byte DMA pieces
   if (K % GD_BK || N % 4 || ldx < K || ldx % 8 || ldy % 4 || (residual && (ldr % 4 || geglu))) return UCE_EINVAL;
   if (geglu && N % 32) return UCE_EINVAL;
   if (ldy < (geglu ? N / 2 : N) || (residual && ldr < N)) return UCE_EINVAL;
   if ((((uintptr_t)x | (uintptr_t)w) & 15) || (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 7)) return UCE_EINVAL;
+  if (outf32 && ((uintptr_t)y & 15)) return UCE_EINVAL;
   // 32-bit buffer offsets: rows are walked in chunks whose X image stays under 2 GB
   const long max_rows = ((1L << 31) - 1 - 2L * K) / (2 * ldx) + 1;
   if ((long)N * K * 2 >= (1L << 31)) return UCE_EINVAL;
   const int force = h->sw.gemm_tile;
+  const long ybytes = outf32 ? 4 : 2;
   for (long m0 = 0; m0 < M; m0 += max_rows) {
     const long mb = (M - m0 < max_rows) ? M - m0 : max_rows;
     const int rc = launch_linear((const unsigned short*)x + m0 * ldx, ldx, w, bias,
                                  residual ? (const void*)((const unsigned short*)residual + m0 * ldr) : nullptr, ldr,
-                                 (unsigned short*)y + m0 * ldy, ldy, mb, N, K, geglu, dtype, (hipStream_t)stream, force);
+                                 (unsigned char*)y + m0 * ldy * ybytes, ldy, mb, N, K, geglu, dtype, (hipStream_t)stream, force,
+                                 h->sw.wide_epilogue, outf32);
     if (rc != UCE_OK) return rc;
   }
   return UCE_OK;

@@ -530,3 +530,74 @@ extern "C" int uce_layernorm_fwd(uce_handle_t h, const void* x, const void* resi
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
+
+// -------------------------------------------------------------------------------------------------------------
+// Row softmax between the two products of the VAE mid-block attention (one head of 512 dims: diffusers AutoencoderKL's
+// `Attention` under `pipe(...).images`, evalscripts/generate-images-sd.py:37-42 -> vae.decode): s [rows, L] f32 scores in,
+// p [rows, L] 16-bit probabilities out.  One workgroup per row: the row (<= 64 KB) lives in registers (up to 16 floats per
+// thread), max and sum by wave shuffles + one LDS exchange, f32 arithmetic, one rounding.
+// -------------------------------------------------------------------------------------------------------------
+namespace {
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+template <bool F16>
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ s, unsigned short* __restrict__ p, int L, float scale_log2e) {
+  __shared__ float red[8];
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* src = s + row * L;
+  unsigned short* dst = p + row * L;
+  constexpr int MAXQ = 16;                           // quads (4 floats) per thread: L <= 256 * 4 * 16 = 16384
+  float4_t v[MAXQ];
+  const int nq = L / 4;
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int q = tid + 256 * i;
+    if (q < nq) {
+      v[i] = *(const float4_t*)(src + 4 * q);
+      m = fmaxf(m, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float mc = m * scale_log2e;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int q = tid + 256 * i;
+    if (q < nq) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][j] = __builtin_amdgcn_exp2f(fmaf(v[i][j], scale_log2e, -mc));
+        sum += v[i][j];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int q = tid + 256 * i;
+    if (q < nq) *(uint2_t*)(dst + 4 * q) = (uint2_t){pack2<F16>(v[i][0] * inv, v[i][1] * inv), pack2<F16>(v[i][2] * inv, v[i][3] * inv)};
+  }
+}
+}  // namespace
+
+extern "C" int uce_softmax_rows(uce_handle_t h, const float* s, void* p, long rows, int L, float scale, int dtype, uce_stream_t stream) {
+  if (!h || !s || !p || rows <= 0 || L <= 0 || L % 8 || L > 16384 || rows > 0x7fffffffL || !(scale > 0.f)) return UCE_EINVAL;
+  UCE_ENTER(h);
+  if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
+  const float sl2 = scale * 1.4426950408889634f;
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL(k_softmax_rows<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (unsigned short*)p, L, sl2);
+  else
+    hipLaunchKernelGGL(k_softmax_rows<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (unsigned short*)p, L, sl2);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}

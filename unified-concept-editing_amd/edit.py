@@ -411,6 +411,25 @@ class UceHandle:
                    "uce_linear_fwd")
         return y
 
+    def linear_f32(self, x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """`x @ weight.T` with an f32 result ([M, N]; x [M, K], weight [N, K] 16-bit): attention scores ahead of softmax_rows."""
+        M, K = x.shape
+        N = weight.shape[0]
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.uce_linear_fwd(self._h, _ptr(x), x.stride(0), _ptr(weight), None, None, 0, _ptr(y), N, M, N, K,
+                                           _lib.EPILOGUE_F32, dt, _stream_ptr(self.device)), "uce_linear_fwd")
+        return y
+
+    def softmax_rows(self, s: torch.Tensor, scale: float, dtype: torch.dtype) -> torch.Tensor:
+        """softmax(scale * s) over the last dim of an f32 [rows, L] tensor -> 16-bit, through uce_softmax_rows."""
+        rows, L = s.shape
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[dtype]
+        p = torch.empty(rows, L, dtype=dtype, device=s.device)
+        _lib.check(self.lib.uce_softmax_rows(self._h, _ptr(s), _ptr(p), rows, L, float(scale), dt, _stream_ptr(self.device)),
+                   "uce_softmax_rows")
+        return p
+
     def geglu(self, x: torch.Tensor) -> torch.Tensor:
         """x [..., 2*inner] -> x[..., :inner] * gelu(x[..., inner:]) through uce_geglu_fwd."""
         inner = x.shape[-1] // 2

@@ -11,7 +11,7 @@ from . import build as _build
 OK, EINVAL, ENOMEM, EDOM, ENOSYS, ECOMM = 0, -22, -12, -33, -38, -70
 ALGO_AUTO, ALGO_PRIMAL, ALGO_DUAL = 0, 1, 2
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
-EPILOGUE_NONE, EPILOGUE_GEGLU = 0, 1
+EPILOGUE_NONE, EPILOGUE_GEGLU, EPILOGUE_F32 = 0, 1, 2
 
 _vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "uce_im2col3x3_c4": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "uce_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "uce_linear_fwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp]),
+    "uce_softmax_rows": (_i, [_vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     "uce_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
 }
 

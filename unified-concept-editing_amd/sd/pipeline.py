@@ -27,6 +27,7 @@ from .scheduler import EulerDiscreteScheduler, PNDMScheduler
 # ("naive", f64-accumulating) solver is one of them and costs ~18 s of start-up per process at
 # batch 2 (48 ms average over 384 calls in profiles/r01), far more at larger batches.  It never wins.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+from . import unet as _unet
 from .unet import UNet2DConditionModel, UNetConfig, conv2d, group_norm_act, linear, upsample2x_conv
 
 MAX_LEN = 77
@@ -117,9 +118,25 @@ class _VaeAttention(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        xr = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        L = H * W
+        if _unet.hip16(h) and C % 32 == 0 and L % 32 == 0 and L <= 16384 and self.to_v.weight.dtype == h.dtype:
+            # ONE head of C = 512 dims: too wide for the register-resident attention kernels, so per image the two products
+            # run on the linear kernel around a row softmax (scores in f32):  S = q k^T,  P = softmax(S / sqrt(C)),
+            # O = P v + b_v (rows of P sum to one).  v^T comes straight out of its projection with the operands swapped
+            # (v^T = W_v h^T), so nothing is transposed.
+            from .. import edit as _edit
+            hd = _edit.UceHandle.get(h.device)
+            q, k = linear(self.to_q, h), linear(self.to_k, h)
+            o = torch.empty_like(q)
+            wv, bv = self.to_v.weight, self.to_v.bias
+            for i in range(B):
+                vt = hd.linear(wv, h[i])                                   # [C, L]
+                p = hd.softmax_rows(hd.linear_f32(q[i], k[i]), C ** -0.5, h.dtype)
+                hd.linear(p, vt, bv, out=o[i])
+            return linear(self.to_out[0], o, residual=xr).reshape(B, H, W, C).permute(0, 3, 1, 2)
         o = F.scaled_dot_product_attention(linear(self.to_q, h)[:, None], linear(self.to_k, h)[:, None],
                                            linear(self.to_v, h)[:, None])[:, 0]
-        xr = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
         return linear(self.to_out[0], o, residual=xr).reshape(B, H, W, C).permute(0, 3, 1, 2)
 
 
