@@ -100,16 +100,26 @@ def physical_cores() -> int:
         return 0
 
 
-def cpu_baseline(inp, repeats: int = 5):
+def cpu_baseline(inp, repeats: int = 5, sweep_threads: bool = True, modules: int = 0, threads: int = 0):
     """The oracle (the reference's own op order on torch CPU: sequential rank-1 fp32 updates, torch.inverse and a
     GEMM per module, uce_sd_erase.py:56-82) timed on the host cores: WHOLE edits of all modules, a fixed thread
-    count, the median of `repeats` runs after one untimed run (bounded sample: ~1.5 s per whole 50-concept edit)."""
+    count, the median of `repeats` runs after one untimed run (bounded sample: ~1.5 s per whole 50-concept edit).
+    `modules` > 0: a bounded sample for the large configs - only the first `modules` modules of the slab are edited (the
+    reference's loop over modules is a plain sequence of independent iterations, uce_sd_erase.py:56) and the time is scaled
+    by rows_total / rows_sampled; the line says so.  `threads` > 0: no sweep, that thread count."""
     from oracle import uce_oracle as O
     Wc = inp["W"].cpu()
     ws, off = [], 0
     for _, o in inp["mods"]:
         ws.append(Wc[off:off + o])
         off += o
+    n_mod = len(ws)
+    scale_up = 1.0
+    if modules and modules < n_mod:
+        # evenly strided through the table, so that the sample mixes the module widths as the table does (the per-module cost
+        # depends on the width: SD-1.4's 32 modules are 320 / 640 / 1280 rows)
+        ws = ws[::n_mod // modules][:modules]
+        scale_up = n_mod / float(len(ws))
     C, G = inp["C"].cpu(), inp["G"].cpu()
     n_e, n_p = inp["n_e"], inp["n_p"]
     edit = [C[i:i + 1] for i in range(n_e)]
@@ -120,22 +130,24 @@ def cpu_baseline(inp, repeats: int = 5):
     def whole():
         t = time.perf_counter()
         O.uce_edit_ref(ws, edit, guide, pres, 1.0, 1.0, 0.5)
-        return time.perf_counter() - t
+        return (time.perf_counter() - t) * scale_up
 
     # thread sweep, one whole edit each after one untimed run (the reference's op order is ~10^4 small torch ops per edit:
-    # it does not scale with cores; SURVEY 8d asks for the count to be stated): the fastest count runs the timed sample
-    torch.set_num_threads(min(CPU_BASELINE_THREADS, ncpu))
+    # it does not scale with cores; SURVEY 8d asks for the count to be stated): the fastest count runs the timed sample.
+    # 1 and 8 are in the sweep on purpose: one core is the scalar port, 8 is the survey container's count.
+    first = threads if threads > 0 else min(CPU_BASELINE_THREADS, ncpu)
+    torch.set_num_threads(first)
     whole()
     sweep = {}
-    if repeats >= 5:
-        for th in sorted({min(CPU_BASELINE_THREADS, ncpu), min(16, ncpu), min(64, ncpu), ncpu}):
+    if threads <= 0 and sweep_threads and repeats >= 5:
+        for th in sorted({1, min(CPU_BASELINE_THREADS, ncpu), min(8, ncpu), min(16, ncpu), min(64, ncpu), ncpu}):
             torch.set_num_threads(th)
             sweep[str(th)] = round(whole(), 4)
-            if sweep[str(th)] > 4.0 * min(sweep.values()):
+            if th >= 16 and sweep[str(th)] > 3.0 * min(sweep.values()):
                 break                                        # far slower already: do not spend the budget on larger counts
         threads = int(min(sweep, key=sweep.get))
-    else:
-        threads = min(CPU_BASELINE_THREADS, ncpu)
+    elif threads <= 0:
+        threads = first
     torch.set_num_threads(threads)
     times = []
     t0 = time.perf_counter()
@@ -145,12 +157,28 @@ def cpu_baseline(inp, repeats: int = 5):
             break
     med = statistics.median(times)
     n = n_e + n_p
+    sample = (f"{len(times)} whole edits (all {n_mod} modules, {n} concepts) after one untimed run" if scale_up == 1.0 else
+              f"{len(times)} edits of {len(ws)} of the {n_mod} modules (evenly strided; {n} concepts) after one untimed run, time x {scale_up:.1f} "
+              f"(the reference edits module after module)")
     return dict(value=round(n / med, 2), unit="concepts/s", cores=threads, kind="port",
                 cpu=cpu_model(), physical_cores=physical_cores(), logical_cpus=ncpu,
                 seconds_per_edit=dict(median=round(med, 4), min=round(min(times), 4), max=round(max(times), 4)),
                 thread_sweep_seconds_per_edit=sweep,
-                sample=f"{len(times)} whole edits (all {len(ws)} modules, {n} concepts) after one untimed run, median "
-                       f"{med:.3f} s, on {threads} torch threads of {ncpu} logical CPUs")
+                sample=f"{sample}, median {med:.3f} s, on {threads} torch threads of {ncpu} logical CPUs")
+
+
+def cpu_baseline_configs(device, threads: int):
+    """The same CPU port for the other single-GPU BASELINE configs, each a bounded sample (a few seconds of host work) at the
+    thread count the headline sweep found fastest."""
+    out = []
+    for name, mods, reps in (("sd14_erase2p3", 0, 3), ("sd14_erase100", 8, 3), ("sd14_erase1000p500", 2, 1), ("sdxl_debias36x2", 4, 1)):
+        try:
+            b = cpu_baseline(make_inputs(name, "cpu"), repeats=reps, sweep_threads=False, modules=mods, threads=threads)
+            out.append({"workload": name, "value": b["value"], "unit": b["unit"], "cores": b["cores"],
+                        "seconds_per_edit": b["seconds_per_edit"]["median"], "sample": b["sample"]})
+        except Exception as err:  # noqa: BLE001
+            out.append({"workload": name, "error": repr(err)})
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -401,7 +429,7 @@ def _scalar_device(device):
 
 
 def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_id="CompVis/stable-diffusion-v1-4",
-                   dtype=torch.bfloat16, vae=True):
+                   dtype=torch.bfloat16, vae=True, rowwise_images=0, keep_pipe=None):
     """Secondary figure (BASELINE.json's second metric): images/s of the edited SD-1.4 pipeline,
     512x512, `steps` PNDM steps (+1 U-Net call), guidance 7.5, bf16, CPU-seeded latents, synthetic
     (seeded-random) weights, cross-attention through uce_xattn_fwd.  Every rank generates its own
@@ -464,6 +492,7 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
     if world > 1:
         torch.distributed.barrier()
     _sync(device)
+    cpu0 = os.times()
     t0 = time.perf_counter()
     if failure is None:
         try:
@@ -475,6 +504,22 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
             failure = f"timed loop: {err!r}"
     _sync(device)
     mine_s = time.perf_counter() - t0                             # this rank's own loop, before it waits for the others
+    cpu1 = os.times()
+    host_cpu_s = (cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)   # this process, all its threads (CPU RNG, tokenizer, image conversion)
+    # the drop-in CLI's default is ONE prompt per pipe() call (generate-images-sd.py:29-42): the same loop row by row, on a
+    # few rows (its own captured step at batch 2)
+    rowwise = None
+    if failure is None and rowwise_images > 0:
+        try:
+            run(0, 1, 2)
+            _sync(device)
+            tr = time.perf_counter()
+            for j in range(rowwise_images):
+                run(j, 1, steps)
+            _sync(device)
+            rowwise = rowwise_images / (time.perf_counter() - tr)
+        except Exception as err:  # noqa: BLE001
+            _log(f"row-wise leg failed: {err!r}")
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
@@ -498,10 +543,46 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
            "data": "synthetic weights; prompts = real coco_30k.csv records (tests/golden/coco30k_rows.csv, their own seeds) then "
                    "same-schema synthetic captions; CPU-seeded latents",
            "seconds": round(el, 3),
-           "per_rank_images_per_s": [round(n_images / s, 4) for s in per_rank]}
+           "per_rank_images_per_s": [round(n_images / s, 4) for s in per_rank],
+           # host side of one rank: CPU seconds (user + system, every thread of the process) per image inside the timed loop -
+           # the CPU-seeded latent draws, tokenisation, launch / graph-replay calls and the uint8 / PIL conversion; an 8-rank
+           # node needs 8 x this per wall second of generation from its host cores
+           "host_cpu_seconds_per_image": round(host_cpu_s / max(n_images, 1), 4),
+           "host_cpu_cores_busy": round(host_cpu_s / max(mine_s, 1e-9), 3)}
+    if rowwise is not None:
+        out["rowwise"] = {"value": round(world * rowwise, 4), "unit": "images/s", "prompts_per_unet_call": 1, "images": rowwise_images,
+                          "note": "the CLI default --batch_prompts 1: one pipe() call per CSV row like generate-images-sd.py:29-42"}
     if bcast_ms is not None:
         out["weight_broadcast_ms"] = round(bcast_ms, 3)
+    if keep_pipe is not None:
+        keep_pipe.append(pipe)
     return out
+
+
+def uce_wall_leg(pipe, device, tmpdir: str):
+    """The number the reference itself prints (uce_sd_erase.py:90-91 "Model edited in X seconds"; README.md:5 "under 1 second"):
+    edit.UCE() END TO END on the synthetic SD-1.4 pipeline - module discovery + slab, one text-encoder forward per unique
+    concept string (or --embed_batch strings per forward), the closed-form edit, device -> host + safetensors - for BASELINE
+    configs 0-2, stage by stage."""
+    from uce_amd import edit as E
+    import contextlib
+    import io
+    out = []
+    for name, n_e, n_p in (("sd14_erase2p3", 2, 3), ("sd14_erase50", 50, 0), ("sd14_erase1000p500", 1000, 500)):
+        edit = [f"artist number {i}" for i in range(n_e)]
+        pres = [f"kept artist {i}" for i in range(n_p)]
+        guide = ["art"] * n_e
+        ent = {"workload": name, "concepts": n_e + n_p}
+        for label, eb in (("per_string", 0), ("embed_batch_64", 64)):
+            tm = {}
+            with contextlib.redirect_stdout(io.StringIO()):
+                E.UCE(pipe, edit, guide, pres, 1.0, 1.0, 0.5, tmpdir, f"wall_{name}_{label}", device=str(device), embed_batch=eb,
+                      timings=tm)
+            ent[label] = {k: round(v, 4) for k, v in tm.items()}
+        out.append(ent)
+    return {"metric": "UCE() wall seconds, end to end (the reference's own printed figure)", "unit": "s",
+            "stages": "slab | embed | edit | save | total", "text_encoder": "CLIP-L architecture, seeded-random weights, bf16, on the GPU",
+            "configs": out}
 
 
 def prompt_table(n: int):
@@ -632,6 +713,7 @@ def main() -> None:
     ap.add_argument("--gen-images", type=int, default=32,
                     help="images per rank for the secondary images/s figure (0 = skip)")
     ap.add_argument("--gen-batch", type=int, default=16, help="prompts denoised per U-Net call")
+    ap.add_argument("--gen-rowwise", type=int, default=4, help="images of the row-by-row (one prompt per call) figure; 0 = skip")
     ap.add_argument("--gen-steps", type=int, default=50)
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs")
     ap.add_argument("--only", default="", choices=["", "edit", "xattn", "sattn", "generate"],
@@ -659,6 +741,21 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
+    # the line says n_gpus = WORLD_SIZE: refuse to print it unless the job really is `--gpus` ranks in ONE process group, one
+    # distinct GPU each (a launcher started with another rank count, or a group that came up smaller, must not pass for an N-GPU run)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: refusing to report an N-GPU line")
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        if backend == "nccl" and os.environ.get("UCE_BENCH_SAME_DEVICE") != "1":
+            ids = [None] * world
+            dist.all_gather_object(ids, (socket.gethostname(), torch.cuda.get_device_properties(device).uuid.__str__()
+                                         if hasattr(torch.cuda.get_device_properties(device), "uuid") else local))
+            if len(set(ids)) != world:
+                raise SystemExit(f"{world} ranks share {len(set(ids))} GPUs: refusing to report an N-GPU line")
+
     from uce_amd import edit as E
     from uce_amd import cli
     H = E.UceHandle.get(device)
@@ -671,7 +768,8 @@ def main() -> None:
         print(json.dumps(sattn_leg(device, gb, iters=4, with_torch=False)), flush=True)
         return
     if args.only == "generate":         # the images/s leg alone (unedited synthetic weights), for A/B runs
-        g = generation_leg(device, world, args.gen_images, args.gen_steps, None, args.gen_batch)
+        g = generation_leg(device, world, args.gen_images, args.gen_steps, None, args.gen_batch,
+                           rowwise_images=args.gen_rowwise if world == 1 else 0)
         if rank == 0:
             print(json.dumps(g), flush=True)
         return
@@ -716,8 +814,18 @@ def main() -> None:
             except Exception as err:  # noqa: BLE001
                 result["configs"].append({"workload": name, "error": repr(err)})
     if args.gen_images > 0:
+        kept = []
         result["generate"] = generation_leg(device, world, args.gen_images, args.gen_steps,
-                                            out if out.shape[1] == 768 else None, args.gen_batch)
+                                            out if out.shape[1] == 768 else None, args.gen_batch,
+                                            rowwise_images=args.gen_rowwise if world == 1 else 0, keep_pipe=kept)
+        if rank == 0 and world == 1 and kept and not args.no_configs:
+            import tempfile
+            try:
+                with tempfile.TemporaryDirectory() as tmp:
+                    result["uce_wall_s"] = uce_wall_leg(kept[0], device, tmp)
+            except Exception as err:  # noqa: BLE001
+                result["uce_wall_s"] = {"error": repr(err)}
+        del kept
     if rank == 0 and args.gen_images > 0:
         result["xattn"] = xattn_leg(device, (2, gb))
         result["sattn"] = sattn_leg(device, gb)
@@ -736,24 +844,40 @@ def main() -> None:
 CPU_BASELINE_CACHE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "uce_bench_cpu_baseline.json")
 
 
+def _bench_sha() -> str:
+    import hashlib
+    return hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]
+
+
+CPU_BASELINE_MAX_AGE_S = 6 * 3600.0
+
+
 def cached_cpu_baseline(inp, world: int):
     """N = 1: measure (and leave the figure in a scratch file).  N > 1: the driver runs N = 1, 2, 4, 8 back to back on one
-    node - reuse the N = 1 measurement of this box when it is there (same host, same workload), else take a shorter
-    bounded sample now; either way the line says where the number was measured."""
-    key = f"{inp['name']}|{cpu_model()}"
+    node - reuse the N = 1 measurement of this box when it is there (same host, same workload, same bench.py and kernel sources,
+    younger than six hours), else take a shorter bounded sample now; either way the line says where and when the number was
+    measured."""
+    key = f"{inp['name']}|{cpu_model()}|{_bench_sha()}|{SOURCE_HASH}"
     if world > 1:
         try:
             c = json.load(open(CPU_BASELINE_CACHE))
-            if c.get("key") == key:
+            age = time.time() - float(c.get("measured_unix", 0))
+            if c.get("key") == key and 0 <= age <= CPU_BASELINE_MAX_AGE_S:
                 c["baseline"]["measured_at_n_gpus"] = 1
+                c["baseline"]["cache_age_s"] = round(age, 1)
                 return c["baseline"]
         except Exception:  # noqa: BLE001
             pass
     b = cpu_baseline(inp, repeats=5 if world == 1 else 2)
     b["measured_at_n_gpus"] = world
+    b["cache_age_s"] = 0.0
     if world == 1:
         try:
-            json.dump({"key": key, "baseline": b}, open(CPU_BASELINE_CACHE, "w"))
+            b["configs"] = cpu_baseline_configs("cpu", b["cores"])
+        except Exception as err:  # noqa: BLE001
+            b["configs"] = [{"error": repr(err)}]
+        try:
+            json.dump({"key": key, "measured_unix": time.time(), "baseline": b}, open(CPU_BASELINE_CACHE, "w"))
         except Exception:  # noqa: BLE001
             pass
     return b

@@ -480,8 +480,8 @@ def test_primal_edit_other_widths(H, N_e, N_p, d, rows_):
 
 @pytest.mark.parametrize("N_e,N_p,d,neg", [(40, 20, 768, "scales"), (300, 700, 768, "scales"), (30, 30, 1024, "lamb")])
 def test_edit_slab_indefinite_system_matches_the_lu_solve(H, N_e, N_p, d, neg):
-    """Negative scales / lamb <= 0 (the reference's `torch.inverse` takes them): edit_slab's normal-equations form against
-    numpy's LU solve in float64.  The tolerance is the reference's own fp32-LU level, not the SPD path's."""
+    """Negative scales / lamb <= 0 (the reference's `torch.inverse` takes them): edit_slab's general form (f64 LU solve) against
+    numpy's LU solve in float64."""
     from uce_amd import edit as E
     C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e + 3)
     lamb = 0.5
@@ -499,7 +499,7 @@ def test_edit_slab_indefinite_system_matches_the_lu_solve(H, N_e, N_p, d, neg):
     slab = E.WeightSlab(["m"], [0], [W.shape[0]], _dev(W))
     out = E.edit_slab(H, slab, _dev(C), _dev(G), _dev(s), lamb).data.cpu()
     want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
-    assert O.rel_fro(out, want) < max(2e-6, 1e-15 * cond * cond), cond
+    assert O.rel_fro(out, want) < max(2e-6, 1e-14 * cond), cond
 
 
 @pytest.mark.parametrize("env,value,N_e,N_p", [("UCE_PROJECT_LA", "0", 100, 80), ("UCE_SPLIT_MAX_NE", "256", 200, 60),

@@ -360,6 +360,26 @@ def test_real_coco30k_rows_shard_disjointly_and_completely(world):
     assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1            # round-robin balance
 
 
+def test_eight_rank_gloo_generation_covers_the_reference_file_list(tmp_path):
+    """The 8-GPU run of BASELINE config 5 without the hardware: 8 gloo ranks of generate_images (tiny model, one step) over the
+    real coco_30k records of the fixture - the union of the PNG names the ranks write equals the list the reference's own loop
+    wrote for the same window, no file is written twice, and the per-rank image counts differ by at most one."""
+    import json
+    csv_path, meta = _coco_fixture()
+    win = meta["windows"][0]
+    worker = os.path.join(REPO_ROOT, "tests", "gen_world_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                    "--master-addr", "127.0.0.1", "--master-port", "29577", worker, str(tmp_path), csv_path],
+                   check=True, env=env, timeout=1200)
+    files = sorted(f for f in os.listdir(tmp_path / "coco") if f.endswith(".png"))
+    assert files == sorted(win["files"])
+    stats = [json.load(open(tmp_path / f"stats_r{r}.json")) for r in range(8)]
+    counts = [int(s["images"]) for s in stats]
+    assert sum(counts) == len(win["files"]) and max(counts) - min(counts) <= 1
+    assert all(int(s["world"]) == 8 and int(s["images_total"]) == len(win["files"]) for s in stats)
+
+
 @pytest.mark.parametrize("fail_rank", [-1, 1])
 def test_bench_generation_leg_two_ranks_gloo(tmp_path, fail_rank):
     """bench.py's generation leg as the N > 1 driver line runs it: weight broadcast, barrier, timed loop, barrier,

@@ -26,6 +26,31 @@ void uce_prof_mark(uce_ctx* h, const char* name, hipStream_t st, bool begin) {
   }
 }
 
+// roctx ranges (tracing): resolved lazily so that the library never links the profiler
+int g_uce_roctx = -1;
+void uce_roctx(const char* name, bool begin) {
+  static int (*push)(const char*) = nullptr;
+  static int (*pop)() = nullptr;
+  if (g_uce_roctx < 0) {
+    const char* e = getenv("UCE_ROCTX");
+    int on = 0;
+    if (e && *e && *e != '0') {
+      void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) {
+        push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        on = push && pop;
+      }
+    }
+    g_uce_roctx = on;
+    if (!on) return;
+  }
+  if (!g_uce_roctx) return;
+  if (begin) (void)push(name);
+  else (void)pop();
+}
+
 static void prof_clear(uce_ctx* h) {
   if (!h->prof) return;
   for (auto& r : h->prof->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

@@ -170,10 +170,20 @@ struct uce_ctx {
 // Measurement aid (uce_profile_begin / uce_profile_end): when h->prof is set, every kernel launch (or launch
 // chain) uce_edit issues is bracketed by two HIP events on the caller's stream.
 void uce_prof_mark(uce_ctx* h, const char* name, hipStream_t st, bool begin);
+// UCE_ROCTX=1: every such scope is also a roctx range (roctxRangePushA / roctxRangePop from libroctx64.so, resolved at the first
+// scope; rocprofv3 --marker-trace shows the launches of the edit / attention entry points under their names); off = one load.
+void uce_roctx(const char* name, bool begin);
+extern int g_uce_roctx;      // -1: not looked at yet, 0: off, 1: on
 struct UceProfScope {
   uce_ctx* h; const char* name; hipStream_t st;
-  UceProfScope(uce_ctx* h_, const char* n, hipStream_t s) : h(h_), name(n), st(s) { if (h && h->prof) uce_prof_mark(h, name, st, true); }
-  ~UceProfScope() { if (h && h->prof) uce_prof_mark(h, name, st, false); }
+  UceProfScope(uce_ctx* h_, const char* n, hipStream_t s) : h(h_), name(n), st(s) {
+    if (g_uce_roctx) uce_roctx(name, true);
+    if (h && h->prof) uce_prof_mark(h, name, st, true);
+  }
+  ~UceProfScope() {
+    if (h && h->prof) uce_prof_mark(h, name, st, false);
+    if (g_uce_roctx) uce_roctx(name, false);
+  }
 };
 
 // ---- internal launchers (defined across the .hip files) -------------------------------------

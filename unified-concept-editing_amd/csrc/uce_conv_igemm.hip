@@ -251,6 +251,7 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
   const long src_h = upsample ? H >> 1 : (long)H * stride, src_w = upsample ? W >> 1 : (long)W * stride;
   if ((long)N * src_h * src_w * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return UCE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  UceProfScope ps(h, "uce_conv3x3_nhwc_fwd", st);
   {
     // outputs that are multiples of 128 / 256 / 320 channels: the direct-to-LDS form (uce_conv_dma.hip), which also carries the
     // stride-2 taps and the residual epilogue

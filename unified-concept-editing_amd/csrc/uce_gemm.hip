@@ -344,6 +344,7 @@ extern "C" int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const voi
   const long max_rows = ((1L << 31) - 1 - 2L * K) / (2 * ldx) + 1;
   if ((long)N * K * 2 >= (1L << 31)) return UCE_EINVAL;
   const int force = h->sw.gemm_tile;
+  UceProfScope ps(h, "uce_linear_fwd", (hipStream_t)stream);
   const long ybytes = outf32 ? 4 : 2;
   for (long m0 = 0; m0 < M; m0 += max_rows) {
     const long mb = (M - m0 < max_rows) ? M - m0 : max_rows;

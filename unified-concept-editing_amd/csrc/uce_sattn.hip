@@ -712,6 +712,7 @@ extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const
     const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, Lk, dh));
     if (rc) return rc;
   }
+  UceProfScope ps(h, "uce_sattn_fwd", (hipStream_t)stream);
   return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, (long)H * dh,
                       h->sw.sattn_vti);
 }
@@ -726,6 +727,7 @@ extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, in
     const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, L, dh));
     if (rc) return rc;
   }
+  UceProfScope ps(h, "uce_sattn_packed_fwd", (hipStream_t)stream);
   return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
                       h->sw.sattn_vti);
 }

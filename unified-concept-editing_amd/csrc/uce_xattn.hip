@@ -604,5 +604,6 @@ extern "C" int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const
   if (dh <= 0 || dh > 160 || (dh & 7)) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   if (B > 65535 || H > 65535) return UCE_EINVAL;
+  UceProfScope ps(h, "uce_xattn_fwd", (hipStream_t)stream);
   return launch_xattn(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.xattn_variant);
 }

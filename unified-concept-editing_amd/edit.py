@@ -584,17 +584,17 @@ def check_spd_inputs(scales, lamb: float) -> bool:
 def edit_slab_general(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: torch.Tensor, s: torch.Tensor,
                       lamb: float) -> WeightSlab:
     """The edit for a symmetric INDEFINITE system (negative scales or lamb <= 0; reference: the same
-    `mat1 @ torch.inverse(mat2)` - its LU inverse does not care about definiteness).  A = lamb I + C^T S C is symmetric and,
-    unless singular, A A is symmetric positive definite, so  Delta^T = A^-1 Bt = (A A)^-1 (A Bt):  the f64 Gram of the
-    primal form (uce_gram), two f64 library GEMMs on the device (rocBLAS through torch), the f64 Cholesky solve on the
-    squared system (uce_solve_delta: a singular A shows up as a non-positive pivot) and the dense apply.  The condition
-    number is squared, in f64: relative error ~1e-16 cond(A)^2 - below the fp32 LU of the reference (~6e-8 cond(A)) for
-    cond(A) < 6e8."""
+    `mat1 @ torch.inverse(mat2)` - its LU inverse does not care about definiteness).  An EDGE path outside the SPD hot path:
+    the f64 Gram of the primal form (uce_gram) and the dense apply (uce_apply) are the library's kernels; the d x d solve
+    Delta^T = A^-1 Bt is ONE general LU solve in f64 on the device through torch.linalg.solve (rocSOLVER - a library call,
+    stated here: the hand-written solver is a Cholesky and an indefinite A has no Cholesky factor).  Error ~1e-16 cond(A),
+    below the reference's fp32 LU inverse for every A that one can invert at all; a singular A raises like the reference's
+    torch.inverse does."""
     A, Bt = handle.gram(C, G, s, lamb)
-    A2 = A @ A
-    A2 = 0.5 * (A2 + A2.T)                                  # the factorisation reads the lower triangle; keep it the symmetric part
-    DT = handle.solve_delta(A2.contiguous(), (A @ Bt).contiguous())
-    handle.status()
+    try:
+        DT = torch.linalg.solve(A, Bt).to(torch.float32).contiguous()
+    except RuntimeError as err:                              # torch._C._LinAlgError is a RuntimeError
+        raise _lib.UceError(_lib.EDOM, f"solve of the indefinite system ({err})") from None
     return slab.like(handle.apply(slab.data, DT))
 
 
@@ -618,21 +618,39 @@ def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[
 
 def UCE(pipe, edit_concepts, guide_concepts, preserve_concepts, erase_scale, preserve_scale, lamb, save_dir,
         exp_name, device: str = "cuda:0", algo: int = _lib.ALGO_AUTO, return_slab: bool = False,
-        embed_batch: int = 0):
+        embed_batch: int = 0, timings: Optional[Dict[str, float]] = None):
     """Same positional signature and artifact as the reference's UCE() (uce_sd_erase.py:12);
-    `device` replaces the module global the reference reads."""
+    `device` replaces the module global the reference reads.  `timings` (optional dict) receives the wall seconds of the
+    stages - slab (module discovery + packing), embed (text encoder, uce_sd_erase.py:25-42), edit (:45-82, device-synchronised),
+    save (:85-88: device -> host + safetensors) - that add up to the reference's own "Model edited in X seconds"."""
     start_time = time.time()
     dev = torch.device(device)
     handle = UceHandle.get(dev)
+
+    def lap(name, t_prev):
+        if timings is None:
+            return t_prev
+        torch.cuda.synchronize(handle.device)
+        now = time.time()
+        timings[name] = timings.get(name, 0.0) + (now - t_prev)
+        return now
+
+    t = start_time
     modules = collect_uce_modules(pipe.unet)
     slab = WeightSlab.from_modules(modules, handle.device)
+    t = lap("slab", t)
     embeds = last_token_embeddings(pipe, list(edit_concepts) + list(guide_concepts) + list(preserve_concepts),
                                    handle.device, batch_size=embed_batch)
+    t = lap("embed", t)
     C, G, s = concept_matrices(embeds, edit_concepts, guide_concepts, preserve_concepts, erase_scale,
                                preserve_scale, handle.device)
     new = edit_slab(handle, slab, C, G, s, lamb, algo)
+    t = lap("edit", t)
     path = save_uce_state(new, save_dir, exp_name)
+    t = lap("save", t)
     end_time = time.time()
+    if timings is not None:
+        timings["total"] = end_time - start_time
     print(f"\n\nErased concepts using UCE\nModel edited in {end_time - start_time} seconds\n")
     return (new, path) if return_slab else None
 
