@@ -233,7 +233,7 @@ int uce_im2col3x3_c4(uce_handle_t h, const void* x, void* cols, int N, int H, in
  * nearest-neighbour upsampling; with stride = 2: [N, 2H, 2W, Cin], diffusers' Downsample2D), w [Cout, 3, 3, Cin] (a channels-last
  * Conv2d weight), bias [Cout] or NULL, residual [N, H, W, Cout] or NULL (added in the epilogue: the `x + conv2(h) + b` join of
  * ResnetBlock2D), y [N, H, W, Cout]; bf16 or f16, f32 accumulation; Cin % 32 == 0, Cout % 8 == 0.  stride = 2 and residual need
- * Cout % 128 == 0 (UCE_ENOSYS otherwise). */
+ * Cout % 128 == 0 or Cout % 320 == 0 (UCE_ENOSYS otherwise). */
 int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const void* bias, void* y, int N, int H, int W,
                          int Cin, int Cout, int upsample, int stride, const void* residual, int dtype, uce_stream_t stream);
 

@@ -376,7 +376,9 @@ def test_conv_dispatch_rule_and_padded_narrow_weights():
         assert not E.conv_prefers_igemm(16, 16, 1280, 1280, 32)      # too few pixel tiles: im2col + library GEMM
         assert not E.conv_prefers_igemm(8, 8, 1280, 1280, 32)
         assert E.conv_prefers_igemm(512, 512, 128, 128, 16)          # VAE decoder
-    assert not E.conv_prefers_igemm(64, 64, 4, 320, 32)              # conv_in: Cin % 64 != 0
+        assert E.conv_prefers_igemm(32, 32, 320, 320, 32, stride=2)      # Downsample2D at the generation batch: own kernel
+        assert not E.conv_prefers_igemm(8, 8, 1280, 1280, 2, stride=2)   # one prompt: too few pixel tiles
+    assert not E.conv_prefers_igemm(64, 64, 4, 320, 32)              # conv_in: 4 channels (its own patch-matrix path)
     conv = torch.nn.Conv2d(128, 3, 3, padding=1)
     w8, b8 = U._padded_out_channels(conv)
     assert w8.shape == (8, 128, 3, 3) and torch.equal(w8[:3], conv.weight) and not w8[3:].any()

@@ -210,35 +210,68 @@ def test_transformer_block_matches_its_torch_twin():
 
 
 def test_unet_forward_matches_its_torch_twin_and_hoists_time_projections():
-    """The tiny U-Net on the GPU against the same weights through torch ops; the 22 time projections are ONE launch."""
+    """The tiny U-Net on the GPU against the same weights through torch ops; the 22 time projections are ONE stacked linear
+    (whichever GEMM takes it at this size), conv_in goes through the 4-channel patch matrix + uce_linear_fwd."""
     from tests.torch_twin import torch_ops
     from uce_amd import edit as E
     from uce_amd.sd import pipeline as sdp
+    from uce_amd.sd import unet as U
     pipe = sdp.load_pipeline("tiny-sd-test", torch.bfloat16, "cuda:0", synthetic=True, vae=False, seed=3)
     g = torch.Generator().manual_seed(0)
     x = _rand((2, 4, 8, 8), g, torch.bfloat16)
     ctx = _rand((2, 77, 64), g, torch.bfloat16)
     t = torch.tensor([500], device="cuda")
-    seen = []
-    orig = E.UceHandle.linear
+    seen, own = [], []
+    orig_w, orig_own = U.linear_w, E.UceHandle.linear
 
-    def counted(self, x_, w, *a, **k):
+    def counted_w(x_, w, *a, **k):
         seen.append((tuple(x_.shape), tuple(w.shape)))
-        return orig(self, x_, w, *a, **k)
+        return orig_w(x_, w, *a, **k)
 
-    E.UceHandle.linear = counted
+    def counted_own(self, x_, w, *a, **k):
+        own.append((tuple(x_.shape), tuple(w.shape)))
+        return orig_own(self, x_, w, *a, **k)
+
+    U.linear_w, E.UceHandle.linear = counted_w, counted_own
     try:
         a = pipe.unet(x, t, ctx).float()
     finally:
-        E.UceHandle.linear = orig
+        U.linear_w, E.UceHandle.linear = orig_w, orig_own
     n_res = sum(1 for m in pipe.unet.modules() if m.__class__.__name__ == "ResnetBlock2D")
     temb_dim = pipe.unet.cfg.block_out_channels[0] * 4
     hoisted = [s for s in seen if s[0] == (2, temb_dim) and s[1][1] == temb_dim and s[1][0] > temb_dim]
     assert n_res == 22 and len(hoisted) == 1                     # one stacked projection, not 22
-    assert any(s[1][1] == 64 and s[0][-1] == 64 and len(s[0]) == 2 and s[0][0] == 2 * 8 * 8 for s in seen)   # conv_in's GEMM
+    assert not [s for s in seen if s[0] == (2, temb_dim) and s[1][0] in (32, 64) and s[1][1] == temb_dim]
+    assert ((2 * 8 * 8, 64), (32, 64)) in own                    # conv_in: [pixels, 64] patch matrix x [Cout, 64]
     with torch_ops():
         b = pipe.unet(x, t, ctx).float()
     assert O.rel_fro(a.cpu(), b.cpu()) < 3e-2
+
+
+def test_small_layers_stay_with_the_gemm_library_and_large_ones_take_the_kernel():
+    """The measured dispatch rule of sd/unet.py: fewer than LINEAR_MIN_ROWS rows -> torch (stream-K library GEMM), else
+    uce_linear_fwd - both give the same layer."""
+    from uce_amd import edit as E
+    from uce_amd.sd import unet as U
+    lin = torch.nn.Linear(320, 640).to("cuda", torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    own = []
+    orig = E.UceHandle.linear
+
+    def counted(self, x_, w, *a, **k):
+        own.append(tuple(x_.shape))
+        return orig(self, x_, w, *a, **k)
+
+    E.UceHandle.linear = counted
+    try:
+        small, big = _rand((2, 64, 320), g, torch.bfloat16), _rand((2, 4096, 320), g, torch.bfloat16)
+        r = _rand((2, 4096, 640), g, torch.bfloat16)
+        ys, yb = U.linear(lin, small), U.linear(lin, big, residual=r)
+    finally:
+        E.UceHandle.linear = orig
+    assert own == [(2, 4096, 320)]
+    assert O.rel_fro(ys.double().cpu(), F.linear(small.double(), lin.weight.double(), lin.bias.double()).cpu()) < 4e-3
+    assert O.rel_fro(yb.double().cpu(), (F.linear(big.double(), lin.weight.double(), lin.bias.double()) + r.double()).cpu()) < 4e-3
 
 
 def test_vae_attention_on_the_linear_kernel_matches_its_torch_twin(H):

@@ -287,7 +287,7 @@ class UceHandle:
                       upsample: bool = False, stride: int = 1, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """3x3 / pad 1 convolution of a channels-last [N, C, H, W] tensor as ONE implicit-GEMM launch (uce_conv3x3_nhwc_fwd): no
         patch matrix.  Cin % 32 == 0, Cout % 8 == 0, channels-last weight.  stride 2 = Downsample2D; `residual` (channels-last,
-        the output's shape) is added in the epilogue; both need Cout % 128 == 0."""
+        the output's shape) is added in the epilogue; both need Cout % 128 == 0 or Cout % 320 == 0."""
         N, Cc, Hs, Ws = x.shape
         Hh, Ww = (2 * Hs, 2 * Ws) if upsample else ((Hs - 1) // stride + 1, (Ws - 1) // stride + 1)
         if stride == 2 and ((Hs | Ws) & 1):
@@ -314,14 +314,14 @@ class UceHandle:
                      max_cols_bytes: int = CONV_COLS_BYTES, upsample: bool = False, stride: int = 1,
                      residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """3x3 / pad 1 convolution of a channels-last [N, C, H, W] tensor: the implicit-GEMM kernels where the measured rule
-        (sd.conv_dispatch) or the request (stride 2, a residual epilogue) says so, else patch matrix through uce_im2col3x3_nhwc +
-        ONE GEMM (uce_linear_fwd) against the channels-last weight viewed as [Cout, 9*C]; the batch is walked in evenly sized
-        chunks whose patch matrix stays under `max_cols_bytes`.
+        (sd.conv_dispatch) says so or for stride 2, else patch matrix through uce_im2col3x3_nhwc + ONE library GEMM against the
+        channels-last weight viewed as [Cout, 9*C] (+ the residual join by uce_add_bias_nhwc_fwd); the batch is walked in
+        evenly sized chunks whose patch matrix stays under `max_cols_bytes`.
         upsample: convolve the 2x nearest-neighbour upsampling of x (output [N, Cout, 2H, 2W]) without materialising it."""
         N, Cc, Hs, Ws = x.shape
         Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs // stride, Ws // stride)
         Cout = weight.shape[0]
-        if stride != 1 or residual is not None or conv_prefers_igemm(Hh, Ww, Cc, Cout, N):
+        if stride != 1 or conv_prefers_igemm(Hh, Ww, Cc, Cout, N):
             return self.conv3x3_igemm(x, weight, bias, upsample=upsample, stride=stride, residual=residual)
         wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -335,7 +335,11 @@ class UceHandle:
             _lib.check(self.lib.uce_im2col3x3_nhwc(self._h, xs[n0].data_ptr(), _ptr(cols), nb, Hh, Ww, Cc, int(upsample),
                                                    _stream_ptr(self.device)), "uce_im2col3x3_nhwc")
             rows = nb * Hh * Ww
-            self.linear(cols[:rows], wmat, bias, out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows])
+            dst = y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows]
+            # few pixel rows, a long contraction (the 16 x 16 / 8 x 8 layers): the GEMM library's stream-K kernels
+            torch.addmm(bias, cols[:rows], wmat.t(), out=dst) if bias is not None else torch.mm(cols[:rows], wmat.t(), out=dst)
+        if residual is not None:
+            return self.add_bias_nhwc(y, residual, None)
         return y
 
     def conv3x3_c4(self, x: torch.Tensor, wmat: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:

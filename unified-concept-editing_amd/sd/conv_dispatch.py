@@ -16,20 +16,27 @@ CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "4096")) << 20
 CONV_IGEMM = os.environ.get("UCE_CONV_IGEMM", "auto")
 
 
-def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32) -> bool:
-    """Measured on an MI355X (tools/probe_igemm.py, bf16): the implicit-GEMM kernels run 800-1110 TF/s (direct-to-LDS
-    256-pixel form, outputs of 256 / 320-multiples) or 600-820 TF/s (128 x 128 form) once there are enough pixel tiles; the
-    library GEMM reaches 0.85-0.95 PF/s on the small-spatial, wide layers but pays the patch-matrix round trip everywhere."""
-    if CONV_IGEMM == "never" or Cin % 64 or Cout % 8:
+def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32, stride: int = 1) -> bool:
+    """Measured on an MI355X (tools/probe_igemm.py, tools/probe_r04.py, bf16): the implicit-GEMM kernels run 800-1110 TF/s
+    (direct-to-LDS form, outputs of 128 / 256 / 320-multiples) or 600-820 TF/s (128 x 128 register-staged form) once there are
+    enough pixel tiles; the library GEMM (stream-K) reaches 0.85-1.25 PF/s on the small-spatial, wide layers but pays the
+    patch-matrix round trip everywhere.  (H, W) = OUTPUT size.  stride 2 (Downsample2D): the direct-to-LDS kernel against
+    MIOpen - 81-139 us against 167-191 at the generation batch, wherever there are at least 64 pixel tiles."""
+    if CONV_IGEMM == "never" or Cin % 32 or Cout % 8:
         return False
     if CONV_IGEMM == "always":
         return True
     M = N * H * W
+    if stride == 2:
+        return (Cout % 128 == 0 or Cout % 320 == 0) and M >= 8192
+    if Cin % 64 and Cout % 128 and Cout % 320:       # (the register-staged fallback kernel needs 64-channel chunks)
+        return False
     if M >= 128 * 1024:                              # U-Net 64 x 64 at the generation batch, every VAE layer >= 128^2
         return True
     # 32 x 32 layers: the direct-to-LDS form (outputs that are multiples of 256 / 320 channels: 835-1113 TF/s against
     # 736-761 for im2col + GEMM) or a long contraction on the 128 x 128 kernel; 16 x 16 and 8 x 8 layers have too few
-    # pixel tiles for either (library GEMM 0.88-0.95 PF/s there)
+    # pixel tiles for either (1280 -> 1280 @ 16 x 16 x 32: 284 us with 128-pixel tiles against 225 for im2col + library GEMM;
+    # @ 8 x 8: 141 against 93)
     return M >= 32 * 1024 and (Cin >= 640 or Cout % 256 == 0 or Cout % 320 == 0)
 
 

@@ -24,6 +24,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .conv_dispatch import conv_prefers_igemm
+
 
 @dataclass
 class UNetConfig:
@@ -161,7 +163,7 @@ def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
 def _conv3x3_epilogue_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
     """the direct-to-LDS kernel takes the layer (stride 2 and the residual epilogue exist only there)"""
     return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 128 == 0
+            and conv.groups == 1 and conv.in_channels % 32 == 0 and (conv.out_channels % 128 == 0 or conv.out_channels % 320 == 0)
             and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -208,7 +210,9 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True, residual: O
     uce_linear_fwd on the pixel rows; everything else (CPU, fp32) is torch."""
     bias = conv.bias if with_bias else None
     if (residual is not None or conv.stride == (2, 2)) and conv.stride in ((1, 1), (2, 2)) and _conv3x3_epilogue_ok(conv, x) \
-            and (x.shape[2] % conv.stride[0] == 0 and x.shape[3] % conv.stride[1] == 0):
+            and (x.shape[2] % conv.stride[0] == 0 and x.shape[3] % conv.stride[1] == 0) \
+            and conv_prefers_igemm(x.shape[2] // conv.stride[0], x.shape[3] // conv.stride[1], conv.in_channels, conv.out_channels,
+                                   x.shape[0], stride=conv.stride[0]):
         from .. import edit as _edit
         return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias, stride=conv.stride[0], residual=residual)
     if _conv3x3_fast_ok(conv, x):
@@ -251,9 +255,17 @@ def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------ linear layers
 
+LINEAR_MIN_ROWS = int(os.environ.get("UCE_LINEAR_MIN_ROWS", "4096"))     # (A/B runs only)
+
+
 def _hip_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    """uce_linear_fwd takes the layer.  Measured rule (tools/probe_r04.py, MI355X): its 128 / 256-row output tiles have no
+    split over the contraction, so a layer with fewer than ~4096 rows (the 8 x 8 mid block at the generation batch, everything
+    below 32 x 32 at the CLI's one-prompt batch) leaves most CUs without a tile - those plain GEMMs stay with the GEMM library
+    (stream-K), like the small-spatial convolutions (sd/conv_dispatch.py)."""
     return (hip16(x) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
-            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0)
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0
+            and x.numel() // x.shape[-1] >= LINEAR_MIN_ROWS)
 
 
 def linear_w(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -628,7 +640,7 @@ class UNet2DConditionModel(nn.Module):
     def _hoist_time_projections(self, temb: torch.Tensor) -> None:
         res = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
         w0 = res[0].time_emb_proj.weight
-        if not (_hip_linear_ok(temb, w0, res[0].time_emb_proj.bias) and all(r.time_emb_proj.weight.shape[0] % 8 == 0 for r in res)):
+        if not (hip16(temb) and w0.dtype == temb.dtype and all(r.time_emb_proj.weight.shape[0] % 8 == 0 for r in res)):
             for r in res:
                 r.temb_addend = None
             return
