@@ -267,6 +267,23 @@ def test_erase_golden(H, name, algo, tile):
     _check_replicas(out, torch.cat(c.w_exact64()), torch.cat(c.w_ref32()), tile)
 
 
+@pytest.mark.parametrize("fused", ["1", "2"])
+@pytest.mark.parametrize("name", ["erase_n2p3_d768", "erase_n50_d768", "erase_quirks_d768", "erase_n12p4_d1024", "erase_n36p4_d2048"])
+def test_erase_golden_one_launch_forms(name, fused):
+    """The one-launch forms of the <= 128-concept edit (UCE_EDIT_FUSED = 1: exact-f32 MFMA update, 2: split-bf16 update from
+    the riders' pre-split R planes) against the reference's own outputs, on the tiled fixtures (1056 rows: ten 112-row
+    super-tiles, the last one ragged) - and twice on one handle (the hand-off words are re-armed by the last block)."""
+    c = Case(name)
+    Hv = _handle_with("UCE_EDIT_FUSED", fused)
+    try:
+        out = _run_case(Hv, c, L.ALGO_AUTO, TILE)
+        again = _run_case(Hv, c, L.ALGO_AUTO, TILE)
+    finally:
+        Hv.close()
+    _check_replicas(out, torch.cat(c.w_exact64()), torch.cat(c.w_ref32()), TILE)
+    assert torch.equal(out, again)
+
+
 @pytest.mark.parametrize("tile", [1, TILE])
 @pytest.mark.parametrize("name", DEBIAS_CASES + DEBIAS_ALIAS_CASES)
 def test_debias_golden(H, name, tile):
@@ -503,11 +520,16 @@ def test_edit_slab_indefinite_system_matches_the_lu_solve(H, N_e, N_p, d, neg):
 
 
 @pytest.mark.parametrize("env,value,N_e,N_p", [("UCE_PROJECT_LA", "0", 100, 80), ("UCE_SPLIT_MAX_NE", "256", 200, 60),
-                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600)])
+                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600),
+                                               ("UCE_EDIT_FUSED", "2", 50, 0), ("UCE_EDIT_FUSED", "2", 100, 20), ("UCE_EDIT_FUSED", "2", 3, 2),
+                                               ("UCE_EDIT_FUSED", "1", 50, 0), ("UCE_EDIT_FUSED", "1", 100, 20),
+                                               ("UCE_EDIT_FUSED", "1", 3, 2)])
 def test_edit_forms_behind_the_switches(env, value, N_e, N_p):
     """The forms uce_edit no longer takes by default stay correct behind their switches: the dual system's Cholesky in a
     launch of its own in front of the projection, the two-pass project + update form for 129 ... 256 edit concepts, the
-    primal path without rider jobs."""
+    primal path without rider jobs, and the ONE-launch forms of the <= 128-concept edit (uce_lowrank_fused.hip: projection, rider
+    chain and update in the same workgroups, the update on exact-f32 MFMAs (1) or on split-bf16 MFMAs from pre-split R planes (2)) -
+    measured 2-4 us behind the projection + update launch pair, which stays the default."""
     d, rows_ = 768, 2500
     C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e)
     rng = np.random.Generator(np.random.PCG64(N_p))

@@ -1,0 +1,13 @@
+out=gpurun_out/r04f; mkdir -p $out
+timeout 900 python -m pytest tests/test_edit_gpu.py tests/test_stress_gpu.py tests/test_sdxl_gpu.py -m gpu -q --timeout 300 -x > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
+tail -8 $out/pytest.log
+for f in 1 0; do
+UCE_EDIT_FUSED=$f timeout 600 python bench.py --no-cpu-baseline --gen-images 0 > $out/bench_fused$f.json 2> $out/bench_fused$f.log; echo "bench fused=$f rc=$?"
+python - <<PY
+import json
+d=json.load(open("$out/bench_fused$f.json"))
+r=d["roofline"]
+print("fused=$f", d["value"], d["ms_per_step"], d["ms_per_step_events"], r["kernel"], r["avg_ms"], r["bound"], r["frac"], r["step_frac"], [(k["kernel"],k["avg_ms"]) for k in r["kernels"]])
+for c in d.get("configs",[]): print("  ", c.get("workload"), c.get("ms_per_step_events"), c.get("step_frac"), [(k["kernel"],k["avg_ms"]) for k in c.get("kernels",[])], c.get("error"))
+PY
+done

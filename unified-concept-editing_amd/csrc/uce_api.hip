@@ -194,7 +194,7 @@ int uce_create(uce_handle_t* out, int device) {
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
                         want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
                         env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30),
-                        env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1)};
+                        env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1), env_int("UCE_EDIT_FUSED", 0)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
@@ -458,6 +458,13 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool riders = n_pad <= h->sw.rider_max_n;
+    if (riders && h->sw.edit_fused && N_edit <= 128) {
+      // ONE launch: projection || (Gram -> Cholesky -> triangular solves in rider blocks), then - in the same workgroups, the T
+      // tile still in LDS - the update of the rows just projected
+      UceProfScope ps(h, "k_lr_fused", st);
+      // DeltaP (the dense bf16 apply's plane scratch, 3 d^2 bf16) is idle on this path: R's planes (3 * 128 * d bf16) live there
+      return launch_lr_fused(W_old, G, C, s, W_new, rows, d, N, N_edit, lamb, h, st, h->sw.edit_fused >= 2 ? h->DeltaP : nullptr);
+    }
     if (riders) {
       // TWO launches: projection || (Gram -> Cholesky -> triangular solves, all in rider blocks of the same launch),
       // then the update

@@ -72,13 +72,16 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_SATTN_VTI       0: V^T of the self-attention transposed on the way into LDS up to 1024 keys, by the k_vt pre-pass beyond |
 //                       1: always inline | 2: always the pre-pass
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
+//   UCE_EDIT_FUSED      uce_edit with at most 128 concepts (default 0: measured 62-64 us at 50 concepts against 64-66 for either one-launch
+//                       form - the update phase is bound by its weight traffic, not by the launch boundary or the MFMA type): 2 = ONE launch (projection, small-system chain, update on split-bf16 MFMAs:
+//                       uce_lowrank_fused.hip) | 1 = one launch, exact-f32 MFMA update | 0 = projection launch + update launch
 //   UCE_WIDE_EPILOGUE   1: GEMM / convolution tiles leave through LDS in whole rows | 0: 8 bytes per lane from the accumulators
 //   UCE_GEMM_TILE       0: tile of uce_linear_fwd by rule | 1000 * BM + BN (256320, 256256, 128320, 128256, 256128): forced
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue;
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -239,6 +242,10 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
                       const float* s = nullptr, int N = 0, float lamb = 0.f, float* R = nullptr);
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
+// projection + rider chain + update in one launch (uce_lowrank_fused.hip): N <= 128 concepts, d in {768, 1024, 2048}
+// Rp != null: the update runs on the bf16 matrix cores (three-way split); Rp = scratch for R's planes, 3 * 128 * d * 2 bytes
+int launch_lr_fused(const float* W_old, const float* G, const float* C, const float* s, float* W_new, long rows, int d, int N,
+                    int N_edit, float lamb, uce_ctx* h, hipStream_t st, unsigned short* Rp = nullptr);
 // the projection with the persistent Cholesky of the dual system (la, own workgroups) in the first workgroups of the launch
 int launch_lr_project_la(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d, int N_edit,
                          const PotrfLaJob& la, int own, hipStream_t st);
