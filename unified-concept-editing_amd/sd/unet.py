@@ -255,17 +255,19 @@ def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------ linear layers
 
-LINEAR_MIN_ROWS = int(os.environ.get("UCE_LINEAR_MIN_ROWS", "4096"))     # (A/B runs only)
+LINEAR_MIN_TILES = int(os.environ.get("UCE_LINEAR_MIN_TILES", "256"))     # (A/B runs only)
 
 
 def _hip_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
     """uce_linear_fwd takes the layer.  Measured rule (tools/probe_r04.py, MI355X): its 128 / 256-row output tiles have no
-    split over the contraction, so a layer with fewer than ~4096 rows (the 8 x 8 mid block at the generation batch, everything
-    below 32 x 32 at the CLI's one-prompt batch) leaves most CUs without a tile - those plain GEMMs stay with the GEMM library
-    (stream-K), like the small-spatial convolutions (sd/conv_dispatch.py)."""
-    return (hip16(x) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
-            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0
-            and x.numel() // x.shape[-1] >= LINEAR_MIN_ROWS)
+    split over the contraction, so a layer that cannot give every CU a 128 x 320 tile (the 8 x 8 mid block at the generation
+    batch; at the CLI's one-prompt batch everything but the widest 64 x 64 projections) stays with the GEMM library's stream-K
+    kernels, like the small-spatial convolutions (sd/conv_dispatch.py): row by row, 2.0 -> 3 images/s."""
+    if not (hip16(x) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0):
+        return False
+    rows = x.numel() // x.shape[-1]
+    return -(-rows // 128) * -(-weight.shape[0] // 320) >= LINEAR_MIN_TILES
 
 
 def linear_w(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
