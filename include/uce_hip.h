@@ -44,6 +44,7 @@ enum {
   UCE_EDOM = -33,     /* system not positive definite (lambda <= 0 with rank-deficient C, s_i < 0) */
   UCE_ENOSYS = -38,   /* feature not built / not available in this process */
   UCE_ECOMM = -70,    /* the collective library reported an error (uce_bcast) */
+  UCE_ETIMEDOUT = -110, /* a bounded in-launch wait between cooperating workgroups gave up (uce_status; the hand-off words are re-armed) */
   UCE_EHIP = -1000    /* -1000 - hipError_t */
 };
 

@@ -474,6 +474,7 @@ def test_edit_two_stream_path_other_widths(H, N_e, N_p, d, rows_):
                                # concepts against 6 lower tiles: the concept split of A is capped by the slab workspace
     (300, 100, 256, 1300),     # 4 blocks, rows not a multiple of the 320-row apply tile
     (600, 500, 1024, 2500),    # 16 blocks: the launch has no room for riders - the apply splits W_old itself, one Gram launch
+    (2200, 100, 192, 700),     # more than 2048 edit concepts: Bt is too long a job for the riders - the Gram launch computes it
     (0, 300, 256, 640),        # nothing to edit: Bt = 0, W_new = W_old (I + 0)
     (70, 10, 2048, 1000),      # primal forced below d: 32 blocks take the launch chain
 ])

@@ -155,6 +155,8 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
   return UCE_OK;
 }
 
+constexpr size_t LA_FLAGS = 2 * 22 * 22 + 2 * 22 + 8;          // k_potrf_la: systems of up to 22 diagonal blocks
+
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
@@ -172,6 +174,7 @@ const char* uce_strerror(int code) {
     case UCE_EDOM: return "system is not positive definite (check lambda > 0 and scales > 0)";
     case UCE_ENOSYS: return "not available in this build";
     case UCE_ECOMM: return "collective (RCCL) call failed";
+    case UCE_ETIMEDOUT: return "an in-launch hand-off between workgroups timed out (hand-off words re-armed; retry)";
     default:
       if (code <= UCE_EHIP) return hipGetErrorString((hipError_t)(UCE_EHIP - code));
       return "unknown error";
@@ -201,7 +204,6 @@ int uce_create(uce_handle_t* out, int device) {
   (void)hipMemset(h->status, 0, sizeof(int));
   if (hipMalloc((void**)&h->ticket, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->ticket, 0, 4 * sizeof(unsigned));
-  constexpr size_t LA_FLAGS = 2 * 22 * 22 + 2 * 22 + 8;        // k_potrf_la: systems of up to 22 diagonal blocks
   if (hipMalloc((void**)&h->la_flags, LA_FLAGS * sizeof(unsigned)) == hipSuccess) (void)hipMemset(h->la_flags, 0, LA_FLAGS * sizeof(unsigned));
   else h->la_flags = nullptr;                                  // (the launch chain is used instead)
   *out = h;
@@ -408,9 +410,12 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     // persistent launch (133 CUs busy for ~215 us at d = 768, latency-bound), rider workgroups of THAT launch do both on
     // the CUs it leaves idle, and the Gram launch in front of it computes A alone, split over the concepts.
     const bool ride = potrf_la_has_room(h, d);
+    const bool ride_bt = ride && N_edit > 0 && N_edit <= 2048;
     RiderJobs jobs(h);
     if (ride) {
-      if (N_edit > 0)
+      // (each rider contracts its d/64 x d/64 tile of Bt over ALL edit concepts: beyond ~2000 of them that outlasts the ~215 us
+      //  factorisation and the "free" Bt would become the critical path of the launch - the Gram launch computes it then)
+      if (ride_bt)
         h->bt_pending = GramPrimalArgs{C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (N_edit + 31) / 32 * 32, (size_t)0};
       if (h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d)) {
         h->h2_pending_src = W_old;
@@ -421,7 +426,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     {
       UceProfScope ps(h, "k_gram_primal", (hipStream_t)stream);
       rc = launch_gram_primal(h, C, G ? G : C, s, N, N_edit, d, lamb, h->M, h->Bt, (hipStream_t)stream,
-                              ride && N_edit > 0 ? 1 : 0);
+                              ride_bt ? 1 : 0);
     }
     if (rc) return rc;
     {
@@ -597,6 +602,16 @@ int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {
   UCE_HIP_TRY(hipMemcpyAsync(&v, h->status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   UCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   *info = v;
+  if (v < 0) {
+    // a bounded in-launch wait gave up (a hand-off of the cooperating workgroups never arrived): NOT a property of the system.
+    // A late poster may have set flags after the launch's last block cleared them - re-arm every hand-off word and the status
+    // word before the next launch on this handle can pass its waits early.
+    (void)hipMemsetAsync(h->ticket, 0, 4 * sizeof(unsigned), (hipStream_t)stream);
+    if (h->la_flags) (void)hipMemsetAsync(h->la_flags, 0, LA_FLAGS * sizeof(unsigned), (hipStream_t)stream);
+    (void)hipMemsetAsync(h->status, 0, sizeof(int), (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return UCE_ETIMEDOUT;
+  }
   return v ? UCE_EDOM : UCE_OK;
 }
 

@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-OK, EINVAL, ENOMEM, EDOM, ENOSYS, ECOMM = 0, -22, -12, -33, -38, -70
+OK, EINVAL, ENOMEM, EDOM, ENOSYS, ECOMM, ETIMEDOUT = 0, -22, -12, -33, -38, -70, -110
 ALGO_AUTO, ALGO_PRIMAL, ALGO_DUAL = 0, 1, 2
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 EPILOGUE_NONE, EPILOGUE_GEGLU, EPILOGUE_F32 = 0, 1, 2
