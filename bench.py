@@ -479,7 +479,7 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
     # the rows this rank would take of the prompt table: real records of the reference's data/coco_30k.csv first (the
     # committed fixture tests/golden/coco30k_rows.csv, with their own evaluation seeds), then rows of the same schema
     # from the caption grammar (tools/make_prompts_csv.py); row r of every `world` belongs to rank r
-    table = prompt_table(world * n_images)
+    table = prompt_table(world * max(n_images, rowwise_images))
     mine = table[rank::world]
     extra = {} if vae else {"output_type": "latent"}
 

@@ -120,3 +120,50 @@ def test_latents_at_sd14_size_match_fp32_within_stated_tolerance():
     assert final_prod <= FINAL_TOL, (final_prod, final_torch)
     assert max(per_call.values()) <= 1.25 * max(per_call_torch.values()) + 0.01, (per_call, per_call_torch)
     assert final_prod <= 1.25 * final_torch + 0.01, (final_prod, final_torch)
+
+
+def test_unet_call_at_the_generation_batch_matches_fp32_within_the_per_call_tolerance():
+    """The dispatch of sd/unet.py depends on the batch: at one prompt per call (the test above) the small layers stay with the
+    GEMM library, at the generation batch every linear layer, every 64 x 64 / 32 x 32 / 16 x 16 convolution, the packed q|k|v
+    attention and the fused epilogues are the hand-written kernels.  ONE U-Net evaluation at SD-1.4 size with 16 prompts (CFG
+    batch 32) - the same bf16-rounded weights through fp32 torch ops, through the product path and through torch's own bf16
+    ops - under the per-call tolerance stated above."""
+    from uce_amd.sd import pipeline as sdp
+    dev = "cuda:0"
+    pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.float32, dev, synthetic=True, vae=False, seed=0)
+    for p in pipe.unet.parameters():
+        p.data.copy_(p.data.to(torch.bfloat16).float())
+    g = torch.Generator().manual_seed(7)
+    n = 16
+    lat = torch.randn((n, 4, 64, 64), generator=g).to(torch.bfloat16)
+    ctx = (torch.randn((2 * n, 77, 768), generator=g) * 0.5).to(torch.bfloat16)
+    t = torch.tensor([481], device=dev)
+    x = torch.cat([lat] * 2).to(dev)
+    try:
+        _set_hip(False)
+        ref = pipe.unet(x.float(), t, ctx.to(dev).float()).float()
+        pipe.unet.to(torch.bfloat16)
+        tb = pipe.unet(x, t, ctx.to(dev)).float()
+        _set_hip(True)
+        from uce_amd import edit as E
+        calls = {"linear": 0, "conv": 0, "packed": 0}
+        orig = (E.UceHandle.linear, E.UceHandle.conv3x3_igemm, E.UceHandle.sattn_packed)
+
+        def wrap(name, fn):
+            def inner(self, *a, **k):
+                calls[name] += 1
+                return fn(self, *a, **k)
+            return inner
+        E.UceHandle.linear, E.UceHandle.conv3x3_igemm, E.UceHandle.sattn_packed = (wrap("linear", orig[0]), wrap("conv", orig[1]),
+                                                                                   wrap("packed", orig[2]))
+        try:
+            got = pipe.unet(x.contiguous(memory_format=torch.channels_last), t, ctx.to(dev)).float()
+        finally:
+            E.UceHandle.linear, E.UceHandle.conv3x3_igemm, E.UceHandle.sattn_packed = orig
+    finally:
+        _set_hip(True)
+    assert calls["packed"] >= 15 and calls["linear"] >= 100 and calls["conv"] >= 20, calls     # the own kernels really ran
+    e_prod, e_torch = O.rel_fro(got, ref), O.rel_fro(tb, ref)
+    print(json.dumps(dict(batch=2 * n, product_bf16_vs_fp32=e_prod, torch_bf16_vs_fp32=e_torch, calls=calls)))
+    assert e_prod <= PER_CALL_TOL, (e_prod, e_torch)
+    assert e_prod <= 1.25 * e_torch + 0.01, (e_prod, e_torch)

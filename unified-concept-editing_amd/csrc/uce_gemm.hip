@@ -306,6 +306,13 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   int bm = (tiles256 < 256 && M > 128) ? 128 : 256;
   if (bn == 128) bm = 256;
   int nst = 4;
+  // Short contractions (K <= 320: ten k-tiles per output tile, the 64 x 64 level of the U-Net): prologue and epilogue are as
+  // long as the main loop, so the shallow-ring forms that put TWO workgroups on a CU win (tools/probe_r04.py, M = 131072:
+  // N = 320: 47 us against 55; GEGLU N = 2560: 336 against 381); longer contractions keep the deep ring
+  if (K <= 320 && M >= 65536) {
+    if (N <= 320) { nst = 2; bm = 128; bn = 320; }
+    else if (N >= 2560 && N % 256 == 0) { nst = 3; bm = 128; bn = 256; }
+  }
   if (force_tile > 0) { nst = force_tile >= 1000000 ? force_tile / 1000000 : 4; bm = (force_tile / 1000) % 1000; bn = force_tile % 1000; }
   // whole-row epilogue where the rows allow 16-byte accesses (every layer of the U-Net); `wide` = 0 keeps the per-lane stores
   const int nout = geglu ? N / 2 : N;
