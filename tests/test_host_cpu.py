@@ -373,7 +373,8 @@ def test_conv_dispatch_rule_and_padded_narrow_weights():
         assert E.conv_prefers_igemm(64, 64, 320, 320, 32)            # U-Net 64 x 64 at the generation batch
         assert E.conv_prefers_igemm(32, 32, 320, 640, 32)            # 32 x 32, 320-multiple output: direct-to-LDS form
         assert E.conv_prefers_igemm(32, 32, 1920, 640, 32)
-        assert not E.conv_prefers_igemm(16, 16, 1280, 1280, 32)      # too few pixel tiles: im2col + library GEMM
+        assert E.conv_prefers_igemm(16, 16, 1280, 1280, 32)          # 64 x 4 tiles of 128 x 320: every CU has one
+        assert not E.conv_prefers_igemm(16, 16, 1280, 1280, 8)       # too few pixel tiles: im2col + library GEMM
         assert not E.conv_prefers_igemm(8, 8, 1280, 1280, 32)
         assert E.conv_prefers_igemm(512, 512, 128, 128, 16)          # VAE decoder
         assert E.conv_prefers_igemm(32, 32, 320, 320, 32, stride=2)      # Downsample2D at the generation batch: own kernel

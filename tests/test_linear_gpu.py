@@ -67,8 +67,8 @@ def test_linear_matches_fp64(H, M, N, K, dtype, bias, res):
     assert torch.equal(y, H.linear(x, w, b, r))           # bit-repeatable
 
 
-@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128", "2128320", "3128256", "3256128"])
-@pytest.mark.parametrize("M,N,K", [(700, 960, 320), (256, 640, 96)])
+@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128", "2128320", "3128256", "3256128", "64256320", "64256256", "64128320"])
+@pytest.mark.parametrize("M,N,K", [(700, 960, 320), (256, 640, 96), (1500, 640, 1280)])
 def test_linear_every_tile_form_forced(tile, M, N, K):
     """UCE_GEMM_TILE pins one tile form for every call (read at uce_create): each form - the last three are the shallow rings
     that put two workgroups on a CU - on shapes with ragged row and column tiles, with bias + residual, and with the GEGLU

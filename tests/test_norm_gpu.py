@@ -330,8 +330,8 @@ def test_conv3x3_stride2_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, res):
     assert O.rel_fro(y.double().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
 
 
-@pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "128256", "256128", "128128"])
-@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(2, 64, 1280, 12, 10), (3, 96, 256, 16, 16)])
+@pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "128256", "256128", "128128", "64256320", "64128320", "64256256", "64128256"])
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(2, 64, 1280, 12, 10), (3, 96, 256, 16, 16), (2, 192, 640, 20, 14)])
 def test_conv3x3_every_tile_form_with_residual(tile, N, Cin, Cout, Hh, Ww):
     """UCE_CONV_TILE pins the tile of the direct-to-LDS convolution: every form (where it divides Cout), with bias and the
     residual epilogue, ragged pixel tiles."""
@@ -339,6 +339,8 @@ def test_conv3x3_every_tile_form_with_residual(tile, N, Cin, Cout, Hh, Ww):
     from uce_amd import edit as E
     if tile != "0" and Cout % (int(tile) % 1000):
         pytest.skip("tile width does not divide Cout")
+    if int(tile) >= 1000000 and Cin % 64:
+        pytest.skip("128-byte k-tiles need Cin % 64 == 0")
     old = os.environ.get("UCE_CONV_TILE")
     os.environ["UCE_CONV_TILE"] = tile
     try:

@@ -59,7 +59,7 @@ def gemm():
         if tag == "ff_proj":
             ent["torch_geglu_us"] = timeit(lambda: H0.geglu(F.linear(x, w, b)))
             ent["own_geglu_us"] = timeit(lambda: H0.linear(x, w, b, geglu=True))
-        for tile in (256320, 128320, 256256, 128256, 2128320, 3128256, 3256128):
+        for tile in (256320, 128320, 256256, 2128320, 3128256, 64256320, 64256256, 64128320):
             Hv = handle(UCE_GEMM_TILE=tile)
             ent[f"t{tile}_us"] = timeit(lambda: Hv.linear(x, w, b))
             if tag == "ff_proj":
@@ -100,7 +100,7 @@ def conv():
                 torch.addmm(b, cols, wmat.t(), out=y)
             ent["im2col_own_gemm_us"] = timeit(im2col_own)
             ent["im2col_lib_gemm_us"] = timeit(im2col_lib)
-        for tile in (256320, 128320, 256256, 128256, 256128, 128128):
+        for tile in (256320, 128320, 256256, 128128, 64256320, 64128320, 64256256):
             if Cout % (tile % 1000):
                 continue
             Hv = handle(UCE_CONV_TILE=tile)

@@ -34,7 +34,7 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int CD_BK = 32, CD_NST = 4;
+
 
 template <bool F16>
 __device__ __forceinline__ float16_t cd_mfma(uint4_t a, uint4_t b, float16_t c) {
@@ -55,8 +55,8 @@ __device__ __forceinline__ float cd_tof(unsigned short v) {
   else return __builtin_bit_cast(float, (unsigned)v << 16);
 }
 
-template <int BM, int BN>
-constexpr size_t cd_smem() { return (size_t)CD_NST * (BM + BN) * CD_BK * 2; }
+template <int BM, int BN, int BK>
+constexpr size_t cd_smem() { return (size_t)(BK == 32 ? 4 : 2) * (BM + BN) * BK * 2; }
 
 // waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 2 .. 5)
 __device__ __forceinline__ void cd_wait_two_tiles(int per) {
@@ -66,7 +66,9 @@ __device__ __forceinline__ void cd_wait_two_tiles(int per) {
   else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE>
+// BK: input channels per k-tile (one tap x BK channels).  32 = 64-byte pixel segments and a ring of four stages; 64 = 128-byte
+// segments (whole cache lines, half the barriers) and a ring of two - 5-10 % ahead on uce_gemm.hip's shapes wherever Cin % 64 == 0.
+template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE, int BK = 32>
 __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                      long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
@@ -76,10 +78,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   static_assert(WGM * WGN == 8, "eight waves");
   constexpr int CD_BM = 32 * TM * WGM;
   static_assert(CD_BM == 128 || CD_BM == 256, "128 or 256 pixels");
-  constexpr int NA = CD_BM / 128;                                     // A wave instructions per wave and k-tile
+  constexpr int CD_BK = BK;
+  constexpr int NST = BK == 32 ? 4 : 2;                               // ring stages
+  constexpr int PPR = BK / 8;                                         // 16-byte pieces per pixel segment
+  constexpr int RPW = 64 / PPR;                                       // rows per DMA wave instruction (16 / 8)
+  constexpr int NA = CD_BM / (RPW * 8);                               // A wave instructions per wave and k-tile
   constexpr int BN = 32 * TN * WGN;
   constexpr int STAGE = (CD_BM + BN) * CD_BK * 2;
-  constexpr int NB = BN / 16;                                         // wave instructions per B image (16 or 20)
+  constexpr int NB = BN / RPW;                                        // wave instructions per B image
+  constexpr int NBJ = (NB + 7) / 8;
+  static_assert(NA <= 4 && NBJ <= 5 && NST * STAGE <= 160 * 1024, "staging");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w % WGM, wn = w / WGM;
@@ -98,15 +106,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   const int cch = Cin / CD_BK, NK = 9 * cch;
   const long K = 9L * Cin;
 
-  // ---- staging coordinates (k-tile invariant).  A wave instruction fills 16 rows x 64 B; lane = (row r, piece p).
-  const int r = lane >> 2, p = lane & 3;
+  // ---- staging coordinates (k-tile invariant).  A wave instruction fills RPW rows x 2 BK bytes; lane = (row r, piece p); the
+  // bank swizzle is applied to the SOURCE piece: (R >> 2) & 3 for 64-byte rows, (R >> 1) & 7 for 128-byte rows
+  auto swz = [](int Rr) { return BK == 32 ? ((Rr >> 2) & 3) : ((Rr >> 1) & 7); };
+  const int r = lane / PPR, p = lane % PPR;
   constexpr unsigned OOB = 0x80000000u;
-  int a_y[2], a_x[2];                                                  // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
-  unsigned a_base[2];                                                  // byte offset of (image, channel piece); OOB: no pixel
+  int a_y[4], a_x[4];                                                  // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
+  unsigned a_base[4];                                                  // byte offset of (image, channel piece); OOB: no pixel
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int R = 16 * (8 * j + w) + r;
-    const int c = p ^ ((R >> 2) & 3);
+    const int R = RPW * (8 * j + w) + r;
+    const int c = p ^ swz(R);
     const long m = m0 + R;
     if (m < M) {
       const long img = m / ((long)H * W);
@@ -121,15 +131,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
       a_base[j] = 0;
     }
   }
-  unsigned b_base[3];
+  unsigned b_base[5];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < NBJ; ++j) {
     const int g = 8 * j + w;
-    const int R = 16 * g + r;
-    const int c = p ^ ((R >> 2) & 3);
+    const int R = RPW * g + r;
+    const int c = p ^ swz(R);
     b_base[j] = (g < NB && n0 + R < Cout) ? (unsigned)(((long)(n0 + R) * K + c * 8) * 2) : OOB;
   }
-  const int per = NA + (w < NB ? 1 : 0) + (8 + w < NB ? 1 : 0) + (16 + w < NB ? 1 : 0);  // this wave's DMAs per k-tile (2 .. 5)
+  int per = NA;                                                        // this wave's DMAs per k-tile
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) per += (8 * j + w < NB) ? 1 : 0;
   const long x_bytes = (M / ((long)H * W)) * (long)Hs * Ws * Cin * 2;
   const long w_bytes = (long)Cout * K * 2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
@@ -147,11 +159,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16, ok ? off : OOB, 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NBJ; ++j) {
       if (8 * j + w < NB)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + CD_BM * 64 + (8 * j + w) * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + CD_BM * CD_BK * 2 + (8 * j + w) * 1024), 16,
                                                  b_base[j] == OOB ? OOB : b_base[j] + (unsigned)(kt * CD_BK * 2), 0, 0, 0);
     }
+  };
+  // waits until this wave's DMAs of every k-tile but the last (NST - 2) issued have landed
+  auto wait_ring = [&]() {
+    if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else cd_wait_two_tiles(per);
   };
 
   float16_t acc[TN][TM];                                               // [channel tile][pixel tile]
@@ -168,30 +185,33 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   for (int a = 0; a < TN; ++a) brow[a] = (wn * TN + a) * 32 + li;
 
   const int last = NK - 1;                                             // (past the last tile the ring re-loads it: constant counts)
-  stage(0, 0);
-  stage(1, 1 < last ? 1 : last);
-  stage(2, 2 < last ? 2 : last);
-  cd_wait_two_tiles(per);
+  constexpr int AHEAD = NST - 1;
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) stage(i, i < last ? i : last);
+  wait_ring();
   __builtin_amdgcn_s_barrier();
+  int slot = 0, fill = AHEAD;
   for (int kt = 0; kt < NK; ++kt) {
-    stage((kt + 3) & 3, kt + 3 < last ? kt + 3 : last);
-    const unsigned char* Ab = smem + (kt & 3) * STAGE;
-    const unsigned char* Bb = Ab + CD_BM * 64;
+    stage(fill, kt + AHEAD < last ? kt + AHEAD : last);
+    const unsigned char* Ab = smem + slot * STAGE;
+    const unsigned char* Bb = Ab + CD_BM * CD_BK * 2;
 #pragma unroll
     for (int s = 0; s < CD_BK / 16; ++s) {
       const int c = 2 * s + lh;
       uint4_t pf[TM], cf[TN];
 #pragma unroll
-      for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * 64 + ((c ^ ((arow[b] >> 2) & 3)) << 4));
+      for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * (2 * CD_BK) + ((c ^ swz(arow[b])) << 4));
 #pragma unroll
-      for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * 64 + ((c ^ ((brow[a] >> 2) & 3)) << 4));
+      for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * (2 * CD_BK) + ((c ^ swz(brow[a])) << 4));
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = cd_mfma<F16>(cf[a], pf[b], acc[a][b]);   // rows = channels, columns = pixels
     }
-    cd_wait_two_tiles(per);                                            // this wave's part of tile kt + 1 has landed
+    wait_ring();                                                       // this wave's part of tile kt + 1 has landed
     __builtin_amdgcn_s_barrier();
+    slot = slot + 1 == NST ? 0 : slot + 1;
+    fill = fill + 1 == NST ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
 
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool WIDE>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int BK = 32>
 int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
                hipStream_t st, int sd, const void* res) {
   constexpr int BM = 32 * TM * WGM;
@@ -245,19 +265,19 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
   const int ntiles = (Cout + BN - 1) / BN;
   const long nwg = mtiles * ntiles;
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
-  const size_t smem = cd_smem<BM, BN>();
+  const size_t smem = cd_smem<BM, BN, BK>();
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
                        (int)mtiles, ntiles, sd, (const unsigned short*)res);
   else
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
                        (int)mtiles, ntiles, sd, (const unsigned short*)res);
   UCE_LAUNCH_CHECK();
@@ -273,16 +293,25 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
                     int dtype, hipStream_t st, int* rc, int sd, const void* res, int force, int wide) {
   *rc = UCE_OK;
-  if (Cin % CD_BK || Cout % 4) return 0;
+  if (Cin % 32 || Cout % 4) return 0;
   int bn = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : Cout % 128 == 0 ? 128 : 0;
   if (!bn) return 0;
   const long t256 = ((M + 255) / 256) * (Cout / bn), t128 = ((M + 127) / 128) * (Cout / bn);
   int bm = 256;
   if (t256 < 200) bm = 128;
   if (bm == 128 && t128 < 200 && Cout % 128 == 0) bn = 128;
-  if (force > 0) { bm = force / 1000; bn = force % 1000; }
-  if (Cout % bn) return 0;
+  int bk = (Cin % 64 == 0 && bn != 128) ? 64 : 32;     // 128-byte k-tiles wherever the channel count allows (the 128-wide tiles keep 64 bytes)
+  if (force > 0) { bk = force >= 1000000 ? 64 : 32; bm = (force / 1000) % 1000; bn = force % 1000; }
+  if (Cout % bn || Cin % bk) return 0;
   const bool wide_ok = wide && Cout % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)res & 15);
+  if (bk == 64 && wide_ok) {                             // UCE_CONV_TILE = 64256320 / 64256256 / 64128320 pins one
+#define UCE_CD64(WGM, WGN, TM, TN) { *rc = launch_dma<WGM, WGN, TM, TN, true, 64>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res); return 1; }
+    if (bm == 256 && bn == 320) UCE_CD64(4, 2, 2, 5)
+    if (bm == 256 && bn == 256) UCE_CD64(2, 4, 4, 2)
+    if (bm == 128 && bn == 320) UCE_CD64(4, 2, 1, 5)
+    if (bm == 128 && bn == 256) UCE_CD64(2, 4, 2, 2)
+#undef UCE_CD64
+  }
 #define UCE_CD(WGM, WGN, TM, TN)                                                                                             \
   {                                                                                                                          \
     *rc = wide_ok ? launch_dma<WGM, WGN, TM, TN, true>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res)            \

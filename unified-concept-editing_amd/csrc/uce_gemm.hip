@@ -31,7 +31,6 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int GD_BK = 32;
 
 template <bool F16>
 __device__ __forceinline__ float16_t gd_mfma(uint4_t a, uint4_t b, float16_t c) {
@@ -76,8 +75,11 @@ __device__ __forceinline__ void gd_wait_dma(int n) {
 // NST: LDS stages of the ring (NST - 1 k-tiles in flight).  4 = one workgroup per CU with a deep ring; 2 / 3 = a ring shallow
 // enough (<= 80 KB with the epilogue's slabs) that TWO workgroups share a CU - one's prologue / epilogue under the other's main
 // loop, what the short contractions (K = 320: ten k-tiles per output tile) need.
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST>
-__global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
+// BK: contraction elements per k-tile.  32 = 64-byte row segments (16 rows per DMA instruction) with the deep ring; 64 = 128-byte
+// segments - whole cache lines, 8 rows per instruction, half the barriers per contraction - with a two-stage ring (one k-tile of
+// ~2500 MFMA cycles in flight covers the DMA latency).
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32>
+__global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
                                                   const unsigned short* __restrict__ Wt,
                                                   const unsigned short* __restrict__ bias,
                                                   const unsigned short* __restrict__ R, long ldr,
@@ -85,11 +87,15 @@ __global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsign
                                                   int mtiles, int ntiles, int outf32) {
   static_assert(WGM * WGN == 8, "eight waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-  static_assert(BM == 128 || BM == 256, "A image: one or two 16-row DMA instructions per wave");
-  constexpr int NA = BM / 128;                                         // A wave instructions per wave and k-tile
-  constexpr int NB = BN / 16;                                          // B wave instructions per k-tile (all waves)
+  static_assert(BM == 128 || BM == 256, "A image: whole DMA instructions per wave");
+  static_assert(BK == 32 || BK == 64, "k-tile");
+  constexpr int PPR = BK / 8;                                          // 16-byte pieces per row segment
+  constexpr int RPW = 64 / PPR;                                        // rows per DMA wave instruction (16 / 8)
+  constexpr int NA = BM / (RPW * 8);                                   // A wave instructions per wave and k-tile (1, 2 / 2, 4)
+  constexpr int NB = BN / RPW;                                         // B wave instructions per k-tile (all waves)
   constexpr int NBJ = (NB + 7) / 8;
-  constexpr int STAGE = (BM + BN) * GD_BK * 2;
+  static_assert(NA <= 4 && NBJ <= 5, "staging registers");
+  constexpr int STAGE = (BM + BN) * BK * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w % WGM, wn = w / WGM;
@@ -103,25 +109,28 @@ __global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsign
   }
   const long m0 = (tile / ntiles) * BM;
   const int n0 = (int)(tile % ntiles) * BN;
-  const int NK = K / GD_BK;
+  const int NK = K / BK;
 
-  // ---- staging coordinates (k-tile invariant).  A wave instruction fills 16 rows x 64 B; lane = (row r, piece p).
-  const int r = lane >> 2, p = lane & 3;
+  // ---- staging coordinates (k-tile invariant).  A wave instruction fills RPW rows x 2 BK bytes; lane = (row r, piece p).
+  // Bank swizzle on the SOURCE piece: row R stores piece p ^ swz(R) at slot p - (R >> 2) & 3 for the 64-byte rows, (R >> 1) & 7 for
+  // the 128-byte rows (16 consecutive rows of a b128 fragment read then fall on 16 distinct 16-byte bank slots)
+  auto swz = [](int Rr) { return BK == 32 ? ((Rr >> 2) & 3) : ((Rr >> 1) & 7); };
+  const int r = lane / PPR, p = lane % PPR;
   constexpr unsigned OOB = 0x80000000u;
-  unsigned a_base[2];          // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
+  unsigned a_base[4];          // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int Rr = 16 * (8 * j + w) + r;
-    const int c = p ^ ((Rr >> 2) & 3);
+    const int Rr = RPW * (8 * j + w) + r;
+    const int c = p ^ swz(Rr);
     const long m = m0 + Rr;
     a_base[j] = (m < M) ? (unsigned)((m * ldx + c * 8) * 2) : OOB;
   }
-  unsigned b_base[3];
+  unsigned b_base[5];
 #pragma unroll
   for (int j = 0; j < NBJ; ++j) {
     const int g = 8 * j + w;
-    const int Rr = 16 * g + r;
-    const int c = p ^ ((Rr >> 2) & 3);
+    const int Rr = RPW * g + r;
+    const int c = p ^ swz(Rr);
     b_base[j] = (g < NB && n0 + Rr < N) ? (unsigned)(((long)(n0 + Rr) * K + c * 8) * 2) : OOB;
   }
   int per = NA;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsign
 
   auto stage = [&](int st, int kt) {
     unsigned char* sbase = smem + st * STAGE;
-    const unsigned koff = (unsigned)(kt * GD_BK * 2);
+    const unsigned koff = (unsigned)(kt * BK * 2);
 #pragma unroll
     for (int j = 0; j < NA; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16,
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsign
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
       if (8 * j + w < NB)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + BM * 64 + (8 * j + w) * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + BM * BK * 2 + (8 * j + w) * 1024), 16,
                                                  b_base[j] == OOB ? OOB : b_base[j] + koff, 0, 0, 0);
     }
   };
@@ -170,15 +179,15 @@ __global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsign
   for (int kt = 0; kt < NK; ++kt) {
     stage(fill, kt + AHEAD < last ? kt + AHEAD : last);
     const unsigned char* Ab = smem + slot * STAGE;
-    const unsigned char* Bb = Ab + BM * 64;
+    const unsigned char* Bb = Ab + BM * BK * 2;
 #pragma unroll
-    for (int s = 0; s < GD_BK / 16; ++s) {
+    for (int s = 0; s < BK / 16; ++s) {
       const int c = 2 * s + lh;
       uint4_t pf[TM], cf[TN];
 #pragma unroll
-      for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * 64 + ((c ^ ((arow[b] >> 2) & 3)) << 4));
+      for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * (2 * BK) + ((c ^ swz(arow[b])) << 4));
 #pragma unroll
-      for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * 64 + ((c ^ ((brow[a] >> 2) & 3)) << 4));
+      for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * (2 * BK) + ((c ^ swz(brow[a])) << 4));
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(512, NST == 4 ? 2 : 4) void k_gemm_dma(const unsign
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST>
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32>
 int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                int K, hipStream_t st, int outf32 = 0) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -262,31 +271,32 @@ int launch_one(const void* x, long ldx, const void* w, const void* bias, const v
   const int ntiles = (N + BN - 1) / BN;
   const long nwg = mtiles * ntiles;
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
-  constexpr size_t ring = (size_t)NST * (BM + BN) * GD_BK * 2;
+  constexpr size_t ring = (size_t)NST * (BM + BN) * BK * 2;
   constexpr size_t slabs = WIDE ? (size_t)8 * uce_epi::wave_bytes<(NST == 4 || TN < 2) ? TN : 2, GEGLU>() : 0;
   constexpr size_t smem = ring > slabs ? ring : slabs;
-  static_assert(NST == 4 || smem <= 80 * 1024, "two workgroups per CU");
+  static_assert(NST == 4 || BK == 64 || smem <= 80 * 1024, "two workgroups per CU");
+  static_assert(smem <= 160 * 1024, "LDS");
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
     attr_once.commit(tok);
   }
-  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                      ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
                      (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4, int BK = 32>
 int launch_shape(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                  int K, int geglu, int dtype, hipStream_t st, int outf32 = 0) {
   if (dtype == UCE_DTYPE_F16)
-    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32);
-  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32);
+    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
+                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32);
+  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
+               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32);
 }
 
 // padded MFMA work of an N-wide output on BN-wide tiles, relative
@@ -298,26 +308,44 @@ inline long waste(int N, int BN) { return (long)((N + BN - 1) / BN) * BN; }
 // 256 the VAE's and the text encoder's widths), and 128-row tiles when 256-row tiles would leave CUs without a workgroup
 int launch_linear(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                   int K, int geglu, int dtype, hipStream_t st, int force_tile, int wide, int outf32) {
+  // Tile: the one whose padded work per CU - ceil(tiles / 256) x BM x BN, over the tile's measured efficiency (256 x 320: 1,
+  // 256 x 256: 0.95, 128 x 320: 0.8; tools/probe_r04.py) - is smallest: 320-wide tiles for SD's 320-multiples unless a narrower or
+  // shorter tile fills the chip's last round better (M = 8192: N = 1280 -> 128 x 320, N = 3840 -> 256 x 256); N that only 128
+  // divides (the VAE's narrow layers) keeps 256 x 128
   const long w320 = waste(N, 320), w256 = waste(N, 256), w128 = waste(N, 128);
-  int bn = 320;
-  if (w256 < w320) bn = 256;
-  if (w128 < (bn == 320 ? w320 : w256)) bn = 128;
-  long tiles256 = ((M + 255) / 256) * ((N + bn - 1) / bn);
-  int bm = (tiles256 < 256 && M > 128) ? 128 : 256;
-  if (bn == 128) bm = 256;
+  int bm = 256, bn = 320;
+  if (w128 < w320 && w128 < w256) {
+    bn = 128;
+  } else {
+    double best = -1.0;
+    const int cand[3][2] = {{256, 320}, {256, 256}, {128, 320}};
+    const double eff[3] = {1.0, 0.95, 0.8};
+    for (int i = 0; i < 3; ++i) {
+      if (cand[i][0] == 128 && M <= 128) continue;
+      const long T = ((M + cand[i][0] - 1) / cand[i][0]) * ((N + cand[i][1] - 1) / cand[i][1]);
+      const double cost = (double)((T + 255) / 256) * cand[i][0] * cand[i][1] / eff[i];
+      if (best < 0.0 || cost < best) { best = cost; bm = cand[i][0]; bn = cand[i][1]; }
+    }
+  }
   int nst = 4;
   // Short contractions (K <= 320: ten k-tiles per output tile, the 64 x 64 level of the U-Net): prologue and epilogue are as
   // long as the main loop, so the shallow-ring forms that put TWO workgroups on a CU win (tools/probe_r04.py, M = 131072:
   // N = 320: 47 us against 55; GEGLU N = 2560: 336 against 381); longer contractions keep the deep ring
-  if (K <= 320 && M >= 65536) {
-    if (N <= 320) { nst = 2; bm = 128; bn = 320; }
-    else if (N >= 2560 && N % 256 == 0) { nst = 3; bm = 128; bn = 256; }
-  }
+  if (K <= 320 && M >= 65536 && N <= 320) { nst = 2; bm = 128; bn = 320; }
+  else if (K <= 320 && M >= 65536 && N >= 2560 && N % 256 == 0) { nst = 3; bm = 128; bn = 256; }
+  else if (K % 64 == 0 && bn != 128) nst = 64;         // 128-byte k-tiles, two stages: 5-10 % ahead of the 64-byte ring wherever K allows
   if (force_tile > 0) { nst = force_tile >= 1000000 ? force_tile / 1000000 : 4; bm = (force_tile / 1000) % 1000; bn = force_tile % 1000; }
   // whole-row epilogue where the rows allow 16-byte accesses (every layer of the U-Net); `wide` = 0 keeps the per-lane stores
   const int nout = geglu ? N / 2 : N;
   const bool wide_ok = wide && !outf32 && nout % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && (!res || (ldr % 8 == 0 && !((uintptr_t)res & 15)));
   if (!wide_ok) nst = 4;
+  // 64-wide k-tiles, two stages (UCE_GEMM_TILE = 64256320 / 64256256 / 64128320; K % 64 == 0, whole-row epilogue)
+  if (nst == 64 && K % 64 == 0 && wide_ok) {
+    if (bm == 256 && bn == 320) return launch_shape<4, 2, 2, 5, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+    if (bm == 256 && bn == 256) return launch_shape<2, 4, 4, 2, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+    if (bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
+  }
+  if (nst == 64) nst = 4;
   // two workgroups per CU (shallow ring): UCE_GEMM_TILE = 2128320 / 3128256 / 3256128
   if (nst == 2 && bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
   if (nst == 3 && bm == 128 && bn == 256) return launch_shape<2, 4, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st);
@@ -342,7 +370,7 @@ extern "C" int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const voi
   if (epilogue != UCE_EPILOGUE_NONE && epilogue != UCE_EPILOGUE_GEGLU && epilogue != UCE_EPILOGUE_F32) return UCE_EINVAL;
   const int geglu = epilogue == UCE_EPILOGUE_GEGLU, outf32 = epilogue == UCE_EPILOGUE_F32;
   // 64-byte k-tiles, 8-byte epilogue accesses, 16-byte DMA pieces
-  if (K % GD_BK || N % 4 || ldx < K || ldx % 8 || ldy % 4 || (residual && (ldr % 4 || geglu))) return UCE_EINVAL;
+  if (K % 32 || N % 4 || ldx < K || ldx % 8 || ldy % 4 || (residual && (ldr % 4 || geglu))) return UCE_EINVAL;
   if (geglu && N % 32) return UCE_EINVAL;
   if (ldy < (geglu ? N / 2 : N) || (residual && ldr < N)) return UCE_EINVAL;
   if ((((uintptr_t)x | (uintptr_t)w) & 15) || (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 7)) return UCE_EINVAL;

@@ -37,7 +37,11 @@ def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32, stride:
     # 736-761 for im2col + GEMM) or a long contraction on the 128 x 128 kernel; 16 x 16 and 8 x 8 layers have too few
     # pixel tiles for either (1280 -> 1280 @ 16 x 16 x 32: 284 us with 128-pixel tiles against 225 for im2col + library GEMM;
     # @ 8 x 8: 141 against 93)
-    return M >= 32 * 1024 and (Cin >= 640 or Cout % 256 == 0 or Cout % 320 == 0)
+    if M >= 32 * 1024 and (Cin >= 640 or Cout % 256 == 0 or Cout % 320 == 0):
+        return True
+    # 16 x 16 at 32 samples: with 128-byte k-tiles and 128-pixel tiles the direct-to-LDS kernel ties im2col + library GEMM (1280 ->
+    # 1280: 229 us against 221) as soon as every CU gets a 128 x 320 tile - and needs no patch matrix
+    return Cin % 64 == 0 and Cout % 320 == 0 and -(-M // 128) * (Cout // 320) >= 256
 
 
 def even_chunk(n: int, cap: int) -> int:
