@@ -102,17 +102,21 @@ def test_sattn_rejects_bad_arguments(H):
         H.sattn(q, q, q, 8)
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
     (2, 8, 1024, 1024, 40, torch.bfloat16),     # dh = 40: one / two query tiles per wave, the pipelined kernel
     (1, 8, 300, 130, 40, torch.bfloat16),       # ragged: a 256-row workgroup with a partial second tile, three key tiles
     (3, 4, 77, 64, 40, torch.float16),          # exactly one key tile (the pipeline's prologue only)
     (2, 8, 512, 200, 80, torch.bfloat16),       # dh = 80: k_sattn and k_sattn_p
     (1, 2, 40, 1, 80, torch.bfloat16),          # a single key
+    (2, 4, 100, 33, 40, torch.bfloat16),        # one key tile whose second half holds a single key
+    (2, 4, 260, 97, 40, torch.bfloat16),        # two key tiles, the last with one key in its second half
+    (1, 4, 257, 128, 40, torch.float16),        # exactly two full key tiles (no padding path in the last tile)
+    (1, 8, 256, 4000, 48, torch.bfloat16),      # 63 key tiles, dh = DHP
 ])
 def test_sattn_every_kernel_form_forced(variant, B, H_, Lq, Lk, dh, dtype):
-    """k_sattn with one (1) and two (2) query tiles per wave and the software-pipelined k_sattn_p (3), each forced through a
-    handle of its own (UCE_SATTN_QT is read at uce_create) at sizes the by-shape rule would not send there."""
+    """k_sattn with one (1) and two (2) query tiles per wave, the software-pipelined k_sattn_p (3) and the half-tile pipeline
+    k_sattn_h (4; dh <= 48, elsewhere the by-shape kernel), each forced through a handle of its own (UCE_SATTN_QT is read at uce_create) at sizes the by-shape rule would not send there."""
     import os
     from uce_amd import edit as E
     old = os.environ.get("UCE_SATTN_QT")
@@ -140,3 +144,38 @@ def test_sattn_every_kernel_form_forced(variant, B, H_, Lq, Lk, dh, dtype):
     assert torch.equal(o, again)
     if Lk == 1:
         assert torch.equal(o.cpu(), v.expand(B, Lq, C).contiguous())
+
+
+def test_sattn_half_tile_pipeline_rising_max_and_packed():
+    """k_sattn_h forced: keys ordered so that the running maximum rises in every half tile (the deferred P V product is
+    rescaled together with the accumulators), and the packed q | k | v entry against three separate tensors."""
+    import os
+    from uce_amd import edit as E
+    old = os.environ.get("UCE_SATTN_QT")
+    os.environ["UCE_SATTN_QT"] = "4"
+    try:
+        Hv = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_SATTN_QT"]
+        else:
+            os.environ["UCE_SATTN_QT"] = old
+    try:
+        g = torch.Generator().manual_seed(21)
+        B, H_, Lq, Lk, dh = 1, 4, 128, 640, 40
+        C = H_ * dh
+        q = (torch.randn(B, Lq, C, generator=g).abs() * 3).to(torch.bfloat16).cuda()
+        ramp = torch.linspace(0.1, 3.0, Lk)[None, :, None]
+        k = (torch.randn(B, Lk, C, generator=g).abs() * ramp).to(torch.bfloat16).cuda()
+        v = torch.randn(B, Lk, C, generator=g).to(torch.bfloat16).cuda()
+        o = Hv.sattn(q, k, v, H_, scale=0.5)
+        assert torch.isfinite(o.float()).all()
+        assert O.rel_fro(o.double().cpu(), _ref_gpu(q, k, v, H_, scale=0.5).cpu()) < TOL_BF16
+        qkv = torch.randn(3, 700, 3 * 320, generator=g).to(torch.bfloat16).cuda()
+        a = Hv.sattn_packed(qkv, 8)
+        qq, kk, vv = (t.contiguous() for t in qkv.split(320, dim=-1))
+        assert torch.equal(a, Hv.sattn(qq, kk, vv, 8))
+        assert O.rel_fro(a.double().cpu(), _ref_gpu(qq, kk, vv, 8).cpu()) < TOL_BF16
+    finally:
+        torch.cuda.synchronize()
+        Hv.close()

@@ -12,8 +12,11 @@
 //               final 1/sum are all per lane (one lane^32 exchange per tile for the max, none for the sum);
 //               O^T = V^T P^T with the P fragments straight out of the S^T accumulators (k_xattn's key
 //               permutation).  bf16/f16 MFMA 32x32x16, f32 softmax and accumulation.
-// The loop is VALU-bound on the softmax (32 exp2 per lane per 64 keys at quarter rate), not MFMA-bound.
+// The loop is VALU-bound on the softmax, not MFMA-bound (tools/ubench/valu_mfma.hip: v_exp_f32 8.2 cycles of the SIMD's VALU
+// per wave, v_fma_f32 4.75 for one wave and 2.4 when two waves alternate, cvt_pk / max3 4.3; per 64 x 64 tile and wave
+// ~310 VALU instructions = ~1900 cycles against 896 of matrix pipe).  k_sattn_h below interleaves the two pipes explicitly.
 #include "uce_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -590,6 +593,354 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_sattn_h: two query tiles per wave (k_sattn's QT = 2: every K / V^T fragment read from LDS feeds two MFMAs), pipelined
+// over HALF key tiles of 32 keys so that both pipes have work from different halves in every stretch of the stream:
+//   sub-step h:   [ P V of half h - 1  |  running max of half h ]   ->  (rarely: rescale O)  ->
+//                 [ K Q^T of half h + 1  |  exp2 + convert of half h ]
+// The MFMAs of each bracket do not depend on its VALU work and the instruction stream alternates them explicitly
+// (sched_group_barrier): k_sattn ran max -> exp -> P V -> K Q^T in sequence inside a wave and the two waves of a SIMD fell into
+// step with each other (both in their softmax, then both in their MFMAs: 2800 cycles per 64 x 64 tile for 1170 of VALU and
+// 896 of matrix pipe).  P V trails by one half so the rescale of O still covers it; K is staged two tiles ahead and V^T
+// one behind: three LDS buffers each.  dh < DVP only (the denominator comes out of the ones row of V^T).
+// ---------------------------------------------------------------------------------------------
+template <int DHP, bool F16, bool VTI>
+__global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
+                                                 const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
+                                                 int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
+                                                 unsigned short one) {
+  constexpr int NDV = (DHP + 31) / 32;
+  constexpr int DVP = NDV * 32;
+  static_assert(DHP < DVP, "the softmax denominator rides in the padding row of V^T");
+  constexpr int KLD = DHP + 8;
+  constexpr int VLD = KT + 4;
+  constexpr int NS = DHP / 16;
+  constexpr int KCH = DHP / 8;
+  constexpr int NKL = (KT * KCH + 255) / 256;
+  constexpr int VCH = KT / 8;
+  constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;
+  constexpr int KB = KT * KLD, VB = DVP * VLD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Kbuf = (unsigned short*)smem_raw;                  // [3][KB]
+  unsigned short* Vbuf = Kbuf + 3 * KB;                              // [3][VB]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int qx, h, b;
+  sattn_block(qx, h, b);
+  const int C = H * dh;
+  const int lq = lane & 31, lh = lane >> 5;
+  const long q0 = (long)qx * 256 + w * 64;
+
+  uint4_t qf[2][NS];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const long row = q0 + 32 * x + lq;
+    const unsigned short* qrow = Q + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * ld + (size_t)h * dh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int dim = 16 * s + 8 * lh;
+      qf[x][s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
+    }
+  }
+  const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
+  const unsigned short* vbase = VTI ? Vt + (size_t)b * Lk * ld + (size_t)h * dh : Vt + ((size_t)b * H + h) * DVP * LkP;
+  uint4_t rk[NKL], rv[NVL];
+  auto g_load_k = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int e = tid + 256 * i;
+      const int key = e / KCH, dim = (e - key * KCH) * 8;
+      rk[i] = (uint4_t){0u, 0u, 0u, 0u};
+      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
+    }
+  };
+  auto g_load_v = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int e = tid + 256 * i;
+      if constexpr (VTI) {
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        rv[i] = (uint4_t){0u, 0u, 0u, 0u};
+        if (e < KT * KCH && key0 + key < Lk && dim < dh) rv[i] = *(const uint4_t*)(vbase + (size_t)(key0 + key) * ld + dim);
+      } else {
+        const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+        if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
+      }
+    }
+  };
+  auto s_store_k = [&](int buf) {
+    unsigned short* Ks = Kbuf + buf * KB;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int e = tid + 256 * i;
+      const int key = e / KCH, dim = (e - key * KCH) * 8;
+      if (e < KT * KCH) *(uint4_t*)(Ks + key * KLD + dim) = rk[i];
+    }
+  };
+  auto s_store_v = [&](int buf) {
+    unsigned short* Vs = Vbuf + buf * VB;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int e = tid + 256 * i;
+      if constexpr (VTI) {
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        if (e < KT * KCH && dim < dh) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Vs[(dim + 2 * q) * VLD + key] = (unsigned short)(rv[i][q] & 0xffffu);
+            Vs[(dim + 2 * q + 1) * VLD + key] = (unsigned short)(rv[i][q] >> 16);
+          }
+        }
+      } else {
+        const int dv = e / VCH, kc = (e - dv * VCH) * 8;
+        if (e < DVP * VCH) {
+          *(uint2_t*)(Vs + dv * VLD + kc) = (uint2_t){rv[i][0], rv[i][1]};
+          *(uint2_t*)(Vs + dv * VLD + kc + 4) = (uint2_t){rv[i][2], rv[i][3]};
+        }
+      }
+    }
+  };
+  if constexpr (VTI) {
+    for (int e = tid; e < 3 * DVP * KT; e += 256) {
+      const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
+      const int dv = rem / KT, key = rem - dv * KT;
+      if (dv >= dh) Vbuf[buf * VB + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
+    }
+  }
+
+  float m[2] = {-INFINITY, -INFINITY};
+  float16_t oacc[2][NDV];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[x][nt][r] = 0.f;
+  uint4_t pf[2][2];                           // P fragments of the half before the current one (zero before the first)
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) pf[x][s2] = (uint4_t){0u, 0u, 0u, 0u};
+
+  const int ntiles = (Lk + KT - 1) / KT;
+  g_load_k(0);
+  g_load_v(0);
+  s_store_k(0);
+  s_store_v(0);
+  if (ntiles > 1) {
+    g_load_k(1);
+    s_store_k(1);
+  }
+  __syncthreads();
+  float16_t sA[2], sB[2];
+  {
+    const unsigned short* Ks = Kbuf + lq * KLD + 8 * lh;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[x][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint4_t kf = *(const uint4_t*)(Ks + 16 * s);
+#pragma unroll
+      for (int x = 0; x < 2; ++x) sA[x] = mfma32<F16>(kf, qf[x][s], sA[x]);
+    }
+  }
+
+  // one sub-step, in two parts.  head: sc = S^T of half hh (complete; MASK: the tile may hold padding keys - only the last
+  // does); P V of half hh - 1 from the 32 key columns at Vp beside the running max of half hh.  tail: sn <- S^T of half
+  // hh + 1 (rows of the K buffer at Kn; NEXT = false: there is none) beside exp2 and the P fragments of half hh.
+  float mc[2] = {0.f, 0.f};
+  auto sub_head = [&](auto mask_c, int hh, float16_t (&sc)[2], const unsigned short* Vp) __attribute__((always_inline)) {
+    constexpr bool MASK = decltype(mask_c)::value;
+    if constexpr (MASK) {
+      if ((hh + 1) * 32 > Lk) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = hh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sc[x][r] = (key < Lk) ? sc[x][r] : -INFINITY;
+          }
+      }
+    }
+    // ---- bracket 1: O^T += V^T P^T of the previous half | running max of this one.  The source order IS the issue order:
+    // one MFMA, a slice of the VALU work, a scheduling fence (left to itself the scheduler emits the VALU work first and the
+    // MFMAs in one run behind it, and sched_group_barrier pipelines did not change that).
+    float mt[2];
+    {
+      uint4_t vf[NDV][2];
+#pragma unroll
+      for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const unsigned short* vrow = Vp + (nt * 32 + lq) * VLD + 4 * lh + 16 * s2;
+          const uint2_t lo = *(const uint2_t*)(vrow);
+          const uint2_t hi = *(const uint2_t*)(vrow + 8);
+          vf[nt][s2] = (uint4_t){lo[0], lo[1], hi[0], hi[1]};
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4 * NDV; ++i) {
+        const int nt = i >> 2, s2 = (i >> 1) & 1, x = i & 1;
+        oacc[x][nt] = mfma32<F16>(vf[nt][s2], pf[x][s2], oacc[x][nt]);
+        if (i < 2) {                            // the tile maximum of query tile i (both key halves of the lane pair)
+          float ma = sc[i][0], mb = sc[i][8];
+#pragma unroll
+          for (int r = 1; r < 8; ++r) {
+            ma = fmaxf(ma, sc[i][r]);
+            mb = fmaxf(mb, sc[i][8 + r]);
+          }
+          const float mab = fmaxf(ma, mb);
+          const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mab), __builtin_bit_cast(unsigned, mab), false, false);
+          mt[i] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (__any(mt[0] > m[0] || mt[1] > m[1])) {  // the running max rarely moves after the first tiles
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const float m_new = fmaxf(m[x], mt[x]);
+        const float alpha = __builtin_amdgcn_exp2f((m[x] - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first half
+        m[x] = m_new;
+        mc[x] = m_new * scale_log2e;
+#pragma unroll
+        for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[x][nt][r] *= alpha;
+      }
+    }
+  };
+  // ---- bracket 2: S^T of the next half | exp2 and the P fragments of this one (16 register pairs over 2 NS MFMAs)
+  auto sub_tail = [&](auto next_c, float16_t (&sc)[2], float16_t (&sn)[2], const unsigned short* Kn) __attribute__((always_inline)) {
+    constexpr bool NEXT = decltype(next_c)::value;
+    {
+      constexpr int NM = 2 * NS, PPC = (16 + NM - 1) / NM;       // MFMAs, pairs per MFMA
+      uint4_t kf[NS];
+      if constexpr (NEXT) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kf[s] = *(const uint4_t*)(Kn + 16 * s);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sn[x][r] = 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if constexpr (NEXT) sn[i & 1] = mfma32<F16>(kf[i >> 1], qf[i & 1][i >> 1], sn[i & 1]);
+#pragma unroll
+        for (int p = i * PPC; p < (i + 1) * PPC && p < 16; ++p) {
+          const int x = p >> 3, r0 = 2 * (p & 7);
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[x][r0], scale_log2e, -mc[x]));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(sc[x][r0 + 1], scale_log2e, -mc[x]));
+          pf[x][r0 >> 3][(r0 & 7) >> 1] = pack2<F16>(e0, e1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // key tile t: K(t) in buffer kb, V^T(t) in vb; K(t + 1) at kb + 1, V^T(t - 1) at vb - 1 (mod 3).  The tile's ONE barrier
+  // stands between the two parts of its second sub-step: before it the stores of K(t + 2) and V^T(t + 1) (fetched at the
+  // top of the tile); the exp2 bracket closes the loop body, so it stays beside its MFMAs
+  // (with the stores behind it the compiler sinks it past them, towards the only use of the P fragments in the next tile).
+  int kb = 0, vb = 0;
+  auto tile = [&](auto last_c, auto mask_c, int t) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
+    const int kb1 = kb == 2 ? 0 : kb + 1, kb2 = kb == 0 ? 2 : kb - 1;
+    const int vb1 = vb == 2 ? 0 : vb + 1, vbp = vb == 0 ? 2 : vb - 1;
+    if (!LAST) {
+      if (t + 2 < ntiles) g_load_k(t + 2);
+      g_load_v(t + 1);
+    }
+    // half 2t: P V of half 2t - 1 (tile t - 1, upper keys; before the first tile: zeros times tile 0), S^T of half 2t + 1
+    sub_head(mask_c, 2 * t, sA, t ? Vbuf + vbp * VB + 32 : Vbuf + vb * VB);
+    sub_tail(std::true_type{}, sA, sB, Kbuf + kb * KB + (32 + lq) * KLD + 8 * lh);
+    // half 2t + 1: P V of half 2t, S^T of half 2t + 2
+    sub_head(mask_c, 2 * t + 1, sB, Vbuf + vb * VB);
+    if (!LAST) {
+      if (t + 2 < ntiles) s_store_k(kb2);
+      s_store_v(vb1);
+      __syncthreads();
+    }
+    sub_tail(std::integral_constant<bool, !LAST>{}, sB, sA, Kbuf + kb1 * KB + lq * KLD + 8 * lh);
+    if (!LAST) {
+      kb = kb1;
+      vb = vb1;
+    }
+  };
+  for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{}, std::false_type{}, t);
+  if (Lk & (KT - 1))
+    tile(std::true_type{}, std::true_type{}, ntiles - 1);
+  else
+    tile(std::true_type{}, std::false_type{}, ntiles - 1);
+  // P V of the last half
+  {
+    const unsigned short* Vp = Vbuf + vb * VB + 32;
+#pragma unroll
+    for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const unsigned short* vrow = Vp + (nt * 32 + lq) * VLD + 4 * lh + 16 * s2;
+        const uint2_t lo = *(const uint2_t*)(vrow);
+        const uint2_t hi = *(const uint2_t*)(vrow + 8);
+        const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+        for (int x = 0; x < 2; ++x) oacc[x][nt] = mfma32<F16>(vf, pf[x][s2], oacc[x][nt]);
+      }
+  }
+
+  // ---- 1 / sum (row DVP - 1 of O^T = tile NDV - 1, register 15 of the lh = 1 lanes), convert, store
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const long row = q0 + 32 * x + lq;
+    const float l1 = oacc[x][NDV - 1][15];
+    const float l0 = __shfl_xor(l1, 32);
+    const float inv = 1.0f / (lh ? l1 : l0);
+    unsigned short* orow = O + ((size_t)b * Lq + (row < Lq ? row : Lq - 1)) * C + (size_t)h * dh;
+#pragma unroll
+    for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = nt * 32 + 8 * g + 4 * lh;
+        if (dv < dh && row < Lq) {
+          const uint2_t o2 = {pack2<F16>(oacc[x][nt][4 * g] * inv, oacc[x][nt][4 * g + 1] * inv),
+                              pack2<F16>(oacc[x][nt][4 * g + 2] * inv, oacc[x][nt][4 * g + 3] * inv)};
+          *(uint2_t*)(orow + dv) = o2;
+        }
+      }
+  }
+}
+
+template <int DHP, bool VTI>
+int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
+                 float scale, int dtype, hipStream_t st, long ld) {
+  const dim3 grid((Lq + 255) / 256, H, B);
+  const float sl2 = scale * 1.4426950408889634f;
+  constexpr int NDV = (DHP + 31) / 32;
+  const size_t smem = (size_t)3 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
+  static PerDeviceOnce attr_once;
+  if (const int tok = attr_once.first()) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.commit(tok);
+  }
+  if (dtype == UCE_DTYPE_F16)
+    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+  else
+    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
+}
+
+
 template <int DHP, bool VTI>
 int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                  float scale, int dtype, hipStream_t st, long ld) {
@@ -638,6 +989,16 @@ int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int
   return UCE_OK;
 }
 
+// k_sattn_h (dh <= 48): by rule where the 256-row workgroups fill the chip twice over and there are at least 8 key tiles.
+// Measured at H = 8, dh = 40, packed q|k|v, us per launch, k_sattn QT = 2 with the V^T pre-pass | k_sattn_h inline V^T:
+//   B = 32:  L = 4096  1349 | 1168     L = 1024  107 | 106
+//   B = 128: L = 4096  5171 | 4898     L = 1024  416 | 362     L = 256  42.6 | 44.5 (stays with k_sattn)
+static bool sattn_use_h(int qt_variant, int dh, int Lq, int Lk, int H, int B) {
+  if (dh > 48) return false;
+  if (qt_variant == 4) return true;
+  return qt_variant == 0 && (long)((Lq + 255) / 256) * H * B >= 1024 && Lk >= 512;
+}
+
 // the kernel for one shape, with (VTI) or without the V^T pre-pass already run
 template <bool VTI>
 int launch_body(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh, float scale,
@@ -645,6 +1006,7 @@ int launch_body(const void* q, const void* k, const void* vt, void* o, int B, in
   // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
   //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
   //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
+  if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
   if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
   if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
     return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
@@ -676,7 +1038,7 @@ size_t sattn_vt_elems(int B, int H, int Lk, int dh) {
 // V^T by the pre-pass (k_vt: straight 16-byte tile copies in the key loop) or transposed on the way into LDS (no pre-pass, no
 // scratch): `vti` = UCE_SATTN_VTI (0: by rule - inline up to 1024 keys, where the pre-pass and its launch are a visible share
 // of a short kernel; 1: always inline; 2: always the pre-pass)
-bool sattn_inline_vt(int Lk, int vti) { return vti == 1 || (vti == 0 && Lk <= 1024); }
+bool sattn_inline_vt(int Lk, int vti, bool use_h) { return vti == 1 || (vti == 0 && (Lk <= 1024 || use_h)); }
 
 // qt_variant (UCE_SATTN_QT, read at uce_create): 0 = measured best by shape, 1 = always k_sattn with one query tile per wave,
 // 2 = two query tiles wherever dh <= 48, 3 = the pipelined kernel wherever it exists (dh <= 48, 64 < dh <= 80)
@@ -685,7 +1047,7 @@ int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o,
                  float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   if (ld <= 0) ld = (long)H * dh;
-  if (sattn_inline_vt(Lk, vti)) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld);
+  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
@@ -708,7 +1070,7 @@ extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const
                              int Lk, int dh, float scale, int dtype, uce_stream_t stream) {
   if (const int rc = sattn_check(h, q, k, v, o, B, H, Lq, Lk, dh, dtype)) return rc;
   UCE_ENTER(h);
-  if (!sattn_inline_vt(Lk, h->sw.sattn_vti)) {
+  if (!sattn_inline_vt(Lk, h->sw.sattn_vti, sattn_use_h(h->sw.sattn_qt, dh, Lq, Lk, H, B))) {
     const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, Lk, dh));
     if (rc) return rc;
   }
@@ -723,7 +1085,7 @@ extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, in
   const long C = (long)H * dh;
   if (const int rc = sattn_check(h, p, p, p, o, B, H, L, L, dh, dtype)) return rc;
   UCE_ENTER(h);
-  if (!sattn_inline_vt(L, h->sw.sattn_vti)) {
+  if (!sattn_inline_vt(L, h->sw.sattn_vti, sattn_use_h(h->sw.sattn_qt, dh, L, L, H, B))) {
     const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, L, dh));
     if (rc) return rc;
   }
