@@ -1,4 +1,6 @@
-out=$PWD/gpurun_out/r04n; mkdir -p $out; repo=$PWD
+#!/bin/bash
+# SQ counters of the self-attention forms at the generation shape (tools/probe_sattn_pmc.py): tools/pmc_sattn.sh <tag>
+out=$PWD/gpurun_out/${1:-sattn_pmc}; mkdir -p $out; repo=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > $out/sq_counters.txt; wc -l $out/sq_counters.txt
 SQ="SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"

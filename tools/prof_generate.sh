@@ -4,7 +4,7 @@ out=$PWD/gpurun_out/${1:-gen}
 mkdir -p $out
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats -d $out -o gen --output-format csv -- python $repo/tools/probe_generate3.py ${2:-20} ${3:-8} > $out/probe.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats -d $out -o gen --output-format csv -- python $repo/tools/prof_generate_loop.py ${2:-20} ${3:-8} > $out/probe.log 2>&1
 cd $repo
 tail -3 $out/probe.log
 f=$(find $out -name "*kernel_stats.csv" | head -1)

@@ -1,5 +1,5 @@
 """GPU probe for rocprofv3: kernels of the denoising loop at B prompts per U-Net call (eager launches,
-so each one is attributed).  Usage: probe_generate3.py [steps] [B]"""
+so each one is attributed).  Usage: prof_generate_loop.py [steps] [B]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

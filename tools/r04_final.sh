@@ -16,4 +16,6 @@ PY
 bash tools/prof_round.sh $tag sd14_erase50 sd14_erase2p3 sd14_erase100 sd14_erase1000p500 sdxl_debias36x2 xattn sattn > $out/prof.log 2>&1
 tail -3 $out/prof.log
 bash tools/prof_generate.sh $tag/gen 20 64 > $out/gen_prof.log 2>&1; tail -25 $out/gen_prof.log | cut -c1-150
+(cd tools/ubench && hipcc --offload-arch=gfx950 -O3 valu_mfma.hip -o /tmp/valu_mfma 2>/dev/null && timeout 60 /tmp/valu_mfma) > $out/ubench_valu_mfma.txt 2>&1; tail -3 $out/ubench_valu_mfma.txt
+bash tools/pmc_sattn.sh $tag/sattn_h_pmc > $out/sattn_h_pmc.txt 2>&1; grep k_sattn $out/sattn_h_pmc.txt | cut -c1-200
 ls $out | head -60
