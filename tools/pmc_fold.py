@@ -89,7 +89,7 @@ def by_kernel(path, wanted):
     return g
 
 
-ALIASES = {"k_xattn_g": "k_xattn", "k_sattn_p": "k_sattn"}       # forms of one kernel that serve the same call
+ALIASES = {"k_xattn_g": "k_xattn", "k_sattn_p": "k_sattn", "k_sattn_h": "k_sattn"}       # forms of one kernel that serve the same call
 
 
 def by_order(path, kernel_names, keys):
