@@ -740,8 +740,9 @@ def main() -> None:
     if os.environ.get("UCE_BENCH_SAME_DEVICE") == "1":
         local = 0
     backend = os.environ.get("UCE_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    dev_index = local if local < torch.cuda.device_count() else 0     # a launcher that masks one GPU per rank shows it as cuda:0
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -758,9 +759,10 @@ def main() -> None:
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
         if backend == "nccl" and os.environ.get("UCE_BENCH_SAME_DEVICE") != "1":
+            # (host, device index) - not the device UUID: a runtime that reports one UUID for every GPU of a node must not
+            # turn a correct 8-GPU launch into a refusal; RCCL itself rejects two ranks on one device
             ids = [None] * world
-            dist.all_gather_object(ids, (socket.gethostname(), torch.cuda.get_device_properties(device).uuid.__str__()
-                                         if hasattr(torch.cuda.get_device_properties(device), "uuid") else local))
+            dist.all_gather_object(ids, (socket.gethostname(), int(local)))
             if len(set(ids)) != world:
                 raise SystemExit(f"{world} ranks share {len(set(ids))} GPUs: refusing to report an N-GPU line")
 
