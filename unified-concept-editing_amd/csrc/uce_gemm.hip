@@ -177,9 +177,12 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
   __builtin_amdgcn_s_barrier();
   int slot = 0, fill = AHEAD;                                          // ring positions of tile kt and of tile kt + AHEAD
   for (int kt = 0; kt < NK; ++kt) {
+#if !defined(UCE_GEMM_ABLATE) || (UCE_GEMM_ABLATE != 3 && UCE_GEMM_ABLATE != 5)
     stage(fill, kt + AHEAD < last ? kt + AHEAD : last);
+#endif
     const unsigned char* Ab = smem + slot * STAGE;
     const unsigned char* Bb = Ab + BM * BK * 2;
+#if !defined(UCE_GEMM_ABLATE) || UCE_GEMM_ABLATE != 2
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int c = 2 * s + lh;
@@ -188,13 +191,24 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
       for (int b = 0; b < TM; ++b) pf[b] = *(const uint4_t*)(Ab + arow[b] * (2 * BK) + ((c ^ swz(arow[b])) << 4));
 #pragma unroll
       for (int a = 0; a < TN; ++a) cf[a] = *(const uint4_t*)(Bb + brow[a] * (2 * BK) + ((c ^ swz(brow[a])) << 4));
+#if defined(UCE_GEMM_ABLATE) && UCE_GEMM_ABLATE == 1
+      // (measurement build: the fragment reads without the MFMAs)
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b][0] += __builtin_bit_cast(float, cf[a][0] ^ pf[b][1]);
+#else
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = gd_mfma<F16>(cf[a], pf[b], acc[a][b]);   // rows = columns of Y, columns = rows of Y
+#endif
     }
+#endif
+#if !defined(UCE_GEMM_ABLATE) || UCE_GEMM_ABLATE < 4
     gd_wait_dma((AHEAD - 1) * per);                                    // this wave's part of tile kt + 1 has landed
     __builtin_amdgcn_s_barrier();
+#endif
     slot = slot + 1 == NST ? 0 : slot + 1;
     fill = fill + 1 == NST ? 0 : fill + 1;
   }
