@@ -85,21 +85,48 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
       for (int i = 0; i < 8; ++i) ad[j][i] = 0.f;
       if (addend && j < mp.NO && oc < mp.OC) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * ald + oc * 8), ad[j]);
     }
-    for (int p = p0 + prow; p < p1; p += mp.RPI) {
+    auto take = [&](const uint4_t (&v)[MAXO]) {
 #pragma unroll
       for (int j = 0; j < MAXO; ++j) {
         const int oc = oc0 + j * tpr;
         if (j < mp.NO && oc < mp.OC) {
           float f[8];
-          unpack8<F16>(*(const uint4_t*)(base + (size_t)p * C + oc * 8), f);
+          unpack8<F16>(v[j], f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float v = f[i] + ad[j][i];
-            s[j][i] += v;
-            q[j][i] = fmaf(v, v, q[j][i]);
+            const float w = f[i] + ad[j][i];
+            s[j][i] += w;
+            q[j][i] = fmaf(w, w, q[j][i]);
           }
         }
       }
+    };
+    auto fetch = [&](int p, uint4_t (&v)[MAXO]) {
+#pragma unroll
+      for (int j = 0; j < MAXO; ++j) {
+        const int oc = oc0 + j * tpr;
+        v[j] = (uint4_t){0u, 0u, 0u, 0u};
+        if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(base + (size_t)p * C + oc * 8);
+      }
+    };
+    // four pixel rows in flight per thread (with few samples a workgroup's chunk is a handful of dependent round trips:
+    // one prompt per call spent 12 us per launch on 5 MB); the accumulation order is the pixel order either way
+    int p = p0 + prow;
+    for (; p + 3 * mp.RPI < p1; p += 4 * mp.RPI) {
+      uint4_t v0[MAXO], v1[MAXO], v2[MAXO], v3[MAXO];
+      fetch(p, v0);
+      fetch(p + mp.RPI, v1);
+      fetch(p + 2 * mp.RPI, v2);
+      fetch(p + 3 * mp.RPI, v3);
+      take(v0);
+      take(v1);
+      take(v2);
+      take(v3);
+    }
+    for (; p < p1; p += mp.RPI) {
+      uint4_t v0[MAXO];
+      fetch(p, v0);
+      take(v0);
     }
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
@@ -136,17 +163,35 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
                                                   unsigned short* __restrict__ y, int HW, int C, int G, int chunks,
                                                   float eps, int silu, long ald) {
   __shared__ float mean_s[64], rstd_s[64];
+  __shared__ double fold_s[2][8][64];
   const GnMap mp = gn_map(C);
   const int tpr = mp.active / mp.RPI;
   const int tid = threadIdx.x;
   const int n = blockIdx.y, ch = blockIdx.x;
   const int cpg = C / G;
+  // the partials of this sample, folded by all 256 threads: thread (sub, g) sums chunks sub, sub + nsub, ... of group g,
+  // then one thread per group adds the nsub sums - a fixed order (bit-repeatable), 8 dependent steps instead of 64
+  const int nsub = G <= 32 ? 8 : 4;
+  {
+    const int g = tid % (256 / nsub), sub = tid / (256 / nsub);
+    double a = 0.0, b = 0.0;
+    if (g < G)
+      for (int c = sub; c < chunks; c += nsub) {
+        const float* p = partial + (((size_t)n * chunks + c) * G + g) * 2;
+        a += (double)p[0];
+        b += (double)p[1];
+      }
+    if (g < 64) {
+      fold_s[0][sub][g] = a;
+      fold_s[1][sub][g] = b;
+    }
+  }
+  __syncthreads();
   if (tid < G) {
     double a = 0.0, b = 0.0;
-    for (int c = 0; c < chunks; ++c) {                 // fixed order
-      const float* p = partial + (((size_t)n * chunks + c) * G + tid) * 2;
-      a += (double)p[0];
-      b += (double)p[1];
+    for (int sub = 0; sub < nsub; ++sub) {
+      a += fold_s[0][sub][tid];
+      b += fold_s[1][sub][tid];
     }
     const double cnt = (double)HW * cpg;
     const double mu = a / cnt;
@@ -181,23 +226,48 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
   }
   const unsigned short* xb = x + (size_t)n * HW * C;
   unsigned short* yb = y + (size_t)n * HW * C;
-  for (int p = p0 + prow; p < p1; p += mp.RPI) {
+  auto fetch = [&](int p, uint4_t (&v)[MAXO]) {
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) {
+      const int oc = oc0 + j * tpr;
+      v[j] = (uint4_t){0u, 0u, 0u, 0u};
+      if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(xb + (size_t)p * C + oc * 8);
+    }
+  };
+  auto put = [&](int p, const uint4_t (&v)[MAXO]) {
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
       const int oc = oc0 + j * tpr;
       if (j < mp.NO && oc < mp.OC) {
         float f[8];
-        unpack8<F16>(*(const uint4_t*)(xb + (size_t)p * C + oc * 8), f);
+        unpack8<F16>(v[j], f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          float v = fmaf(f[i], sa[j][i], sb[j][i]);
-          if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-          f[i] = v;
+          float w = fmaf(f[i], sa[j][i], sb[j][i]);
+          if (silu) w = w * __builtin_amdgcn_rcpf(1.0f + __expf(-w));
+          f[i] = w;
         }
         const uint4_t o = {pack2<F16>(f[0], f[1]), pack2<F16>(f[2], f[3]), pack2<F16>(f[4], f[5]), pack2<F16>(f[6], f[7])};
         *(uint4_t*)(yb + (size_t)p * C + oc * 8) = o;
       }
     }
+  };
+  int p = p0 + prow;
+  for (; p + 3 * mp.RPI < p1; p += 4 * mp.RPI) {         // four pixel rows in flight per thread (see k_gn_stats)
+    uint4_t v0[MAXO], v1[MAXO], v2[MAXO], v3[MAXO];
+    fetch(p, v0);
+    fetch(p + mp.RPI, v1);
+    fetch(p + 2 * mp.RPI, v2);
+    fetch(p + 3 * mp.RPI, v3);
+    put(p, v0);
+    put(p + mp.RPI, v1);
+    put(p + 2 * mp.RPI, v2);
+    put(p + 3 * mp.RPI, v3);
+  }
+  for (; p < p1; p += mp.RPI) {
+    uint4_t v0[MAXO];
+    fetch(p, v0);
+    put(p, v0);
   }
 }
 
