@@ -345,7 +345,10 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   // Short contractions (K <= 320: ten k-tiles per output tile, the 64 x 64 level of the U-Net): prologue and epilogue are as
   // long as the main loop, so the shallow-ring forms that put TWO workgroups on a CU win (tools/probe_r04.py, M = 131072:
   // N = 320: 47 us against 55; GEGLU N = 2560: 336 against 381); longer contractions keep the deep ring
-  if (K <= 320 && M >= 65536 && N <= 320) { nst = 2; bm = 128; bn = 320; }
+  // (at four times those rows - 64 prompts per call - the 128-byte k-tiles are ahead again: M = 524288, N = 320: 210 us against
+  // 239; N = 2560: 256 x 256 tiles 1544 against 1594 for the three-stage 128 x 256 form and 1624 for 256 x 320)
+  if (K <= 320 && M >= 65536 && M < 196608 && N <= 320) { nst = 2; bm = 128; bn = 320; }
+  else if (K <= 320 && K % 64 == 0 && M >= 65536 && N >= 2560 && N % 256 == 0) { nst = 64; bm = 256; bn = 256; }
   else if (K <= 320 && M >= 65536 && N >= 2560 && N % 256 == 0) { nst = 3; bm = 128; bn = 256; }
   else if (K % 64 == 0 && bn != 128) nst = 64;         // 128-byte k-tiles, two stages: 5-10 % ahead of the 64-byte ring wherever K allows
   if (force_tile > 0) { nst = force_tile >= 1000000 ? force_tile / 1000000 : 4; bm = (force_tile / 1000) % 1000; bn = force_tile % 1000; }
