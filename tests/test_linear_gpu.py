@@ -298,3 +298,131 @@ def test_vae_attention_on_the_linear_kernel_matches_its_torch_twin(H):
     y = H.linear_f32(x.permute(0, 2, 3, 1).reshape(-1, 512)[:700], att.to_q.weight.to(torch.bfloat16))
     assert y.dtype == torch.float32
     assert O.rel_fro(y.double().cpu(), (x.permute(0, 2, 3, 1).reshape(-1, 512)[:700].double() @ att.to_q.weight.double().T).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("wide", ["1", "0"])
+@pytest.mark.parametrize("M,N,K,ncs,dtype,bias,res", [
+    (4096, 960, 320, 320, torch.bfloat16, False, False),     # the packed q | k | v projection of a 64 x 64 attn1 layer: q scaled
+    (1000, 1920, 640, 640, torch.bfloat16, True, True),      # bias and residual: (x w^T + b) * c + r on the scaled columns
+    (333, 768, 256, 36, torch.float16, True, False),         # a boundary inside a 4-column group's tile, ragged M
+    (515, 128, 64, 128, torch.bfloat16, False, False),       # every column scaled
+])
+def test_linear_column_scale(wide, M, N, K, ncs, dtype, bias, res):
+    """uce_linear_colscale_fwd: the first n_scaled columns leave as (x w^T + bias) * col_scale, the factor on the f32
+    accumulators (one rounding) - whole-row and per-lane epilogue."""
+    Hv = _handle_with("UCE_WIDE_EPILOGUE", wide)
+    try:
+        g = torch.Generator().manual_seed(M + N + ncs)
+        x = _rand((M, K), g, dtype)
+        w = _rand((N, K), g, dtype, K ** -0.5)
+        b = _rand((N,), g, dtype) if bias else None
+        r = _rand((M, N), g, dtype) if res else None
+        c = 40 ** -0.5 * 1.4426950408889634
+        y = Hv.linear(x, w, b, r, col_scale=c, n_scaled=ncs)
+        want = x.double() @ w.double().T
+        if bias:
+            want = want + b.double()
+        want[:, :ncs] *= float(torch.tensor(c, dtype=torch.float32))
+        if res:
+            want = want + r.double()
+        assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[dtype]
+        assert O.rel_fro(y[:, :ncs].double().cpu(), want[:, :ncs].cpu()) < TOL[dtype]
+        # the unscaled columns are the plain layer's, bit for bit
+        assert torch.equal(y[:, ncs:], Hv.linear(x, w, b, r)[:, ncs:])
+        from uce_amd import lib as L
+        with pytest.raises(L.UceError):
+            Hv.linear(x, w, b, r, col_scale=c, n_scaled=ncs + 2)          # not a multiple of 4
+        with pytest.raises(L.UceError):
+            Hv.linear(x, w, b, r, col_scale=c, n_scaled=N + 4)
+    finally:
+        torch.cuda.synchronize()
+        Hv.close()
+
+
+def test_attn1_prescaled_path_matches_the_plain_one():
+    """sd.unet.Attention at dh = 40 with UCE_SATTN_PRESCALE: the scaled projection + uce_sattn_packed_prescaled_fwd against the
+    plain packed path on the same layer (both within one output rounding of fp64; they differ by the roundings of q only)."""
+    from uce_amd.sd import unet as U
+    torch.manual_seed(3)
+    att = U.Attention(320, 8, 40).to("cuda:0", torch.bfloat16)
+    x = (torch.randn(4, 4096, 320) * 1.5).to(torch.bfloat16).cuda()
+    old = U.SATTN_PRESCALE
+    try:
+        U.SATTN_PRESCALE = False
+        a = att(x)
+        U.SATTN_PRESCALE = True
+        b = att(x)
+    finally:
+        U.SATTN_PRESCALE = old
+    q, k, v = (F.linear(x.double(), w.double()) for w in (att.to_q.weight, att.to_k.weight, att.to_v.weight))
+    B, L, C = q.shape
+    sp = lambda t: t.view(B, L, 8, 40).transpose(1, 2)
+    o = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * 40 ** -0.5, dim=-1) @ sp(v)
+    want = F.linear(o.transpose(1, 2).reshape(B, L, C), att.to_out[0].weight.double(), att.to_out[0].bias.double())
+    ea, eb = O.rel_fro(a.double().cpu(), want.cpu()), O.rel_fro(b.double().cpu(), want.cpu())
+    print(dict(plain=ea, prescaled=eb))
+    assert ea < 1.5e-2 and eb < 1.5e-2 and eb < 1.5 * ea + 1e-3
+
+
+@pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "64256320", "64128320", "2128320", "3128256"])
+@pytest.mark.parametrize("M,N,K1,K2,bias,res", [
+    (4096, 320, 320, 320, True, False),        # up_blocks.3: x | skip at 64 x 64
+    (1100, 640, 1280, 640, True, True),        # ragged rows, residual
+    (700, 1280, 1280, 1280, False, False),
+    (300, 320, 64, 32, True, False),           # one k-tile from each source (64-wide tiles cannot split at 64 | 32: EINVAL -> skipped)
+])
+def test_linear_over_a_two_source_contraction(tile, M, N, K1, K2, bias, res):
+    """uce_linear_cat_fwd(x, x2) == uce_linear_fwd(torch.cat([x, x2], dim=-1)) bit for bit, in every tile form, the two
+    sources with different row strides."""
+    if int(tile) >= 64000000 and ((K1 + K2) % 64 or K1 % 64):
+        pytest.skip("128-byte k-tiles need K and K1 to be multiples of 64")
+    Hv = _handle_with("UCE_GEMM_TILE", tile)
+    try:
+        g = torch.Generator().manual_seed(M + K1 + K2)
+        dtype = torch.bfloat16
+        x, x2 = _rand((M, K1), g, dtype), _rand((M, K2), g, dtype)
+        w = _rand((N, K1 + K2), g, dtype, (K1 + K2) ** -0.5)
+        b = _rand((N,), g, dtype) if bias else None
+        r = _rand((M, N), g, dtype) if res else None
+        got = Hv.linear(x, w, b, r, x2=x2)
+        want = Hv.linear(torch.cat([x, x2], dim=-1), w, b, r)
+        assert torch.equal(got, want)
+        ref = torch.cat([x, x2], dim=-1).double() @ w.double().T
+        if bias:
+            ref = ref + b.double()
+        if res:
+            ref = ref + r.double()
+        assert O.rel_fro(got.double().cpu(), ref.cpu()) < TOL[dtype]
+        # column slices of wider tensors as the two sources (row strides larger than the widths)
+        wide1, wide2 = _rand((M, K1 + 64), g, dtype), _rand((M, K2 + 32), g, dtype)
+        got = Hv.linear(wide1[:, :K1], w, b, r, x2=wide2[:, 32:])
+        assert torch.equal(got, Hv.linear(torch.cat([wide1[:, :K1], wide2[:, 32:]], dim=-1), w, b, r))
+    finally:
+        torch.cuda.synchronize()
+        Hv.close()
+
+
+def test_up_block_reads_the_skip_connection_in_place():
+    """sd.unet.UpBlock with UCE_CAT_FREE: two-source GroupNorm + two-source shortcut GEMM against the torch.cat path of the
+    same block - the same arithmetic in the same order, so bit for bit - and no torch.cat on the way."""
+    from uce_amd.sd import unet as U
+    torch.manual_seed(5)
+    blk = U.ResnetBlock2D(640 + 320, 320, 1280, 32).to("cuda:0", torch.bfloat16).to(memory_format=torch.channels_last)
+    cl = lambda t: t.to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    x, skip = cl(torch.randn(8, 640, 64, 64)), cl(torch.randn(8, 320, 64, 64))
+    temb = torch.randn(8, 1280).to(torch.bfloat16).cuda()
+    old = U.CAT_FREE
+    cats = []
+    real_cat = torch.cat
+    try:
+        U.CAT_FREE = False
+        want = blk(x, temb, skip=skip)
+        U.CAT_FREE = True
+        assert blk.cat_free_ok(x, skip)
+        torch.cat = lambda *a, **k: (cats.append(1), real_cat(*a, **k))[1]
+        got = blk(x, temb, skip=skip)
+    finally:
+        torch.cat = real_cat
+        U.CAT_FREE = old
+    assert not cats
+    assert torch.equal(got, want)

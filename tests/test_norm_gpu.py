@@ -383,3 +383,32 @@ def test_conv_in_on_four_channels(H, N, Cout, Hh, Ww, dtype):
     ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
     assert y.shape == ref.shape
     assert O.rel_fro(y.double().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("N,C1,C2,Hh,Ww,G,dtype,addend", [
+    (2, 1280, 1280, 8, 8, 32, torch.bfloat16, False),      # the up blocks' concatenations of SD-1.4 (x | skip)
+    (2, 1280, 640, 16, 16, 32, torch.bfloat16, False),
+    (2, 640, 320, 32, 32, 32, torch.bfloat16, True),
+    (3, 320, 320, 64, 64, 32, torch.bfloat16, False),
+    (2, 64, 8, 5, 7, 8, torch.float16, True),              # one octet from the second tensor, ragged pixel count
+    (1, 2048, 2048, 4, 4, 32, torch.bfloat16, False),      # two octets per thread, the split between them
+])
+def test_groupnorm_of_a_concatenation_that_is_never_written(H, N, C1, C2, Hh, Ww, G, dtype, addend):
+    """uce_groupnorm_cat_nhwc_fwd(x, x2) == uce_groupnorm_nhwc_fwd(torch.cat([x, x2], dim=1)), bit for bit (same thread <->
+    channel map, same summation order), and the argument checks of the two-source form."""
+    g = torch.Generator().manual_seed(C1 + C2 + Hh)
+    cl = lambda t: t.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    x, x2 = cl(torch.randn(N, C1, Hh, Ww, generator=g) * 1.5 + 0.3), cl(torch.randn(N, C2, Hh, Ww, generator=g) - 0.2)
+    C = C1 + C2
+    w = (torch.rand(C, generator=g) + 0.5).to(dtype).cuda()
+    b = (torch.randn(C, generator=g) * 0.2).to(dtype).cuda()
+    ad = (torch.randn(N, C, generator=g) * 0.5).to(dtype).cuda() if addend else None
+    got = H.groupnorm_nhwc(x, w, b, G, 1e-5, True, ad, x2=x2)
+    want = H.groupnorm_nhwc(torch.cat([x, x2], dim=1).contiguous(memory_format=torch.channels_last), w, b, G, 1e-5, True, ad)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    from uce_amd import lib as L
+    if C1 > 8:
+        with pytest.raises(L.UceError):                    # C1 = 4 is not a whole octet
+            H.groupnorm_nhwc(x[:, :4].contiguous(memory_format=torch.channels_last), w[:C2 + 4].contiguous(), b[:C2 + 4].contiguous(),
+                             1, 1e-5, True, None, x2=x2)

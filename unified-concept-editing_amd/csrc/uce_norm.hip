@@ -60,8 +60,11 @@ __host__ __device__ inline GnMap gn_map(int C) {
 
 // `addend` (optional, [N, C], same dtype): x + addend[n][c] is what gets normalised (the ResnetBlock2D's
 // "h + time_emb_proj(...)[:, :, None, None]" and the bias of the convolution that produced x, folded in).
+// `x2` (optional): the channels [C1, C) of every pixel come from a second tensor x2 [N, HW, C - C1] - the skip connection of an
+// up block, whose torch.cat([x, skip], dim=1) is then never written (C1 % 8 == 0; x2 == nullptr: C1 == C).
 template <bool F16>
-__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
+__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int C1,
+                                                  const unsigned short* __restrict__ addend,
                                                   float* __restrict__ partial, int HW, int C, int G, int chunks, long ald) {
   extern __shared__ __attribute__((aligned(16))) float red[];     // [RPI][C][2]
   const GnMap mp = gn_map(C);
@@ -76,11 +79,15 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[j][i] = q[j][i] = 0.f;
   if (tid < mp.active) {
-    const unsigned short* base = x + (size_t)n * HW * C;
+    const unsigned short* src[MAXO];                   // this thread's octet j of pixel 0 of sample n, and its pixel stride
+    int pst[MAXO];
     float ad[MAXO][8];
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
       const int oc = oc0 + j * tpr;
+      const bool second = oc * 8 >= C1;
+      pst[j] = second ? C - C1 : C1;
+      src[j] = second ? x2 + (size_t)n * HW * (C - C1) + (oc * 8 - C1) : x + (size_t)n * HW * C1 + oc * 8;
 #pragma unroll
       for (int i = 0; i < 8; ++i) ad[j][i] = 0.f;
       if (addend && j < mp.NO && oc < mp.OC) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * ald + oc * 8), ad[j]);
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
       for (int j = 0; j < MAXO; ++j) {
         const int oc = oc0 + j * tpr;
         v[j] = (uint4_t){0u, 0u, 0u, 0u};
-        if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(base + (size_t)p * C + oc * 8);
+        if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(src[j] + (size_t)p * pst[j]);
       }
     };
     // four pixel rows in flight per thread (with few samples a workgroup's chunk is a handful of dependent round trips:
@@ -157,7 +164,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
 }
 
 template <bool F16>
-__global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
+__global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int C1,
+                                                  const unsigned short* __restrict__ addend,
                                                   const unsigned short* __restrict__ gamma,
                                                   const unsigned short* __restrict__ beta, const float* __restrict__ partial,
                                                   unsigned short* __restrict__ y, int HW, int C, int G, int chunks,
@@ -205,9 +213,14 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
   const int p0 = (int)((long)HW * ch / chunks), p1 = (int)((long)HW * (ch + 1) / chunks);
   const int oc0 = tid % tpr, prow = tid / tpr;
   float sa[MAXO][8], sb[MAXO][8];
+  const unsigned short* src[MAXO];
+  int pst[MAXO];
 #pragma unroll
   for (int j = 0; j < MAXO; ++j) {
     const int oc = oc0 + j * tpr;
+    const bool second = oc * 8 >= C1;
+    pst[j] = second ? C - C1 : C1;
+    src[j] = second ? x2 + (size_t)n * HW * (C - C1) + (oc * 8 - C1) : x + (size_t)n * HW * C1 + oc * 8;
     if (j < mp.NO && oc < mp.OC) {
       float g8[8], b8[8];
       unpack8<F16>(*(const uint4_t*)(gamma + oc * 8), g8);
@@ -224,14 +237,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
       }
     }
   }
-  const unsigned short* xb = x + (size_t)n * HW * C;
   unsigned short* yb = y + (size_t)n * HW * C;
   auto fetch = [&](int p, uint4_t (&v)[MAXO]) {
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
       const int oc = oc0 + j * tpr;
       v[j] = (uint4_t){0u, 0u, 0u, 0u};
-      if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(xb + (size_t)p * C + oc * 8);
+      if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(src[j] + (size_t)p * pst[j]);
     }
   };
   auto put = [&](int p, const uint4_t (&v)[MAXO]) {
@@ -279,14 +291,15 @@ extern "C" int uce_groupnorm_chunks(int HW) {
 }
 
 // ws: N * uce_groupnorm_chunks(HW) * G * 2 floats, owned by the caller
-extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, const void* gamma, const void* beta,
-                                      void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
-                                      long addend_ld, uce_stream_t stream) {
+static int groupnorm_launch(uce_handle_t h, const void* x, const void* x2, int C1, const void* addend, const void* gamma,
+                            const void* beta, void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
+                            long addend_ld, uce_stream_t stream) {
   if (!h || !x || !gamma || !beta || !y || !ws || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64) return UCE_EINVAL;
   const long ald = addend_ld > 0 ? addend_ld : C;
   if (addend && (ald < C || ald % 8)) return UCE_EINVAL;
   UCE_ENTER(h);
   if (C % 8 || C % G || C > 8 * 256 * MAXO || N > 65535) return UCE_EINVAL;
+  if (x2 ? (C1 <= 0 || C1 >= C || C1 % 8) : C1 != C) return UCE_EINVAL;
   if (dtype != UCE_DTYPE_BF16 && dtype != UCE_DTYPE_F16) return UCE_ENOSYS;
   const int chunks = uce_groupnorm_chunks(HW);
   const GnMap mp = gn_map(C);
@@ -295,20 +308,33 @@ extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void*
   const dim3 grid(chunks, N), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == UCE_DTYPE_F16) {
-    hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)addend, ws, HW,
-                       C, G, chunks, ald);
-    hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)addend,
-                       (const unsigned short*)gamma,
+    hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
+                       (const unsigned short*)addend, ws, HW, C, G, chunks, ald);
+    hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
+                       (const unsigned short*)addend, (const unsigned short*)gamma,
                        (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu, ald);
   } else {
-    hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)addend, ws, HW,
-                       C, G, chunks, ald);
-    hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)addend,
-                       (const unsigned short*)gamma,
+    hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
+                       (const unsigned short*)addend, ws, HW, C, G, chunks, ald);
+    hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
+                       (const unsigned short*)addend, (const unsigned short*)gamma,
                        (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu, ald);
   }
   UCE_LAUNCH_CHECK();
   return UCE_OK;
+}
+
+extern "C" int uce_groupnorm_nhwc_fwd(uce_handle_t h, const void* x, const void* addend, const void* gamma, const void* beta,
+                                      void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
+                                      long addend_ld, uce_stream_t stream) {
+  return groupnorm_launch(h, x, nullptr, C, addend, gamma, beta, y, ws, N, HW, C, G, eps, silu, dtype, addend_ld, stream);
+}
+
+extern "C" int uce_groupnorm_cat_nhwc_fwd(uce_handle_t h, const void* x, const void* x2, int C1, const void* addend,
+                                          const void* gamma, const void* beta, void* y, float* ws, int N, int HW, int C, int G,
+                                          float eps, int silu, int dtype, long addend_ld, uce_stream_t stream) {
+  if (!x2) return UCE_EINVAL;
+  return groupnorm_launch(h, x, x2, C1, addend, gamma, beta, y, ws, N, HW, C, G, eps, silu, dtype, addend_ld, stream);
 }
 
 // -------------------------------------------------------------------------------------------------------------

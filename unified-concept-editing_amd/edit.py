@@ -243,25 +243,34 @@ class UceHandle:
                                           float(scale), dt, _stream_ptr(self.device)), "uce_sattn_fwd")
         return out
 
-    def sattn_packed(self, qkv: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
-        """Self-attention on a packed projection qkv [B, L, 3 * C] (q | k | v columns) through uce_sattn_packed_fwd -> [B, L, C]."""
+    def sattn_packed(self, qkv: torch.Tensor, heads: int, scale: Optional[float] = None, prescaled: bool = False) -> torch.Tensor:
+        """Self-attention on a packed projection qkv [B, L, 3 * C] (q | k | v columns) through uce_sattn_packed_fwd -> [B, L, C].
+        `prescaled`: the q columns already hold to_q(x) * scale * log2(e) (`linear(..., col_scale=, n_scaled=)`):
+        uce_sattn_packed_prescaled_fwd."""
         B, Lq, C3 = qkv.shape
         Cc = C3 // 3
         dh = Cc // heads
-        scale = dh ** -0.5 if scale is None else scale
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[qkv.dtype]
         out = torch.empty(B, Lq, Cc, dtype=qkv.dtype, device=qkv.device)
+        if prescaled:
+            _lib.check(self.lib.uce_sattn_packed_prescaled_fwd(self._h, _ptr(qkv), _ptr(out), B, heads, Lq, dh, dt,
+                                                               _stream_ptr(self.device)), "uce_sattn_packed_prescaled_fwd")
+            return out
+        scale = dh ** -0.5 if scale is None else scale
         _lib.check(self.lib.uce_sattn_packed_fwd(self._h, _ptr(qkv), _ptr(out), B, heads, Lq, dh, float(scale), dt,
                                                  _stream_ptr(self.device)), "uce_sattn_packed_fwd")
         return out
 
     def groupnorm_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float,
-                       silu: bool, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       silu: bool, addend: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """GroupNorm (+ SiLU) of a channels-last [N, C, H, W] tensor through uce_groupnorm_nhwc_fwd; `addend` [N, C]
-        (optional) is added per (sample, channel) before the normalisation."""
-        N, Cc, Hh, Ww = x.shape
+        (optional) is added per (sample, channel) before the normalisation.  `x2` (channels-last, same N, H, W): the norm of
+        torch.cat([x, x2], dim=1) without the concatenation (uce_groupnorm_cat_nhwc_fwd)."""
+        N, C1, Hh, Ww = x.shape
+        Cc = C1 + (0 if x2 is None else x2.shape[1])
         hw = Hh * Ww
-        y = torch.empty_like(x)                                    # keeps the channels_last strides
+        y = torch.empty_like(x) if x2 is None else \
+            torch.empty((N, Cc, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ws = torch.empty(N * self.lib.uce_groupnorm_chunks(hw) * groups * 2, dtype=torch.float32, device=x.device)
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
         ald = 0
@@ -269,6 +278,11 @@ class UceHandle:
             if addend.dim() != 2 or addend.stride(1) != 1 or addend.stride(0) % 8 or addend.data_ptr() % 16:
                 addend = addend.contiguous()
             ald = addend.stride(0)
+        if x2 is not None:
+            _lib.check(self.lib.uce_groupnorm_cat_nhwc_fwd(self._h, _ptr(x), _ptr(x2), C1, _ptr(addend), _ptr(weight), _ptr(bias),
+                                                           _ptr(y), _ptr(ws), N, hw, Cc, groups, float(eps), int(silu), dt, ald,
+                                                           _stream_ptr(self.device)), "uce_groupnorm_cat_nhwc_fwd")
+            return y
         _lib.check(self.lib.uce_groupnorm_nhwc_fwd(self._h, _ptr(x), _ptr(addend), _ptr(weight), _ptr(bias), _ptr(y),
                                                    _ptr(ws), N, hw, Cc, groups, float(eps), int(silu), dt, ald,
                                                    _stream_ptr(self.device)), "uce_groupnorm_nhwc_fwd")
@@ -384,11 +398,30 @@ class UceHandle:
         return eps_out, prev
 
     def linear(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               residual: Optional[torch.Tensor] = None, geglu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, geglu: bool = False, out: Optional[torch.Tensor] = None,
+               col_scale: float = 1.0, n_scaled: int = 0, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`x @ weight.T (+ bias) (+ residual)` over the last dim of x through uce_linear_fwd (16-bit, f32 accumulate); with
         `geglu`, weight / bias are the interleaved rows of a GEGLU projection (sd.unet.geglu_interleave) and the result is
         `hidden * gelu(gate)` with half as many columns.  x / residual / out may be row-strided 2-D views (last dim
-        contiguous): slices of wider tensors are read and written in place."""
+        contiguous): slices of wider tensors are read and written in place.  `n_scaled` > 0: the first n_scaled output
+        columns times `col_scale` on the f32 accumulators (uce_linear_colscale_fwd).  `x2` [..., K2]: the layer applied to
+        torch.cat([x, x2], dim=-1) without the concatenation (uce_linear_cat_fwd; weight [N, K + K2])."""
+        if x2 is not None:
+            K1, K2 = x.shape[-1], x2.shape[-1]
+            N = weight.shape[0]
+            dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+            xa, xb = x.reshape(-1, K1), x2.reshape(-1, K2)
+            xa = xa if xa.stride(1) == 1 else xa.contiguous()
+            xb = xb if xb.stride(1) == 1 else xb.contiguous()
+            M = xa.shape[0]
+            y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+            r2 = None if residual is None else residual.reshape(-1, N)
+            ldr = 0 if r2 is None else r2.stride(0)
+            w = weight if weight.is_contiguous() else weight.contiguous()
+            _lib.check(self.lib.uce_linear_cat_fwd(self._h, _ptr(xa), xa.stride(0), _ptr(xb), xb.stride(0), K1, _ptr(w), _ptr(bias),
+                                                   _ptr(r2), ldr, _ptr(y), N, M, N, K1 + K2, _lib.EPILOGUE_NONE, dt,
+                                                   _stream_ptr(self.device)), "uce_linear_cat_fwd")
+            return y
         K = x.shape[-1]
         N = weight.shape[0]
         n_out = N // 2 if geglu else N
@@ -410,6 +443,11 @@ class UceHandle:
             y, ldy = out, (out.stride(0) if out.dim() == 2 else n_out)
         r2, ldr = (None, 0) if residual is None else rows2d(residual, N)
         w = weight if weight.is_contiguous() else weight.contiguous()
+        if n_scaled:
+            _lib.check(self.lib.uce_linear_colscale_fwd(self._h, _ptr(x2), ldx, _ptr(w), _ptr(bias), _ptr(r2), ldr, _ptr(y), ldy, M, N,
+                                                        K, _lib.EPILOGUE_GEGLU if geglu else _lib.EPILOGUE_NONE, dt, float(col_scale),
+                                                        int(n_scaled), _stream_ptr(self.device)), "uce_linear_colscale_fwd")
+            return y
         _lib.check(self.lib.uce_linear_fwd(self._h, _ptr(x2), ldx, _ptr(w), _ptr(bias), _ptr(r2), ldr, _ptr(y), ldy, M, N, K,
                                            _lib.EPILOGUE_GEGLU if geglu else _lib.EPILOGUE_NONE, dt, _stream_ptr(self.device)),
                    "uce_linear_fwd")

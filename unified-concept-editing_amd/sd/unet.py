@@ -115,14 +115,17 @@ def _hip_nhwc_ok(x: torch.Tensor) -> bool:
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+def group_norm_act(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, addend: Optional[torch.Tensor] = None,
+                   x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`silu(norm(x + addend[:, :, None, None]))` (silu / addend optional).  On a GPU, for bf16/f16 activations in
     channels_last memory format, one fused HIP launch pair (uce_groupnorm_nhwc_fwd) instead of torch's broadcast add,
-    GroupNorm kernels and SiLU pass."""
+    GroupNorm kernels and SiLU pass.  `x2`: the norm of torch.cat([x, x2], dim=1) (the caller has checked `cat_free_ok`)."""
     if _hip_nhwc_ok(x) and norm.num_groups <= 64 and norm.weight is not None and norm.weight.dtype == x.dtype:
         from .. import edit as _edit
         ad = None if addend is None else addend.to(x.dtype)          # (a strided column slice is read in place)
-        return _edit.UceHandle.get(x.device).groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, ad)
+        return _edit.UceHandle.get(x.device).groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, ad, x2=x2)
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=1)
     if addend is not None:
         x = x + addend[:, :, None, None].to(x.dtype)
     y = norm(x)
@@ -256,6 +259,9 @@ def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------ linear layers
 
 LINEAR_MIN_TILES = int(os.environ.get("UCE_LINEAR_MIN_TILES", "256"))     # (A/B runs only)
+CAT_FREE = os.environ.get("UCE_CAT_FREE", "0") != "0"       # up blocks: x and the skip connection read in place, no torch.cat
+SATTN_PRESCALE = os.environ.get("UCE_SATTN_PRESCALE", "0") != "0"          # dh = 40 attn1 layers: q leaves its projection scaled
+LOG2E = 1.4426950408889634
 
 
 def _hip_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
@@ -358,16 +364,42 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
         self.temb_addend: Optional[torch.Tensor] = None      # this block's slice of the U-Net's hoisted time projections
 
-    def forward(self, x, temb):
+    def cat_free_ok(self, x: torch.Tensor, skip: torch.Tensor) -> bool:
+        """The block can read x and the skip connection in place (two-source GroupNorm, two-source shortcut GEMM): own kernels on
+        both consumers, channel counts the k-tiles and octets divide."""
+        sc = self.conv_shortcut
+        if not (CAT_FREE and sc is not None and _hip_nhwc_ok(x) and _hip_nhwc_ok(skip) and skip.dtype == x.dtype
+                and x.shape[0] == skip.shape[0] and x.shape[2:] == skip.shape[2:]
+                and x.shape[1] % 64 == 0 and skip.shape[1] % 32 == 0 and x.shape[1] + skip.shape[1] <= 4096):
+            return False
+        if not (self.norm1.num_groups <= 64 and self.norm1.weight is not None and self.norm1.weight.dtype == x.dtype):
+            return False
+        rows = x.shape[0] * x.shape[2] * x.shape[3]
+        w = sc.weight
+        return (sc.kernel_size == (1, 1) and w.dtype == x.dtype and w.shape[0] % 4 == 0
+                and -(-rows // 128) * -(-w.shape[0] // 320) >= LINEAR_MIN_TILES)
+
+    def forward(self, x, temb, skip: Optional[torch.Tensor] = None):
+        """`skip`: the block runs on torch.cat([x, skip], dim=1) (up blocks) - read in place where the kernels allow it."""
+        if skip is not None and not self.cat_free_ok(x, skip):
+            x, skip = torch.cat([x, skip], dim=1), None
         # conv biases and the time-embedding add ride in the fused kernels: norm2 sees conv1(.) + (b1 + temb_c),
         # the residual join adds b2 (+ the shortcut's bias) in the same pass
-        h = conv_nobias(self.conv1, group_norm_act(self.norm1, x, True))
+        h = conv_nobias(self.conv1, group_norm_act(self.norm1, x, True, x2=skip))
         ad = self.temb_addend
         if ad is None:
             ad = linear(self.time_emb_proj, F.silu(temb))
             if self.conv1.bias is not None:
                 ad = ad + self.conv1.bias[None, :]
-        if self.conv_shortcut is not None:
+        if skip is not None:
+            # the 1x1 shortcut over x | skip: ONE GEMM whose contraction walks the two tensors in turn
+            from .. import edit as _edit
+            sc = self.conv_shortcut
+            N, C1, Hh, Ww = x.shape
+            y = _edit.UceHandle.get(x.device).linear(_nhwc_rows(x), sc.weight.reshape(sc.out_channels, -1), sc.bias,
+                                                     x2=_nhwc_rows(skip))
+            x = y.view(N, Hh, Ww, sc.out_channels).permute(0, 3, 1, 2)
+        elif self.conv_shortcut is not None:
             x = conv2d(self.conv_shortcut, x)                      # 1x1: a linear layer over the pixel rows, bias in its epilogue
         # x + conv2(.) + b2: the residual join rides in conv2's epilogue
         return conv2d(self.conv2, group_norm_act(self.norm2, h, True, addend=ad), residual=x)
@@ -396,7 +428,15 @@ class Attention(nn.Module):
             from .. import edit as _edit
             wq, wk, wv = self.to_q.weight, self.to_k.weight, self.to_v.weight
             wqkv = derived(self, "qkv", _pkey(wq, wk, wv), lambda: torch.cat([wq.detach(), wk.detach(), wv.detach()]).contiguous())
-            o = _edit.UceHandle.get(x.device).sattn_packed(linear_w(x.contiguous(), wqkv), self.heads)
+            handle = _edit.UceHandle.get(x.device)
+            dh = wq.shape[0] // self.heads
+            if SATTN_PRESCALE and dh == 40:
+                # the softmax scale (times log2 e) rides in the projection's epilogue, on the f32 accumulators of the q columns:
+                # the attention kernel's exp2 then takes the scores as the matrix cores deliver them (csrc/uce_sattn.hip, FOLD)
+                qkv = handle.linear(x.contiguous(), wqkv, col_scale=dh ** -0.5 * LOG2E, n_scaled=wq.shape[0])
+                o = handle.sattn_packed(qkv, self.heads, prescaled=True)
+            else:
+                o = handle.sattn_packed(linear_w(x.contiguous(), wqkv), self.heads)
             return linear(self.to_out[0], o, residual)
         ctx = x if context is None else context
         q = linear(self.to_q, x)
@@ -572,8 +612,7 @@ class UpBlock(nn.Module):
 
     def forward(self, x, skips: List[torch.Tensor], temb, context):
         for i, res in enumerate(self.resnets):
-            x = torch.cat([x, skips.pop()], dim=1)
-            x = res(x, temb)
+            x = res(x, temb, skip=skips.pop())
             if self.has_cross:
                 x = self.attentions[i](x, context)
         if self.upsamplers is not None:
