@@ -164,3 +164,62 @@ def test_two_persistent_factorisations_side_by_side(d):
             assert float((out.double() - want).norm() / want.norm()) < 1e-5
     finally:
         H2.close()
+
+
+ASAN_GPU_CHILD = r"""
+import os, sys
+sys.path.insert(0, os.environ["UCE_REPO_ROOT"])
+import torch
+from uce_amd import edit as E, lib as L
+assert L.lib_path() == os.environ["UCE_HIP_LIB"]
+ref = torch.load(os.environ["UCE_ASAN_REF"])
+H = E.UceHandle("cuda:0")
+outs = {}
+for name, (C, G, s, W) in ref["inputs"].items():
+    outs[name] = H.edit(C.cuda(), G.cuda(), s.cuda(), 0.5, W.cuda(), check=True).cpu()
+q, k, v = (t.cuda() for t in ref["qkv"])
+outs["xattn"] = H.xattn(q, k[:, :77].contiguous(), v[:, :77].contiguous(), 8).cpu()
+outs["sattn"] = H.sattn(q, k, v, 8).cpu()
+x, w = ref["lin"]
+outs["linear"] = H.linear(x.cuda(), w.cuda()).cpu()
+torch.cuda.synchronize()
+H.close()
+for n, t in outs.items():
+    assert torch.equal(t, ref["outputs"][n]), n
+print("asan gpu child ok")
+"""
+
+
+def test_edit_and_attention_through_the_address_sanitizer_build(tmp_path):
+    """The host side under AddressSanitizer on the GPU: the low-rank, the two-block and the primal edit (workspace growth, rider
+    hand-off words, the persistent Cholesky's job tables), both attention entries and a linear layer run in a child process that
+    loads the ASAN build - results bit-identical to the product library's (same device code), no ASAN report."""
+    import os
+    import subprocess
+    import sys
+    from uce_amd import REPO_ROOT, build as B, edit as E
+    path = B.asan_lib_path()
+    if not os.path.exists(path):
+        pytest.skip("the ASAN variant was not built (__graft_entry__.build() does)")
+    H = E.UceHandle.get("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    inputs = {}
+    for name, (N, n_e, rows) in {"lowrank": (50, 50, 2048), "two_block": (100, 100, 1024), "primal": (800, 500, 1024)}.items():
+        C = torch.randn(N, 768, generator=g)
+        C = (C + 2.0 * torch.randn(1, 768, generator=g)) * 0.9
+        G = C[:n_e].roll(1, 0).contiguous()
+        inputs[name] = (C, G, torch.ones(N), (torch.rand(rows, 768, generator=g) * 2 - 1) * 768 ** -0.5)
+    qkv = [torch.randn(2, 300, 320, generator=g).to(torch.bfloat16) for _ in range(3)]
+    lin = (torch.randn(4096, 320, generator=g).to(torch.bfloat16), (torch.randn(320, 320, generator=g) * 0.05).to(torch.bfloat16))
+    outputs = {n: H.edit(C.cuda(), G.cuda(), s.cuda(), 0.5, W.cuda(), check=True).cpu() for n, (C, G, s, W) in inputs.items()}
+    q, k, v = (t.cuda() for t in qkv)
+    outputs["xattn"] = H.xattn(q, k[:, :77].contiguous(), v[:, :77].contiguous(), 8).cpu()
+    outputs["sattn"] = H.sattn(q, k, v, 8).cpu()
+    outputs["linear"] = H.linear(lin[0].cuda(), lin[1].cuda()).cpu()
+    ref = tmp_path / "ref.pt"
+    torch.save({"inputs": inputs, "qkv": qkv, "lin": lin, "outputs": outputs}, ref)
+    env = dict(os.environ, UCE_HIP_LIB=path, LD_PRELOAD=B.asan_runtime(), UCE_REPO_ROOT=REPO_ROOT, UCE_ASAN_REF=str(ref),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=86:protect_shadow_gap=0")
+    res = subprocess.run([sys.executable, "-c", ASAN_GPU_CHILD], env=env, capture_output=True, text=True, timeout=900)
+    assert "AddressSanitizer" not in res.stderr, res.stderr[-3000:]
+    assert res.returncode == 0 and "asan gpu child ok" in res.stdout, (res.returncode, res.stdout[-500:], res.stderr[-3000:])

@@ -27,6 +27,10 @@ FLAGS = list(BASE_FLAGS)
 if os.environ.get("UCE_CHAIN_DEBUG"):          # phase stamps of the rider chain (tools/dbg_chain.py); never in the product build
     FLAGS.append("-DUCE_CHAIN_DEBUG")
 FLAGS += os.environ.get("UCE_DEFINES", "").split()            # experiment switches (-DNAME=VALUE ...), empty in the product build
+# the host-side AddressSanitizer build (tests/test_abi_cpu.py, SURVEY.md section 5 "sanitizers"): the handle's workspace
+# management, argument checks and dispatch compiled with ASAN, the device code left alone (gfx950 without xnack has no device ASAN)
+ASAN_DEFINES = "-fsanitize=address -fno-gpu-sanitize -shared-libsan -g"
+LINK_FLAGS = [f for f in FLAGS if f.startswith("-fsanitize") or f in ("-shared-libsan", "-fno-gpu-sanitize")]
 
 # Objects are only as fresh as the FLAGS they were compiled with: every flag set gets its own object directory, and a
 # build with debug / experiment flags links its own library file - the product libuce_hip.so is only ever made of
@@ -105,13 +109,43 @@ def build(force: bool = False, verbose: bool = True) -> str:
     stale_objs = set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - set(objs)
     for o in stale_objs:                      # a removed source must not stay linked in
         os.remove(o)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + LINK_FLAGS + ["-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print("[uce_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB_PATH
 
 
+def asan_runtime() -> str:
+    """The shared AddressSanitizer runtime of the compiler behind hipcc (to LD_PRELOAD into a Python that loads the ASAN build)."""
+    out = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(out) or not os.path.exists(out):
+        cands = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+        if not cands:
+            raise RuntimeError("libclang_rt.asan-x86_64.so not found")
+        out = cands[-1]
+    return out
+
+
+def asan_lib_path() -> str:
+    """Where build_asan() puts its library (the variant name is a hash of the flag set)."""
+    flags = BASE_FLAGS + ASAN_DEFINES.split()
+    return os.path.join(LIB_DIR, "libuce_hip.%s.so" % hashlib.sha256(" ".join(flags).encode()).hexdigest()[:10])
+
+
+def build_asan(verbose: bool = False) -> str:
+    """Build (if stale) the host-ASAN variant in a child interpreter - the flag set is fixed at import - and return its path."""
+    import sys
+    env = dict(os.environ, UCE_DEFINES=ASAN_DEFINES)
+    env.pop("UCE_CHAIN_DEBUG", None)
+    res = subprocess.run([sys.executable, os.path.abspath(__file__), "--if-stale"] + ([] if verbose else ["--quiet"]),
+                         env=env, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("ASAN build failed:\n" + res.stdout[-2000:] + res.stderr[-2000:])
+    return res.stdout.strip().splitlines()[-1]
+
+
 if __name__ == "__main__":
-    build(force=True)
+    import sys
+    build(force="--if-stale" not in sys.argv, verbose="--quiet" not in sys.argv)
     print(LIB_PATH)

@@ -143,7 +143,7 @@ template <int DHP, bool F16, int QT, bool VTI>
 __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
-                                               unsigned short one) {
+                                               unsigned short one, float lazy) {
   constexpr int NDV = (DHP + 31) / 32;      // output row tiles (of O^T)
   constexpr int DVP = NDV * 32;
   constexpr int KLD = DHP + 8;              // K tile row stride (elements): odd multiple of 16 B
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int qx, h, b;
   sattn_block(qx, h, b);
+  const float lazy_raw = lazy / scale_log2e;    // the lazy-maximum threshold in units of the raw scores (scale > 0)
   const int C = H * dh;
   const int lq = lane & 31, lh = lane >> 5;
   const long q0 = (long)qx * (128 * QT) + w * (32 * QT);
@@ -304,7 +305,10 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][j][r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32));
-      const float m_new = fmaxf(m[t], mt);                            // finite: every tile holds at least one real key
+      // lazy running maximum: raised only when a tile's maximum is more than `lazy` (log2 units) above it, so exp2's argument
+      // stays <= lazy (P <= 2^lazy: same relative precision, f32 sums) and the rescale of O below is rare even though SOME
+      // lane's maximum moves in almost every tile of a 64-query wave
+      const float m_new = (mt > m[t] + lazy_raw) ? mt : m[t];         // finite: every tile holds at least one real key
       const float alpha = __builtin_amdgcn_exp2f((m[t] - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first tile
       const float mc = m_new * scale_log2e;
       m[t] = m_new;
@@ -393,7 +397,7 @@ template <int DHP, bool F16, bool VTI>
 __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                  int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
-                                                 unsigned short one) {
+                                                 unsigned short one, float lazy) {
   constexpr int NDV = (DHP + 31) / 32;
   constexpr int DVP = NDV * 32;
   constexpr int KLD = DHP + 8;
@@ -410,6 +414,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int qx, h, b;
   sattn_block(qx, h, b);
+  const float lazy_raw = lazy / scale_log2e;    // the lazy-maximum threshold in units of the raw scores (scale > 0)
   const int C = H * dh;
   const int lq = lane & 31, lh = lane >> 5;
   const long row = (long)qx * 128 + w * 32 + lq;
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[j][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m, mt);
+    const float m_new = (mt > m + lazy_raw) ? mt : m;          // lazy running maximum (see k_sattn)
     const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_log2e);
     const float mc = m_new * scale_log2e;
     m = m_new;
@@ -640,7 +645,7 @@ template <int DHP, bool F16, bool VTI, bool FOLD>
 __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                  int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
-                                                 unsigned short one) {
+                                                 unsigned short one, float lazy) {
   constexpr int NDV = (DHP + 31) / 32;
   constexpr int DVP = NDV * 32;
   static_assert(DHP < DVP, "the softmax denominator rides in the padding row of V^T");
@@ -659,6 +664,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int qx, h, b;
   sattn_block(qx, h, b);
+  const float lazy_raw = lazy / scale_log2e;    // the lazy-maximum threshold in units of the raw scores (scale > 0)
   const int C = H * dh;
   const int lq = lane & 31, lh = lane >> 5;
   const long q0 = (long)qx * 256 + w * 64;
@@ -842,11 +848,13 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
       }
     }
     if constexpr (FOLD) {
-      // sc = s * c - mc (the MFMA subtracted the running maximum): the maximum moved iff some entry is positive.  mc stays a sum
-      // of two element-type numbers, rounded UP, so that the corrected entries are <= 0 and an unchanged maximum never
-      // re-enters this branch; the first half (mc = 0, nothing accumulated) takes it unconditionally and may lower mc.
+      // sc = s * c - mc (the MFMA subtracted the running maximum).  The maximum is LAZY: raised only when some entry exceeds
+      // `lazy` (log2 units; exp2's argument stays <= lazy) - in a 64-query wave SOME lane's maximum moves in almost every half tile,
+      // so an exact running maximum would take this branch (correct the scores in flight, rescale O) nearly always.  mc is a sum
+      // of two element-type numbers, rounded UP; the first half (mc = 0, nothing accumulated) takes the branch unconditionally
+      // and may lower mc.
       const bool first = hh == 0;
-      if (__any(mt[0] > 0.f || mt[1] > 0.f) || first) {
+      if (__any(mt[0] > lazy || mt[1] > lazy) || first) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
           const float want = mc[x] + (first ? mt[x] : fmaxf(mt[x], 0.f));
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
         }
       }
     } else {
-    if (__any(mt[0] > m[0] || mt[1] > m[1])) {  // the running max rarely moves after the first tiles
+    if (__any(mt[0] > m[0] + lazy_raw || mt[1] > m[1] + lazy_raw)) {  // lazy running maximum: see k_sattn
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const float m_new = fmaxf(m[x], mt[x]);
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
 
 template <int DHP, bool VTI, bool FOLD>
 int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
-                 float scale, int dtype, hipStream_t st, long ld) {
+                 float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 255) / 256, H, B);
   const float sl2 = sattn_sl2(scale);
   constexpr int NDV = (DHP + 31) / 32;
@@ -999,10 +1007,10 @@ int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, i
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI, FOLD>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
     hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI, FOLD>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
@@ -1010,7 +1018,7 @@ int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, i
 
 template <int DHP, bool VTI>
 int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
-                 float scale, int dtype, hipStream_t st, long ld) {
+                 float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 127) / 128, H, B);
   const float sl2 = sattn_sl2(scale);
   constexpr int NDV = (DHP + 31) / 32;
@@ -1024,17 +1032,17 @@ int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, i
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_sattn_p<DHP, true, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
     hipLaunchKernelGGL((k_sattn_p<DHP, false, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
 template <int DHP, int QT, bool VTI>
 int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
-               float scale, int dtype, hipStream_t st, long ld) {
+               float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
   const float sl2 = sattn_sl2(scale);
   constexpr int NDV = (DHP + 31) / 32;
@@ -1048,10 +1056,10 @@ int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int
   }
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_sattn<DHP, true, QT, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
     hipLaunchKernelGGL((k_sattn<DHP, false, QT, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
-                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one);
+                       (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
@@ -1069,30 +1077,30 @@ static bool sattn_use_h(int qt_variant, int dh, int Lq, int Lk, int H, int B) {
 // the kernel for one shape, with (VTI) or without the V^T pre-pass already run
 template <bool VTI>
 int launch_body(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh, float scale,
-                int dtype, hipStream_t st, int qt_variant, long ld, int fold) {
+                int dtype, hipStream_t st, int qt_variant, long ld, int fold, float lazy) {
   // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
   //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
   //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
   if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) {
     // dh = 40: the scale and the running maximum ride in the MFMA (two spare contraction slots), see k_sattn_h<FOLD>
-    if (fold && dh == 40) return launch_cfg_h<48, VTI, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
-    return launch_cfg_h<48, VTI, false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+    if (fold && dh == 40) return launch_cfg_h<48, VTI, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+    return launch_cfg_h<48, VTI, false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   }
-  if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
-    return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+    return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if (dh <= 48) {
     // two query tiles per wave once there are enough 256-row workgroups to fill the chip twice over
     const long wg2 = (long)((Lq + 255) / 256) * H * B;
     if (qt_variant != 1 && (qt_variant == 2 || wg2 >= 1024))
-      return launch_cfg<48, 2, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
-    return launch_cfg<48, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+      return launch_cfg<48, 2, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+    return launch_cfg<48, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   }
-  if (dh <= 64) return launch_cfg<64, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
-  if (dh <= 80) return launch_cfg<80, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
-  if (dh <= 96) return launch_cfg<96, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
-  if (dh <= 128) return launch_cfg<128, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
-  return launch_cfg<160, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld);
+  if (dh <= 64) return launch_cfg<64, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  if (dh <= 80) return launch_cfg<80, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  if (dh <= 96) return launch_cfg<96, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  if (dh <= 128) return launch_cfg<128, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  return launch_cfg<160, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
 }
 
 }  // namespace
@@ -1115,18 +1123,18 @@ bool sattn_inline_vt(int Lk, int vti, bool use_h) { return vti == 1 || (vti == 0
 // 2 = two query tiles wherever dh <= 48, 3 = the pipelined kernel wherever it exists (dh <= 48, 64 < dh <= 80)
 // ld: row stride (elements) of q, k and v; o rows are H * dh apart.
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, int fold) {
+                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, int fold, float lazy) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   if (ld <= 0) ld = (long)H * dh;
   if (fold == 2) scale = PRESCALED;             // q = to_q(x) * scale * log2(e) (uce_sattn_packed_prescaled_fwd)
-  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, fold);
+  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, fold, lazy);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   hipLaunchKernelGGL(k_vt, dim3(LkP / 64, (DVP + 63) / 64, B * H), dim3(256), 0, st, (const unsigned short*)v,
                      (unsigned short*)vt, H, Lk, dh, DVP, LkP, ones_row, one, ld);
   UCE_LAUNCH_CHECK();
-  return launch_body<false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, fold);
+  return launch_body<false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, fold, lazy);
 }
 
 static int sattn_check(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
@@ -1148,7 +1156,7 @@ extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const
   }
   UceProfScope ps(h, "uce_sattn_fwd", (hipStream_t)stream);
   return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, (long)H * dh,
-                      h->sw.sattn_vti, h->sw.sattn_fold);
+                      h->sw.sattn_vti, h->sw.sattn_fold, (float)h->sw.sattn_lazy);
 }
 
 extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, float scale, int dtype,
@@ -1163,7 +1171,7 @@ extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, in
   }
   UceProfScope ps(h, "uce_sattn_packed_fwd", (hipStream_t)stream);
   return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
-                      h->sw.sattn_vti, h->sw.sattn_fold);
+                      h->sw.sattn_vti, h->sw.sattn_fold, (float)h->sw.sattn_lazy);
 }
 
 extern "C" int uce_sattn_packed_prescaled_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, int dtype,
@@ -1178,5 +1186,5 @@ extern "C" int uce_sattn_packed_prescaled_fwd(uce_handle_t h, const void* qkv, v
   }
   UceProfScope ps(h, "uce_sattn_packed_prescaled_fwd", (hipStream_t)stream);
   return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, 1.f, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
-                      h->sw.sattn_vti, 2);
+                      h->sw.sattn_vti, 2, (float)h->sw.sattn_lazy);
 }
