@@ -175,13 +175,6 @@ int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, v
 int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, float scale, int dtype,
                          uce_stream_t stream);
 
-/* uce_sattn_packed_fwd for a projection whose q columns already carry the softmax scale: q = to_q(x) * (scale * log2(e)), as
- * uce_linear_colscale_fwd writes them (the scale goes onto the f32 accumulators, so q is rounded ONCE, like the reference's).
- * The kernels then take exp2 of the scores as they leave the matrix cores; at dh = 40 (the 4096- and 1024-token attn1 layers of
- * SD-1.4) the running maximum is subtracted by the MFMA as well (two spare contraction slots): no FMA per score. */
-int uce_sattn_packed_prescaled_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, int dtype,
-                                   uce_stream_t stream);
-
 /* SURVEY section 8(f) row 3 - GroupNorm (+ SiLU) of the U-Net / VAE at inference (diffusers ResnetBlock2D:
  * conv(silu(group_norm(x)))) for channels-last activations:  x, y [N, HW, C] (an NCHW tensor in
  * torch.channels_last memory format), gamma, beta [C], all bf16 or f16; G <= 64 groups of C/G consecutive
@@ -266,14 +259,6 @@ int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const voi
 enum { UCE_EPILOGUE_NONE = 0, UCE_EPILOGUE_GEGLU = 1, UCE_EPILOGUE_F32 = 2 };
 int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr,
                    void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream);
-
-/* uce_linear_fwd whose first n_scaled output columns leave as (x w^T + bias) * col_scale, the factor applied to the f32
- * accumulators (one rounding): the packed to_q | to_k | to_v projection of an attn1 layer with scale * log2(e) folded into q
- * (diffusers Attention.scale, applied by F.scaled_dot_product_attention in the reference).  n_scaled % 4 == 0, <= N; not with
- * UCE_EPILOGUE_GEGLU. */
-int uce_linear_colscale_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual,
-                            long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype, float col_scale,
-                            int n_scaled, uce_stream_t stream);
 
 /* uce_linear_fwd over a two-source contraction: columns [0, K1) of a row of the input come from x (row stride ldx), columns
  * [K1, K) from x2 (row stride ldx2) - the 1x1 conv_shortcut of an up block's ResnetBlock2D reading x and the skip connection in

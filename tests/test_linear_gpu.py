@@ -300,70 +300,6 @@ def test_vae_attention_on_the_linear_kernel_matches_its_torch_twin(H):
     assert O.rel_fro(y.double().cpu(), (x.permute(0, 2, 3, 1).reshape(-1, 512)[:700].double() @ att.to_q.weight.double().T).cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("wide", ["1", "0"])
-@pytest.mark.parametrize("M,N,K,ncs,dtype,bias,res", [
-    (4096, 960, 320, 320, torch.bfloat16, False, False),     # the packed q | k | v projection of a 64 x 64 attn1 layer: q scaled
-    (1000, 1920, 640, 640, torch.bfloat16, True, True),      # bias and residual: (x w^T + b) * c + r on the scaled columns
-    (333, 768, 256, 36, torch.float16, True, False),         # a boundary inside a 4-column group's tile, ragged M
-    (515, 128, 64, 128, torch.bfloat16, False, False),       # every column scaled
-])
-def test_linear_column_scale(wide, M, N, K, ncs, dtype, bias, res):
-    """uce_linear_colscale_fwd: the first n_scaled columns leave as (x w^T + bias) * col_scale, the factor on the f32
-    accumulators (one rounding) - whole-row and per-lane epilogue."""
-    Hv = _handle_with("UCE_WIDE_EPILOGUE", wide)
-    try:
-        g = torch.Generator().manual_seed(M + N + ncs)
-        x = _rand((M, K), g, dtype)
-        w = _rand((N, K), g, dtype, K ** -0.5)
-        b = _rand((N,), g, dtype) if bias else None
-        r = _rand((M, N), g, dtype) if res else None
-        c = 40 ** -0.5 * 1.4426950408889634
-        y = Hv.linear(x, w, b, r, col_scale=c, n_scaled=ncs)
-        want = x.double() @ w.double().T
-        if bias:
-            want = want + b.double()
-        want[:, :ncs] *= float(torch.tensor(c, dtype=torch.float32))
-        if res:
-            want = want + r.double()
-        assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[dtype]
-        assert O.rel_fro(y[:, :ncs].double().cpu(), want[:, :ncs].cpu()) < TOL[dtype]
-        # the unscaled columns are the plain layer's, bit for bit
-        assert torch.equal(y[:, ncs:], Hv.linear(x, w, b, r)[:, ncs:])
-        from uce_amd import lib as L
-        with pytest.raises(L.UceError):
-            Hv.linear(x, w, b, r, col_scale=c, n_scaled=ncs + 2)          # not a multiple of 4
-        with pytest.raises(L.UceError):
-            Hv.linear(x, w, b, r, col_scale=c, n_scaled=N + 4)
-    finally:
-        torch.cuda.synchronize()
-        Hv.close()
-
-
-def test_attn1_prescaled_path_matches_the_plain_one():
-    """sd.unet.Attention at dh = 40 with UCE_SATTN_PRESCALE: the scaled projection + uce_sattn_packed_prescaled_fwd against the
-    plain packed path on the same layer (both within one output rounding of fp64; they differ by the roundings of q only)."""
-    from uce_amd.sd import unet as U
-    torch.manual_seed(3)
-    att = U.Attention(320, 8, 40).to("cuda:0", torch.bfloat16)
-    x = (torch.randn(4, 4096, 320) * 1.5).to(torch.bfloat16).cuda()
-    old = U.SATTN_PRESCALE
-    try:
-        U.SATTN_PRESCALE = False
-        a = att(x)
-        U.SATTN_PRESCALE = True
-        b = att(x)
-    finally:
-        U.SATTN_PRESCALE = old
-    q, k, v = (F.linear(x.double(), w.double()) for w in (att.to_q.weight, att.to_k.weight, att.to_v.weight))
-    B, L, C = q.shape
-    sp = lambda t: t.view(B, L, 8, 40).transpose(1, 2)
-    o = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * 40 ** -0.5, dim=-1) @ sp(v)
-    want = F.linear(o.transpose(1, 2).reshape(B, L, C), att.to_out[0].weight.double(), att.to_out[0].bias.double())
-    ea, eb = O.rel_fro(a.double().cpu(), want.cpu()), O.rel_fro(b.double().cpu(), want.cpu())
-    print(dict(plain=ea, prescaled=eb))
-    assert ea < 1.5e-2 and eb < 1.5e-2 and eb < 1.5 * ea + 1e-3
-
-
 @pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "64256320", "64128320", "2128320", "3128256"])
 @pytest.mark.parametrize("M,N,K1,K2,bias,res", [
     (4096, 320, 320, 320, True, False),        # up_blocks.3: x | skip at 64 x 64

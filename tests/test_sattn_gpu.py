@@ -179,117 +179,3 @@ def test_sattn_half_tile_pipeline_rising_max_and_packed():
     finally:
         torch.cuda.synchronize()
         Hv.close()
-
-
-def _handle_with(env: dict):
-    """A handle of its own created under `env` (the A/B switches are read at uce_create)."""
-    import os
-    from uce_amd import edit as E
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return E.UceHandle("cuda:0")
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
-
-
-LOG2E = 1.4426950408889634
-
-FOLD_SHAPES = [
-    (2, 8, 1024, torch.bfloat16, 1.0),    # full tiles
-    (1, 8, 130, torch.bfloat16, 1.0),     # ragged: partial query tile, three key tiles, the last one masked
-    (3, 4, 64, torch.float16, 1.0),       # exactly one key tile, f16 (the maximum rides as two f16 pieces)
-    (2, 4, 33, torch.bfloat16, 1.0),      # second half of the only tile holds a single key
-    (1, 4, 128, torch.float16, 1.0),      # two full tiles, no masked path
-    (2, 4, 1, torch.bfloat16, 1.0),       # one key: softmax == 1
-    (1, 8, 4000, torch.bfloat16, 1.0),    # 63 key tiles, 16 query workgroups
-    (1, 4, 640, torch.bfloat16, 6.0),     # large logits (|s c| ~ 100)
-    (1, 4, 640, torch.bfloat16, 0.05),    # tiny logits
-]
-
-
-@pytest.mark.parametrize("B,H_,L,dtype,mag", FOLD_SHAPES)
-def test_sattn_fold_prescaled_q(B, H_, L, dtype, mag):
-    """k_sattn_h<FOLD> behind uce_sattn_packed_prescaled_fwd (forced at every size): q columns that already hold
-    q * scale * log2(e) - the MFMA subtracts the running maximum, exp2 takes the scores as they come.  Reference: fp64 softmax
-    of the SAME (rounded) q', i.e. softmax(ln 2 * q' k^T) v."""
-    Hv = _handle_with({"UCE_SATTN_QT": "4"})
-    try:
-        g = torch.Generator().manual_seed(L * 3 + int(mag * 10))
-        dh = 40
-        C = H_ * dh
-        c = dh ** -0.5 * LOG2E
-        qp = (torch.randn(B, L, C, generator=g) * mag * c).to(dtype)
-        k = (torch.randn(B, L, C, generator=g) * mag).to(dtype)
-        v = torch.randn(B, L, C, generator=g).to(dtype)
-        qkv = torch.cat([qp, k, v], dim=-1).cuda()
-        o = Hv.sattn_packed(qkv, H_, prescaled=True)
-        again = Hv.sattn_packed(qkv, H_, prescaled=True)
-        ref = _ref_gpu(qp.cuda(), k.cuda(), v.cuda(), H_, scale=1.0 / LOG2E)
-        assert torch.isfinite(o.float()).all()
-        assert O.rel_fro(o.double().cpu(), ref.cpu()) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
-        assert torch.equal(o, again)
-        if L == 1:
-            assert torch.equal(o.cpu(), v)
-    finally:
-        torch.cuda.synchronize()
-        Hv.close()
-
-
-def test_sattn_fold_special_rows():
-    """The cases the folded maximum has to get right: every score negative in the first half tile (the maximum is LOWERED from its
-    start value 0), a maximum that rises in every half tile (the deferred P V product is rescaled with the accumulators, the
-    scores in flight are corrected), a maximum that sits in the first key (no later tile enters the update branch), and scores far
-    above 2^8 (the two-piece maximum keeps exp2's argument exact to 2^-16 of the maximum)."""
-    Hv = _handle_with({"UCE_SATTN_QT": "4"})
-    try:
-        g = torch.Generator().manual_seed(33)
-        B, H_, L, dh = 1, 4, 640, 40
-        C = H_ * dh
-        c = dh ** -0.5 * LOG2E
-        v = torch.randn(B, L, C, generator=g).to(torch.bfloat16)
-        qa = torch.randn(B, L, C, generator=g).abs()
-        ka = torch.randn(B, L, C, generator=g).abs()
-        ramp = torch.linspace(0.1, 3.0, L)[None, :, None]
-        cases = {
-            "all negative": (qa * 2 * c, -ka),
-            "rising": (qa * 3 * c, ka * ramp),
-            "falling": (qa * 3 * c, ka * ramp.flip(1)),
-            "huge": (qa * 12 * c, ka * ramp * 2),
-        }
-        for name, (qp, k) in cases.items():
-            qp, k = qp.to(torch.bfloat16), k.to(torch.bfloat16)
-            qkv = torch.cat([qp, k, v], dim=-1).cuda()
-            o = Hv.sattn_packed(qkv, H_, prescaled=True)
-            ref = _ref_gpu(qp.cuda(), k.cuda(), v.cuda(), H_, scale=1.0 / LOG2E)
-            assert torch.isfinite(o.float()).all(), name
-            assert O.rel_fro(o.double().cpu(), ref.cpu()) < TOL_BF16, name
-    finally:
-        torch.cuda.synchronize()
-        Hv.close()
-
-
-def test_sattn_fold_in_kernel_scale_matches_plain():
-    """UCE_SATTN_FOLD=1: the generic entry on the folded kernel, Q scaled (and rounded once more) inside the kernel - against
-    fp64 and against the FMA form of the same kernel on N(0, 1) inputs, where the second rounding of Q stays far below bf16's own."""
-    Hf, Hp = _handle_with({"UCE_SATTN_QT": "4", "UCE_SATTN_FOLD": "1"}), _handle_with({"UCE_SATTN_QT": "4"})
-    try:
-        g = torch.Generator().manual_seed(4)
-        for (B, H_, Lq, Lk, dt) in ((2, 8, 512, 512, torch.bfloat16), (1, 4, 130, 97, torch.float16)):
-            C = H_ * 40
-            q = torch.randn(B, Lq, C, generator=g).to(dt).cuda()
-            k = torch.randn(B, Lk, C, generator=g).to(dt).cuda()
-            v = torch.randn(B, Lk, C, generator=g).to(dt).cuda()
-            a, b = Hf.sattn(q, k, v, H_), Hp.sattn(q, k, v, H_)
-            ref = _ref_gpu(q, k, v, H_)
-            tol = TOL_BF16 if dt == torch.bfloat16 else TOL_F16
-            assert O.rel_fro(a.double().cpu(), ref.cpu()) < tol
-            assert O.rel_fro(a.double().cpu(), b.double().cpu()) < tol
-    finally:
-        torch.cuda.synchronize()
-        Hf.close()
-        Hp.close()

@@ -71,8 +71,6 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       wherever dh <= 48 | 3: the software-pipelined k_sattn_p wherever it exists
 //   UCE_SATTN_VTI       0: V^T of the self-attention transposed on the way into LDS up to 1024 keys, by the k_vt pre-pass beyond |
 //                       1: always inline | 2: always the pre-pass
-//   UCE_SATTN_FOLD      1: k_sattn_h at dh = 40 with scale * log2(e) folded into Q and the running maximum subtracted by the MFMA
-//                       (no FMA per score in front of exp2) | 0: the FMA form
 //   UCE_SATTN_LAZY      self-attention: the running maximum of the online softmax is raised only when a key tile's maximum exceeds
 //                       it by more than this many powers of two (default 8: P <= 256; 0: exact running maximum, rescale whenever it moves)
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
@@ -85,7 +83,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_fold, sattn_lazy;
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -258,7 +256,7 @@ int uce_ensure_T_floats(uce_ctx* h, size_t need);   // h->T holds >= need floats
 int uce_ensure_Vt(uce_ctx* h, size_t elems);
 size_t sattn_vt_elems(int B, int H, int Lk, int dh);
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st, int qt_variant = 0, long ld = 0, int vti = 0, int fold = 0, float lazy = 8.f);
+                 float scale, int dtype, hipStream_t st, int qt_variant = 0, long ld = 0, int vti = 0, float lazy = 8.f);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
                  int dh, float scale, int dtype, hipStream_t st, int variant = 1);
 

@@ -69,7 +69,7 @@ constexpr int wave_bytes() { return 32 * row_bytes<CH, GEGLU>(); }
 template <int TM, int TN, bool F16, bool GEGLU, int CH, int CA>
 __device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], int b, unsigned char* lds, const unsigned short* __restrict__ bias,
                                             const unsigned short* __restrict__ res, long ldr, unsigned short* __restrict__ Y,
-                                            long ldy, long mrow0, int ncol0, long M, int N, int lane, float cscale, int ncs) {
+                                            long ldy, long mrow0, int ncol0, long M, int N, int lane) {
   constexpr int CW = (TN - CA < CH) ? TN - CA : CH;
   constexpr int ROWB = row_bytes<CH, GEGLU>();
   constexpr int CPR = (GEGLU ? CW * 32 : CW * 64) / 16;                   // 16-byte pieces per row of the chunk
@@ -101,10 +101,9 @@ __device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], int b, uns
         const int n = ncol0 + a * 32 + 8 * g + 4 * lh;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias && n < N) unpack4<F16>(*(const uint2_t*)(bias + n), bv);
-        const float cs = n < ncs ? cscale : 1.f;                          // (column scale: ncs is a multiple of 4)
         *(uint2_t*)(lds + li * ROWB + (aa * 32 + 8 * g + 4 * lh) * 2) =
-            (uint2_t){pack2<F16>((acc[a][b][4 * g] + bv[0]) * cs, (acc[a][b][4 * g + 1] + bv[1]) * cs),
-                      pack2<F16>((acc[a][b][4 * g + 2] + bv[2]) * cs, (acc[a][b][4 * g + 3] + bv[3]) * cs)};
+            (uint2_t){pack2<F16>(acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1]),
+                      pack2<F16>(acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3])};
       }
     }
   }
@@ -129,7 +128,7 @@ __device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], int b, uns
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the chunk is read before the next one overwrites it
   if constexpr (CA + CH < TN)
-    store_chunk<TM, TN, F16, GEGLU, CH, CA + CH>(acc, b, lds, bias, res, ldr, Y, ldy, mrow0, ncol0, M, N, lane, cscale, ncs);
+    store_chunk<TM, TN, F16, GEGLU, CH, CA + CH>(acc, b, lds, bias, res, ldr, Y, ldy, mrow0, ncol0, M, N, lane);
 }
 
 // acc[a][b][4 g + i]: column 32 a + 8 g + 4 lh + i of the wave's TN x 32 columns, row 32 b + li of its TM x 32 rows.
@@ -137,15 +136,13 @@ __device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], int b, uns
 //   bias    indexed by the (interleaved, for GEGLU) column; may be null.   res / ldr: residual rows (MODE 0), may be null
 //   mrow0   first row of the wave's slab (global), ncol0 its first column in the index space of `bias` (a multiple of 32)
 //   M, N    bounds in that space (GEGLU: N counts the interleaved columns; the output has N / 2)
-//   cscale, ncs   MODE 0: columns < ncs leave as (acc + bias) * cscale (uce_linear_colscale_fwd; ncs = 0: none)
 template <int TM, int TN, bool F16, bool GEGLU, int CH = TN>
 __device__ __forceinline__ void store_rows(float16_t (&acc)[TN][TM], unsigned char* lds, const unsigned short* __restrict__ bias,
                                            const unsigned short* __restrict__ res, long ldr, unsigned short* __restrict__ Y,
-                                           long ldy, long mrow0, int ncol0, long M, int N, int lane, float cscale = 1.f,
-                                           int ncs = 0) {
+                                           long ldy, long mrow0, int ncol0, long M, int N, int lane) {
 #pragma unroll
   for (int b = 0; b < TM; ++b)
-    store_chunk<TM, TN, F16, GEGLU, CH, 0>(acc, b, lds, bias, res, ldr, Y, ldy, mrow0, ncol0, M, N, lane, cscale, ncs);
+    store_chunk<TM, TN, F16, GEGLU, CH, 0>(acc, b, lds, bias, res, ldr, Y, ldy, mrow0, ncol0, M, N, lane);
 }
 
 }  // namespace uce_epi

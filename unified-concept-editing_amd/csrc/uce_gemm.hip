@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
                                                   const unsigned short* __restrict__ bias,
                                                   const unsigned short* __restrict__ R, long ldr,
                                                   unsigned short* __restrict__ Y, long ldy, long M, int N, int K,
-                                                  int mtiles, int ntiles, int outf32, float cscale, int ncs,
+                                                  int mtiles, int ntiles, int outf32,
                                                   const unsigned short* __restrict__ X2, long ldx2, int K1) {
   static_assert(WGM * WGN == 8, "eight waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
     __builtin_amdgcn_s_barrier();                                      // every wave's tail re-loads have landed: the ring is free
     constexpr int CH = (NST == 4 || TN < 2) ? TN : 2;                  // (shallow ring: the slabs must fit the smaller allocation)
     uce_epi::store_rows<TM, TN, F16, GEGLU, CH>(acc, smem + w * uce_epi::wave_bytes<CH, GEGLU>(), bias, R, ldr, Y, ldy,
-                                                m0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane, cscale, ncs);
+                                                m0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane);
   } else if constexpr (GEGLU) {
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -273,7 +273,6 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
         const int n = n0 + (wn * TN + a) * 32 + 8 * g + 4 * lh;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias && n < N) gd_unpack4<F16>(*(const uint2_t*)(bias + n), bv);
-        const float cs = n < ncs ? cscale : 1.f;
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
           const long m = m0 + (wm * TM + b) * 32 + li;
@@ -281,12 +280,12 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (R) gd_unpack4<F16>(*(const uint2_t*)(R + m * ldr + n), rv);
             if (outf32) {                                                // f32 result (attention scores ahead of a softmax)
-              *(float4_t*)((float*)Y + m * ldy + n) = (float4_t){(acc[a][b][4 * g] + bv[0]) * cs + rv[0], (acc[a][b][4 * g + 1] + bv[1]) * cs + rv[1],
-                                                                 (acc[a][b][4 * g + 2] + bv[2]) * cs + rv[2], (acc[a][b][4 * g + 3] + bv[3]) * cs + rv[3]};
+              *(float4_t*)((float*)Y + m * ldy + n) = (float4_t){acc[a][b][4 * g] + bv[0] + rv[0], acc[a][b][4 * g + 1] + bv[1] + rv[1],
+                                                                 acc[a][b][4 * g + 2] + bv[2] + rv[2], acc[a][b][4 * g + 3] + bv[3] + rv[3]};
               continue;
             }
-            const uint2_t o = {gd_pack2<F16>((acc[a][b][4 * g] + bv[0]) * cs + rv[0], (acc[a][b][4 * g + 1] + bv[1]) * cs + rv[1]),
-                               gd_pack2<F16>((acc[a][b][4 * g + 2] + bv[2]) * cs + rv[2], (acc[a][b][4 * g + 3] + bv[3]) * cs + rv[3])};
+            const uint2_t o = {gd_pack2<F16>(acc[a][b][4 * g] + bv[0] + rv[0], acc[a][b][4 * g + 1] + bv[1] + rv[1]),
+                               gd_pack2<F16>(acc[a][b][4 * g + 2] + bv[2] + rv[2], acc[a][b][4 * g + 3] + bv[3] + rv[3])};
             *(uint2_t*)(Y + m * ldy + n) = o;
           }
         }
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
 
 template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32>
 int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
-               int K, hipStream_t st, int outf32 = 0, float cscale = 1.f, int ncs = 0, const void* x2 = nullptr, long ldx2 = 0,
+               int K, hipStream_t st, int outf32 = 0, const void* x2 = nullptr, long ldx2 = 0,
                int K1 = 0) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   if (x2 && K1 % BK) return UCE_EINVAL;
@@ -318,20 +317,20 @@ int launch_one(const void* x, long ldx, const void* w, const void* bias, const v
   }
   hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                      ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
-                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, cscale, ncs, (const unsigned short*)x2, ldx2, K1);
+                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, (const unsigned short*)x2, ldx2, K1);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
 template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4, int BK = 32>
 int launch_shape(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
-                 int K, int geglu, int dtype, hipStream_t st, int outf32 = 0, float cscale = 1.f, int ncs = 0, const void* x2 = nullptr,
+                 int K, int geglu, int dtype, hipStream_t st, int outf32 = 0, const void* x2 = nullptr,
                  long ldx2 = 0, int K1 = 0) {
   if (dtype == UCE_DTYPE_F16)
     return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, cscale, ncs, x2, ldx2, K1);
+                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1);
   return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, cscale, ncs, x2, ldx2, K1);
+               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1);
 }
 
 // padded MFMA work of an N-wide output on BN-wide tiles, relative
@@ -342,7 +341,7 @@ inline long waste(int N, int BN) { return (long)((N + BN - 1) / BN) * BN; }
 // tile choice: the column width that wastes the fewest MFMAs on N (320 tiles SD's 320 / 640 / 1280 / 2560 ... exactly,
 // 256 the VAE's and the text encoder's widths), and 128-row tiles when 256-row tiles would leave CUs without a workgroup
 int launch_linear(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
-                  int K, int geglu, int dtype, hipStream_t st, int force_tile, int wide, int outf32, float cscale = 1.f, int ncs = 0,
+                  int K, int geglu, int dtype, hipStream_t st, int force_tile, int wide, int outf32,
                   const void* x2 = nullptr, long ldx2 = 0, int K1 = 0) {
   // Tile: the one whose padded work per CU - ceil(tiles / 256) x BM x BN, over the tile's measured efficiency (256 x 320: 1,
   // 256 x 256: 0.95, 128 x 320: 0.8; tools/probe_r04.py) - is smallest: 320-wide tiles for SD's 320-multiples unless a narrower or
@@ -380,18 +379,18 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   if (!wide_ok) nst = 4;
   // 64-wide k-tiles, two stages (UCE_GEMM_TILE = 64256320 / 64256256 / 64128320; K % 64 == 0, whole-row epilogue)
   if (nst == 64 && K % 64 == 0 && wide_ok) {
-    if (bm == 256 && bn == 320) return launch_shape<4, 2, 2, 5, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1);
-    if (bm == 256 && bn == 256) return launch_shape<2, 4, 4, 2, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1);
-    if (bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1);
+    if (bm == 256 && bn == 320) return launch_shape<4, 2, 2, 5, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1);
+    if (bm == 256 && bn == 256) return launch_shape<2, 4, 4, 2, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1);
+    if (bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2, 64>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1);
   }
   if (nst == 64) nst = 4;
   // two workgroups per CU (shallow ring): UCE_GEMM_TILE = 2128320 / 3128256 / 3256128
-  if (nst == 2 && bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1);
-  if (nst == 3 && bm == 128 && bn == 256) return launch_shape<2, 4, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1);
-  if (nst == 3 && bm == 256 && bn == 128) return launch_shape<4, 2, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1);
+  if (nst == 2 && bm == 128 && bn == 320) return launch_shape<4, 2, 1, 5, true, 2>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1);
+  if (nst == 3 && bm == 128 && bn == 256) return launch_shape<2, 4, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1);
+  if (nst == 3 && bm == 256 && bn == 128) return launch_shape<4, 2, 2, 2, true, 3>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1);
 #define UCE_GD(WGM, WGN, TM, TN)                                                                                                  \
-  return wide_ok ? launch_shape<WGM, WGN, TM, TN, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, cscale, ncs, x2, ldx2, K1) \
-                 : launch_shape<WGM, WGN, TM, TN, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, outf32, cscale, ncs, x2, ldx2, K1);
+  return wide_ok ? launch_shape<WGM, WGN, TM, TN, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1) \
+                 : launch_shape<WGM, WGN, TM, TN, false>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, outf32, x2, ldx2, K1);
   if (bm == 256 && bn == 320) { UCE_GD(4, 2, 2, 5) }
   if (bm == 256 && bn == 256) { UCE_GD(2, 4, 4, 2) }
   if (bm == 128 && bn == 320) { UCE_GD(4, 2, 1, 5) }
@@ -402,7 +401,7 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
 }
 
 static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual,
-                        long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype, float cscale, int ncs,
+                        long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype,
                         uce_stream_t stream, const char* name, const void* x2 = nullptr, long ldx2 = 0, int K1 = 0) {
   if (!h || !x || !w || !y || M <= 0 || N <= 0 || K <= 0) return UCE_EINVAL;
   if (x2 && (K1 <= 0 || K1 >= K || K1 % 32 || ldx < K1 || ldx2 < K - K1 || ldx2 % 8 || ((uintptr_t)x2 & 15))) return UCE_EINVAL;
@@ -413,7 +412,6 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
   // 64-byte k-tiles, 8-byte epilogue accesses, 16-byte DMA pieces
   if (K % 32 || N % 4 || (!x2 && ldx < K) || ldx % 8 || ldy % 4 || (residual && (ldr % 4 || geglu))) return UCE_EINVAL;
   if (geglu && N % 32) return UCE_EINVAL;
-  if (ncs < 0 || ncs > N || ncs % 4 || (ncs && geglu)) return UCE_EINVAL;
   if (ldy < (geglu ? N / 2 : N) || (residual && ldr < N)) return UCE_EINVAL;
   if ((((uintptr_t)x | (uintptr_t)w) & 15) || (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 7)) return UCE_EINVAL;
   if (outf32 && ((uintptr_t)y & 15)) return UCE_EINVAL;
@@ -429,7 +427,7 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
     const int rc = launch_linear((const unsigned short*)x + m0 * ldx, ldx, w, bias,
                                  residual ? (const void*)((const unsigned short*)residual + m0 * ldr) : nullptr, ldr,
                                  (unsigned char*)y + m0 * ldy * ybytes, ldy, mb, N, K, geglu, dtype, (hipStream_t)stream, force,
-                                 h->sw.wide_epilogue, outf32, cscale, ncs,
+                                 h->sw.wide_epilogue, outf32,
                                  x2 ? (const void*)((const unsigned short*)x2 + m0 * ldx2) : nullptr, ldx2, K1);
     if (rc != UCE_OK) return rc;
   }
@@ -438,20 +436,13 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
 
 extern "C" int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual,
                               long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream) {
-  return linear_entry(h, x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, epilogue, dtype, 1.f, 0, stream, "uce_linear_fwd");
-}
-
-extern "C" int uce_linear_colscale_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual,
-                                       long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype, float col_scale,
-                                       int n_scaled, uce_stream_t stream) {
-  return linear_entry(h, x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, epilogue, dtype, col_scale, n_scaled, stream,
-                      "uce_linear_colscale_fwd");
+  return linear_entry(h, x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, epilogue, dtype, stream, "uce_linear_fwd");
 }
 
 extern "C" int uce_linear_cat_fwd(uce_handle_t h, const void* x, long ldx, const void* x2, long ldx2, int K1, const void* w,
                                   const void* bias, const void* residual, long ldr, void* y, long ldy, long M, int N, int K,
                                   int epilogue, int dtype, uce_stream_t stream) {
   if (!x2) return UCE_EINVAL;
-  return linear_entry(h, x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, epilogue, dtype, 1.f, 0, stream, "uce_linear_cat_fwd", x2,
+  return linear_entry(h, x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, epilogue, dtype, stream, "uce_linear_cat_fwd", x2,
                       ldx2, K1);
 }

@@ -47,39 +47,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-// a packed pair of 16-bit elements times c, rounded back to the element type
-template <bool F16>
-__device__ __forceinline__ unsigned scale2(unsigned w, float c) {
-  if constexpr (F16) {
-    const float2_t v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), float2_t);
-    return pack2<true>(v[0] * c, v[1] * c);
-  } else {
-    return pack2<false>(__builtin_bit_cast(float, w << 16) * c, __builtin_bit_cast(float, w & 0xffff0000u) * c);
-  }
-}
-
-// the smallest element-type number >= v (finite v)
-template <bool F16>
-__device__ __forceinline__ float ceil_elem(float v) {
-  if constexpr (F16) {
-    _Float16 hf = (_Float16)v;
-    if ((float)hf < v) {
-      unsigned short bits = __builtin_bit_cast(unsigned short, hf);
-      bits = (bits & 0x8000u) ? (unsigned short)(bits - 1) : (unsigned short)(bits + 1);
-      hf = __builtin_bit_cast(_Float16, bits);
-    }
-    return (float)hf;
-  } else {
-    const unsigned bits = __builtin_bit_cast(unsigned, v);
-    return __builtin_bit_cast(float, (bits + (v > 0.f ? 0xffffu : 0u)) & 0xffff0000u);
-  }
-}
-
 constexpr int KT = 64;            // keys per tile
-
-// scale * log2(e), the factor in front of the scores inside exp2; PRESCALED (internal): q already carries it
-constexpr float PRESCALED = -1.f;
-inline float sattn_sl2(float scale) { return scale == PRESCALED ? 1.f : scale * 1.4426950408889634f; }
 
 // (query tile, head, batch) of a workgroup.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
 // its own L2: with the natural order the query tiles of one (batch, head) land on all 8 XCDs and every XCD streams every
@@ -305,9 +273,10 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][j][r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32));
-      // lazy running maximum: raised only when a tile's maximum is more than `lazy` (log2 units) above it, so exp2's argument
-      // stays <= lazy (P <= 2^lazy: same relative precision, f32 sums) and the rescale of O below is rare even though SOME
-      // lane's maximum moves in almost every tile of a 64-query wave
+      // LAZY running maximum: raised only when a tile's maximum is more than `lazy` powers of two above it, so exp2's argument
+      // stays <= lazy (P <= 2^lazy: the same relative precision in bf16 / f16, f32 sums) and the rescale of O below is rare.  With
+      // the exact running maximum SOME lane's maximum moves in almost every tile of a 64-query wave (probability
+      // 1 - (1 - 1/t)^64 at tile t for exchangeable scores), so the "rare" branch ran nearly always.
       const float m_new = (mt > m[t] + lazy_raw) ? mt : m[t];         // finite: every tile holds at least one real key
       const float alpha = __builtin_amdgcn_exp2f((m[t] - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first tile
       const float mc = m_new * scale_log2e;
@@ -641,7 +610,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 // 896 of matrix pipe).  P V trails by one half so the rescale of O still covers it; K is staged two tiles ahead and V^T
 // one behind: three LDS buffers each.  dh < DVP only (the denominator comes out of the ones row of V^T).
 // ---------------------------------------------------------------------------------------------
-template <int DHP, bool F16, bool VTI, bool FOLD>
+template <int DHP, bool F16, bool VTI>
 __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                  int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
@@ -678,10 +647,6 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
     for (int s = 0; s < NS; ++s) {
       const int dim = 16 * s + 8 * lh;
       qf[x][s] = (dim < dh) ? *(const uint4_t*)(qrow + dim) : (uint4_t){0u, 0u, 0u, 0u};
-      if constexpr (FOLD) {                     // Q <- Q * scale * log2(e), rounded once more to the element type
-#pragma unroll
-        for (int j = 0; j < 4; ++j) qf[x][s][j] = scale2<F16>(qf[x][s][j], scale_log2e);
-      }
     }
   }
   const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
@@ -695,11 +660,6 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
       const int key = e / KCH, dim = (e - key * KCH) * 8;
       rk[i] = (uint4_t){0u, 0u, 0u, 0u};
       if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
-      // FOLD: the two contraction slots behind the head dims (dh = DHP - 8) hold 1.0 in every key row; the matching slots
-      // of Q^T carry minus the running maximum (two element-type pieces), so the MFMA itself yields s * c - m
-      if constexpr (FOLD) {
-        if (dim == DHP - 8) rk[i] = (uint4_t){(unsigned)one | ((unsigned)one << 16), 0u, 0u, 0u};
-      }
     }
   };
   auto g_load_v = [&](int t) {
@@ -757,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
     }
   }
 
-  float m[2] = {-INFINITY, -INFINITY};         // FOLD: unused (mc is the state)
+  float m[2] = {-INFINITY, -INFINITY};
   float16_t oacc[2][NDV];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -847,33 +807,6 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if constexpr (FOLD) {
-      // sc = s * c - mc (the MFMA subtracted the running maximum).  The maximum is LAZY: raised only when some entry exceeds
-      // `lazy` (log2 units; exp2's argument stays <= lazy) - in a 64-query wave SOME lane's maximum moves in almost every half tile,
-      // so an exact running maximum would take this branch (correct the scores in flight, rescale O) nearly always.  mc is a sum
-      // of two element-type numbers, rounded UP; the first half (mc = 0, nothing accumulated) takes the branch unconditionally
-      // and may lower mc.
-      const bool first = hh == 0;
-      if (__any(mt[0] > lazy || mt[1] > lazy) || first) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          const float want = mc[x] + (first ? mt[x] : fmaxf(mt[x], 0.f));
-          const float hi = ceil_elem<F16>(want);
-          const float lo = ceil_elem<F16>(want - hi);                     // <= 0, exact difference
-          const float m_new = hi + lo;
-          const float delta = m_new - mc[x];
-          const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-          mc[x] = m_new;
-          if (lh) qf[x][NS - 1][0] = pack2<F16>(-hi, -lo);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[x][r] -= delta;
-#pragma unroll
-          for (int nt = 0; nt < NDV; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[x][nt][r] *= alpha;
-        }
-      }
-    } else {
     if (__any(mt[0] > m[0] + lazy_raw || mt[1] > m[1] + lazy_raw)) {  // lazy running maximum: see k_sattn
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
@@ -886,7 +819,6 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[x][nt][r] *= alpha;
       }
-    }
     }
   };
   // ---- bracket 2: S^T of the next half | exp2 and the P fragments of this one (16 register pairs over 2 NS MFMAs)
@@ -910,8 +842,8 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
 #pragma unroll
         for (int p = i * PPC; p < (i + 1) * PPC && p < 16; ++p) {
           const int x = p >> 3, r0 = 2 * (p & 7);
-          const float e0 = __builtin_amdgcn_exp2f(FOLD ? sc[x][r0] : fmaf(sc[x][r0], scale_log2e, -mc[x]));
-          const float e1 = __builtin_amdgcn_exp2f(FOLD ? sc[x][r0 + 1] : fmaf(sc[x][r0 + 1], scale_log2e, -mc[x]));
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[x][r0], scale_log2e, -mc[x]));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(sc[x][r0 + 1], scale_log2e, -mc[x]));
           pf[x][r0 >> 3][(r0 & 7) >> 1] = pack2<F16>(e0, e1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -991,25 +923,25 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   }
 }
 
-template <int DHP, bool VTI, bool FOLD>
+template <int DHP, bool VTI>
 int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                  float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 255) / 256, H, B);
-  const float sl2 = sattn_sl2(scale);
+  const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)3 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI, FOLD>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
-    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI, FOLD>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -1020,7 +952,7 @@ template <int DHP, bool VTI>
 int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                  float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 127) / 128, H, B);
-  const float sl2 = sattn_sl2(scale);
+  const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
@@ -1044,7 +976,7 @@ template <int DHP, int QT, bool VTI>
 int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
-  const float sl2 = sattn_sl2(scale);
+  const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
   const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
@@ -1077,15 +1009,11 @@ static bool sattn_use_h(int qt_variant, int dh, int Lq, int Lk, int H, int B) {
 // the kernel for one shape, with (VTI) or without the V^T pre-pass already run
 template <bool VTI>
 int launch_body(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh, float scale,
-                int dtype, hipStream_t st, int qt_variant, long ld, int fold, float lazy) {
+                int dtype, hipStream_t st, int qt_variant, long ld, float lazy) {
   // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
   //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
   //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
-  if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) {
-    // dh = 40: the scale and the running maximum ride in the MFMA (two spare contraction slots), see k_sattn_h<FOLD>
-    if (fold && dh == 40) return launch_cfg_h<48, VTI, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-    return launch_cfg_h<48, VTI, false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  }
+  if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
     return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
@@ -1123,18 +1051,17 @@ bool sattn_inline_vt(int Lk, int vti, bool use_h) { return vti == 1 || (vti == 0
 // 2 = two query tiles wherever dh <= 48, 3 = the pipelined kernel wherever it exists (dh <= 48, 64 < dh <= 80)
 // ld: row stride (elements) of q, k and v; o rows are H * dh apart.
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, int fold, float lazy) {
+                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, float lazy) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   if (ld <= 0) ld = (long)H * dh;
-  if (fold == 2) scale = PRESCALED;             // q = to_q(x) * scale * log2(e) (uce_sattn_packed_prescaled_fwd)
-  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, fold, lazy);
+  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   hipLaunchKernelGGL(k_vt, dim3(LkP / 64, (DVP + 63) / 64, B * H), dim3(256), 0, st, (const unsigned short*)v,
                      (unsigned short*)vt, H, Lk, dh, DVP, LkP, ones_row, one, ld);
   UCE_LAUNCH_CHECK();
-  return launch_body<false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, fold, lazy);
+  return launch_body<false>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy);
 }
 
 static int sattn_check(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
@@ -1156,7 +1083,7 @@ extern "C" int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const
   }
   UceProfScope ps(h, "uce_sattn_fwd", (hipStream_t)stream);
   return launch_sattn(q, k, v, h->Vt, o, B, H, Lq, Lk, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, (long)H * dh,
-                      h->sw.sattn_vti, h->sw.sattn_fold, (float)h->sw.sattn_lazy);
+                      h->sw.sattn_vti, (float)h->sw.sattn_lazy);
 }
 
 extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, float scale, int dtype,
@@ -1171,20 +1098,5 @@ extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, in
   }
   UceProfScope ps(h, "uce_sattn_packed_fwd", (hipStream_t)stream);
   return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
-                      h->sw.sattn_vti, h->sw.sattn_fold, (float)h->sw.sattn_lazy);
-}
-
-extern "C" int uce_sattn_packed_prescaled_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, int dtype,
-                                              uce_stream_t stream) {
-  const unsigned short* p = (const unsigned short*)qkv;
-  const long C = (long)H * dh;
-  if (const int rc = sattn_check(h, p, p, p, o, B, H, L, L, dh, dtype)) return rc;
-  UCE_ENTER(h);
-  if (!sattn_inline_vt(L, h->sw.sattn_vti, sattn_use_h(h->sw.sattn_qt, dh, L, L, H, B))) {
-    const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, L, dh));
-    if (rc) return rc;
-  }
-  UceProfScope ps(h, "uce_sattn_packed_prescaled_fwd", (hipStream_t)stream);
-  return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, 1.f, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
-                      h->sw.sattn_vti, 2, (float)h->sw.sattn_lazy);
+                      h->sw.sattn_vti, (float)h->sw.sattn_lazy);
 }

@@ -243,20 +243,14 @@ class UceHandle:
                                           float(scale), dt, _stream_ptr(self.device)), "uce_sattn_fwd")
         return out
 
-    def sattn_packed(self, qkv: torch.Tensor, heads: int, scale: Optional[float] = None, prescaled: bool = False) -> torch.Tensor:
-        """Self-attention on a packed projection qkv [B, L, 3 * C] (q | k | v columns) through uce_sattn_packed_fwd -> [B, L, C].
-        `prescaled`: the q columns already hold to_q(x) * scale * log2(e) (`linear(..., col_scale=, n_scaled=)`):
-        uce_sattn_packed_prescaled_fwd."""
+    def sattn_packed(self, qkv: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+        """Self-attention on a packed projection qkv [B, L, 3 * C] (q | k | v columns) through uce_sattn_packed_fwd -> [B, L, C]."""
         B, Lq, C3 = qkv.shape
         Cc = C3 // 3
         dh = Cc // heads
+        scale = dh ** -0.5 if scale is None else scale
         dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[qkv.dtype]
         out = torch.empty(B, Lq, Cc, dtype=qkv.dtype, device=qkv.device)
-        if prescaled:
-            _lib.check(self.lib.uce_sattn_packed_prescaled_fwd(self._h, _ptr(qkv), _ptr(out), B, heads, Lq, dh, dt,
-                                                               _stream_ptr(self.device)), "uce_sattn_packed_prescaled_fwd")
-            return out
-        scale = dh ** -0.5 if scale is None else scale
         _lib.check(self.lib.uce_sattn_packed_fwd(self._h, _ptr(qkv), _ptr(out), B, heads, Lq, dh, float(scale), dt,
                                                  _stream_ptr(self.device)), "uce_sattn_packed_fwd")
         return out
@@ -399,12 +393,11 @@ class UceHandle:
 
     def linear(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                residual: Optional[torch.Tensor] = None, geglu: bool = False, out: Optional[torch.Tensor] = None,
-               col_scale: float = 1.0, n_scaled: int = 0, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+               x2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`x @ weight.T (+ bias) (+ residual)` over the last dim of x through uce_linear_fwd (16-bit, f32 accumulate); with
         `geglu`, weight / bias are the interleaved rows of a GEGLU projection (sd.unet.geglu_interleave) and the result is
         `hidden * gelu(gate)` with half as many columns.  x / residual / out may be row-strided 2-D views (last dim
-        contiguous): slices of wider tensors are read and written in place.  `n_scaled` > 0: the first n_scaled output
-        columns times `col_scale` on the f32 accumulators (uce_linear_colscale_fwd).  `x2` [..., K2]: the layer applied to
+        contiguous): slices of wider tensors are read and written in place.  `x2` [..., K2]: the layer applied to
         torch.cat([x, x2], dim=-1) without the concatenation (uce_linear_cat_fwd; weight [N, K + K2])."""
         if x2 is not None:
             K1, K2 = x.shape[-1], x2.shape[-1]
@@ -443,11 +436,6 @@ class UceHandle:
             y, ldy = out, (out.stride(0) if out.dim() == 2 else n_out)
         r2, ldr = (None, 0) if residual is None else rows2d(residual, N)
         w = weight if weight.is_contiguous() else weight.contiguous()
-        if n_scaled:
-            _lib.check(self.lib.uce_linear_colscale_fwd(self._h, _ptr(x2), ldx, _ptr(w), _ptr(bias), _ptr(r2), ldr, _ptr(y), ldy, M, N,
-                                                        K, _lib.EPILOGUE_GEGLU if geglu else _lib.EPILOGUE_NONE, dt, float(col_scale),
-                                                        int(n_scaled), _stream_ptr(self.device)), "uce_linear_colscale_fwd")
-            return y
         _lib.check(self.lib.uce_linear_fwd(self._h, _ptr(x2), ldx, _ptr(w), _ptr(bias), _ptr(r2), ldr, _ptr(y), ldy, M, N, K,
                                            _lib.EPILOGUE_GEGLU if geglu else _lib.EPILOGUE_NONE, dt, _stream_ptr(self.device)),
                    "uce_linear_fwd")
