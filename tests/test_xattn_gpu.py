@@ -99,10 +99,14 @@ def test_xattn_shapes(H, B, H_, Lq, Lk, dh, dtype):
     (2, 8, 256, 77, 160, torch.bfloat16),
     (16, 4, 70, 33, 160, torch.float16),      # f16, two key tiles only
     (3, 8, 64, 1, 40, torch.bfloat16),        # a single key: O == V
+    (2, 10, 1000, 77, 64, torch.bfloat16),    # dh = 64 (SD-2.x / SDXL): five heads per column group, ten waves; two groups
+    (8, 5, 333, 33, 64, torch.bfloat16),      # one group, XCD remap, two key tiles
+    (3, 20, 130, 80, 64, torch.float16),      # four groups, 80 keys, f16
+    (2, 10, 64, 1, 64, torch.bfloat16),       # a single key
 ])
 def test_xattn_group_kernel_forced(H, variant, B, H_, Lq, Lk, dh, dtype):
     """The 640-byte column-group kernel (default only at generation-batch sizes) forced at every size: its 16-wave
-    (variant 2) and 8-wave (variant 3) dh = 40 forms, dh = 80 / 160, ragged tiles, the XCD remap, both dtypes."""
+    (variant 2) and 8-wave (variant 3) dh = 40 forms, dh = 64 / 80 / 160, ragged tiles, the XCD remap, both dtypes."""
     import os
     g = torch.Generator().manual_seed(Lq * 11 + dh + B)
     C = H_ * dh

@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Group kernel (the default for dh in {40, 80, 160}, i.e. SD-1.x): one workgroup = one batch sample x one
-// 320-channel column group (8 / 4 / 2 heads = 640 bytes of every [B, L, C] row = five whole 128-byte lines) x a run
+// Group kernel (the default for dh in {40, 80, 160}, i.e. SD-1.x, and dh = 64, i.e. SD-2.x / SDXL): one workgroup = one batch sample x
+// one 320-channel column group (8 / 5 / 4 / 2 heads = 640 bytes of every [B, L, C] row = five whole 128-byte lines) x a run
 // of consecutive query tiles.  k_xattn gives each (batch, head) its own workgroup, so the 80 / 160 / 320 bytes a
 // head owns of a row are fetched - and the partial lines of O written - by different workgroups on different XCDs
 // (2.6 L2 fills per line at dh = 40: 0.33 of the HBM roofline).  Here every byte of Q is loaded exactly once with
@@ -590,6 +590,7 @@ int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, in
       if (variant == 3) return launch_group<40, 8>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);
       return launch_group<40, 16>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);
     }
+    if (big && dh == 64) return launch_group<64, 10>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);   // SD-2.x / SDXL: 5 heads per group
     if (big && dh == 80) return launch_group<80, 8>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);
     if (big && dh == 160) return launch_group<160, 4>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);
   }
