@@ -39,8 +39,11 @@ def handle(**env):
                 os.environ[k] = v
 
 
+PROBE_B = int(os.environ.get("UCE_PROBE_B", "32"))      # CFG batch (32 = 16 prompts per call; 128 = the bench's 64)
+
+
 def gemm():
-    B = 32
+    B = PROBE_B
     shapes = []
     for hw, C in ((4096, 320), (1024, 640), (256, 1280), (64, 1280)):
         M = B * hw
@@ -72,10 +75,11 @@ def gemm():
 
 
 def conv():
-    B = 32
+    B = PROBE_B
     cases = [(B, 320, 320, 64, 64, 1), (B, 640, 640, 32, 32, 1), (B, 1280, 1280, 16, 16, 1), (B, 2560, 1280, 16, 16, 1),
              (B, 1280, 1280, 8, 8, 1), (B, 2560, 1280, 8, 8, 1), (B, 1920, 640, 32, 32, 1), (B, 960, 320, 64, 64, 1),
-             (B, 320, 320, 64, 64, 2), (B, 640, 640, 32, 32, 2), (B, 1280, 1280, 16, 16, 2)]
+             (B, 320, 320, 64, 64, 2), (B, 640, 640, 32, 32, 2), (B, 1280, 1280, 16, 16, 2),
+             (B, 640, 320, 64, 64, 1), (B, 320, 640, 32, 32, 1), (B, 1280, 640, 32, 32, 1), (B, 640, 1280, 16, 16, 1)]
     H0 = E.UceHandle.get("cuda:0")
     for N, Cin, Cout, Hh, Ww, stride in cases:
         x = torch.randn(N, Cin, Hh, Ww, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
