@@ -412,3 +412,52 @@ def test_groupnorm_of_a_concatenation_that_is_never_written(H, N, C1, C2, Hh, Ww
         with pytest.raises(L.UceError):                    # C1 = 4 is not a whole octet
             H.groupnorm_nhwc(x[:, :4].contiguous(memory_format=torch.channels_last), w[:C2 + 4].contiguous(), b[:C2 + 4].contiguous(),
                              1, 1e-5, True, None, x2=x2)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,dtype,stride,up,bias,res", [
+    (2, 320, 320, 64, 64, torch.bfloat16, 1, False, True, True),      # the resnet convolutions of the 64 x 64 level, BN = 320
+    (3, 64, 640, 12, 10, torch.bfloat16, 1, False, True, True),       # ragged pixel tiles (360 pixels), one k-tile per tap
+    (2, 192, 1280, 20, 14, torch.float16, 1, False, False, True),     # f16, three k-tiles per tap, four channel tiles, no bias
+    (2, 128, 256, 16, 16, torch.bfloat16, 1, False, True, False),     # BN = 256 (the VAE's widths): 64 tiles per wave, all in AGPRs
+    (1, 512, 512, 24, 24, torch.bfloat16, 1, False, True, True),
+    (2, 320, 320, 32, 32, torch.bfloat16, 2, False, True, False),     # Downsample2D: stride 2
+    (1, 64, 320, 10, 6, torch.float16, 2, False, True, True),         # stride 2, ragged, residual
+    (2, 640, 640, 16, 16, torch.bfloat16, 1, True, True, False),      # Upsample2D: the 2x nearest upsample fused into the taps
+])
+def test_conv3x3_one_wave_per_simd_form(N, Cin, Cout, Hh, Ww, dtype, stride, up, bias, res):
+    """k_conv3x3_w1 (UCE_CONV_W1=2: wherever the shape allows - 4 waves, 128 x 160 / 128 x 128 wave tiles, accumulators pinned in
+    AGPRs / VGPRs by inline-asm MFMAs, DMAs and fragment reads issued from inside the MFMA stream) against torch in fp64, twice
+    for bit-repeatability, and against the 8-wave form on the same inputs."""
+    import os
+    from uce_amd import edit as E
+    old = os.environ.get("UCE_CONV_W1")
+    os.environ["UCE_CONV_W1"] = "2"
+    try:
+        Hv = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_CONV_W1"]
+        else:
+            os.environ["UCE_CONV_W1"] = old
+    g = torch.Generator().manual_seed(Cin + Cout + Hh + stride)
+    cl = lambda t: t.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    x = cl(torch.randn(N, Cin, Hh, Ww, generator=g))
+    w = cl(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g).to(dtype).cuda() if bias else None
+    Ho, Wo = (2 * Hh, 2 * Ww) if up else (Hh // stride, Ww // stride)
+    r = cl(torch.randn(N, Cout, Ho, Wo, generator=g)) if res else None
+    try:
+        y = Hv.conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r)
+        again = Hv.conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r)
+        torch.cuda.synchronize()
+    finally:
+        Hv.close()
+    xin = F.interpolate(x.double(), scale_factor=2.0, mode="nearest") if up else x.double()
+    ref = F.conv2d(xin, w.double(), None if b is None else b.double(), stride=stride, padding=1)
+    if res:
+        ref = ref + r.double()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert torch.equal(y, again)
+    other = E.UceHandle.get("cuda:0").conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r)      # the 8-wave form
+    assert O.rel_fro(y.double().cpu(), other.double().cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)

@@ -87,9 +87,17 @@ def conv():
         b = torch.randn(Cout, device="cuda").bfloat16()
         Ho, Wo = Hh // stride, Ww // stride
         ent = {"N": N, "Cin": Cin, "Cout": Cout, "H": Hh, "W": Ww, "stride": stride, "gflop": 2e-9 * N * Ho * Wo * 9 * Cin * Cout}
-        ent["miopen_us"] = timeit(lambda: F.conv2d(x, w, b, stride=stride, padding=1), 5)
+        fast = os.environ.get("UCE_PROBE_FAST") == "1"          # own forms only (MIOpen's first call per shape searches for seconds)
+        if not fast:
+            ent["miopen_us"] = timeit(lambda: F.conv2d(x, w, b, stride=stride, padding=1), 5)
         ent["rule_us"] = timeit(lambda: H0.conv3x3_igemm(x, w, b, stride=stride))
-        if stride == 1:
+        Hw = handle(UCE_CONV_W1=2)                               # the one-wave-per-SIMD form (uce_conv_w1.hip)
+        ent["w1_us"] = timeit(lambda: Hw.conv3x3_igemm(x, w, b, stride=stride))
+        ent["rule2_us"] = timeit(lambda: H0.conv3x3_igemm(x, w, b, stride=stride))
+        ent["w1_TFs"] = ent["gflop"] / ent["w1_us"] * 1e-3
+        torch.cuda.synchronize()
+        Hw.close()
+        if stride == 1 and not fast:
             wmat = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
             cols = torch.empty(N * Hh * Ww, 9 * Cin, device="cuda", dtype=torch.bfloat16)
             y = torch.empty(N * Hh * Ww, Cout, device="cuda", dtype=torch.bfloat16)
@@ -104,7 +112,7 @@ def conv():
                 torch.addmm(b, cols, wmat.t(), out=y)
             ent["im2col_own_gemm_us"] = timeit(im2col_own)
             ent["im2col_lib_gemm_us"] = timeit(im2col_lib)
-        for tile in (256320, 128320, 256256, 128128, 64256320, 64128320, 64256256):
+        for tile in (() if fast else (256320, 128320, 256256, 128128, 64256320, 64128320, 64256256)):
             if Cout % (tile % 1000):
                 continue
             Hv = handle(UCE_CONV_TILE=tile)

@@ -73,6 +73,8 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       1: always inline | 2: always the pre-pass
 //   UCE_SATTN_LAZY      self-attention: the running maximum of the online softmax is raised only when a key tile's maximum exceeds
 //                       it by more than this many powers of two (default 8: P <= 256; 0: exact running maximum, rescale whenever it moves)
+//   UCE_CONV_W1         one-wave-per-SIMD convolution (uce_conv_w1.hip: 4 waves, 128 x 160 / 128 x 128 wave tiles, accumulators pinned in
+//                       AGPRs): 1 (default) = where a layer gives every CU a 256-pixel tile | 2 = wherever the shape allows | 0 = off
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
 //   UCE_EDIT_FUSED      uce_edit with at most 128 concepts (default 0: measured 62-64 us at 50 concepts against 64-66 for either one-launch
 //                       form - the update phase is bound by its weight traffic, not by the launch boundary or the MFMA type): 2 = ONE launch (projection, small-system chain, update on split-bf16 MFMAs:
@@ -83,7 +85,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy;
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy, conv_w1;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -195,6 +197,8 @@ struct UceProfScope {
 int uce_ensure(uce_ctx* h, int d, int n);
 // uce_conv_dma.hip: 1 = launched (*rc = status), 0 = shape not taken by the direct-to-LDS form
 // (the caller decides by UceSwitches::conv_dma whether to ask)
+int launch_conv_w1(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
+                   hipStream_t st, int* rc, int sd, const void* res, int mode);
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
                     int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0, int wide = 1);
 
