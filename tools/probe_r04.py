@@ -49,7 +49,7 @@ def gemm():
         M = B * hw
         shapes += [(M, C, C, "proj"), (M, 3 * C, C, "qkv"), (M, 8 * C, C, "ff_proj"), (M, C, 4 * C, "ff_out")]
     shapes += [(32, 17920, 1280, "temb_cat"), (B * 77, 320, 768, "ctx_kv")]
-    H0 = E.UceHandle.get("cuda:0")
+    H0 = handle(UCE_GEMM_W1=0)
     for M, N, K, tag in shapes:
         x = torch.randn(M, K, device="cuda").bfloat16()
         w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
@@ -59,10 +59,16 @@ def gemm():
         ent["torch_us"] = timeit(lambda: F.linear(x, w, b))
         ent["own_us"] = timeit(lambda: H0.linear(x, w, b))
         ent["own_res_us"] = timeit(lambda: H0.linear(x, w, b, r))
+        Hw = handle(UCE_GEMM_W1=2)                               # the one-wave-per-SIMD kernel (uce_conv_w1.hip, one tap)
+        ent["w1_us"] = timeit(lambda: Hw.linear(x, w, b))
+        ent["w1_res_us"] = timeit(lambda: Hw.linear(x, w, b, r))
+        ent["own2_us"] = timeit(lambda: H0.linear(x, w, b))
+        torch.cuda.synchronize()
+        Hw.close()
         if tag == "ff_proj":
             ent["torch_geglu_us"] = timeit(lambda: H0.geglu(F.linear(x, w, b)))
             ent["own_geglu_us"] = timeit(lambda: H0.linear(x, w, b, geglu=True))
-        for tile in (256320, 128320, 256256, 2128320, 3128256, 64256320, 64256256, 64128320):
+        for tile in (() if os.environ.get("UCE_PROBE_FAST") == "1" else (256320, 128320, 256256, 2128320, 3128256, 64256320, 64256256, 64128320)):
             Hv = handle(UCE_GEMM_TILE=tile)
             ent[f"t{tile}_us"] = timeit(lambda: Hv.linear(x, w, b))
             if tag == "ff_proj":
@@ -80,7 +86,10 @@ def conv():
              (B, 1280, 1280, 8, 8, 1), (B, 2560, 1280, 8, 8, 1), (B, 1920, 640, 32, 32, 1), (B, 960, 320, 64, 64, 1),
              (B, 320, 320, 64, 64, 2), (B, 640, 640, 32, 32, 2), (B, 1280, 1280, 16, 16, 2),
              (B, 640, 320, 64, 64, 1), (B, 320, 640, 32, 32, 1), (B, 1280, 640, 32, 32, 1), (B, 640, 1280, 16, 16, 1)]
-    H0 = E.UceHandle.get("cuda:0")
+    if os.environ.get("UCE_PROBE_VAE") == "1":                 # the VAE decoder's layers at a decode batch of 16 images
+        cases = [(16, 512, 512, 64, 64, 1), (16, 512, 512, 128, 128, 1), (16, 512, 256, 256, 256, 1), (16, 256, 256, 256, 256, 1),
+                 (8, 256, 128, 512, 512, 1)]
+    H0 = handle(UCE_CONV_W1=0)                                   # the 8-wave forms: the fixed reference of every row
     for N, Cin, Cout, Hh, Ww, stride in cases:
         x = torch.randn(N, Cin, Hh, Ww, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
         w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * (9 * Cin) ** -0.5).bfloat16().contiguous(memory_format=torch.channels_last)
@@ -91,7 +100,7 @@ def conv():
         if not fast:
             ent["miopen_us"] = timeit(lambda: F.conv2d(x, w, b, stride=stride, padding=1), 5)
         ent["rule_us"] = timeit(lambda: H0.conv3x3_igemm(x, w, b, stride=stride))
-        Hw = handle(UCE_CONV_W1=2)                               # the one-wave-per-SIMD form (uce_conv_w1.hip)
+        Hw = handle(UCE_CONV_W1=2)                               # the one-wave-per-SIMD form (uce_conv_w1.hip) wherever it exists
         ent["w1_us"] = timeit(lambda: Hw.conv3x3_igemm(x, w, b, stride=stride))
         ent["rule2_us"] = timeit(lambda: H0.conv3x3_igemm(x, w, b, stride=stride))
         ent["w1_TFs"] = ent["gflop"] / ent["w1_us"] * 1e-3

@@ -75,6 +75,8 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       it by more than this many powers of two (default 8: P <= 256; 0: exact running maximum, rescale whenever it moves)
 //   UCE_CONV_W1         one-wave-per-SIMD convolution (uce_conv_w1.hip: 4 waves, 128 x 160 / 128 x 128 wave tiles, accumulators pinned in
 //                       AGPRs): 1 (default) = where a layer gives every CU a 256-pixel tile | 2 = wherever the shape allows | 0 = off
+//   UCE_GEMM_W1         the same kernel with one tap for uce_linear_fwd's plain epilogue on contiguous rows: 0 = off | 1 = compute-bound
+//                       shapes that fill the chip (K >= 640, >= 256 tiles) | 2 = wherever the shape allows
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
 //   UCE_EDIT_FUSED      uce_edit with at most 128 concepts (default 0: measured 62-64 us at 50 concepts against 64-66 for either one-launch
 //                       form - the update phase is bound by its weight traffic, not by the launch boundary or the MFMA type): 2 = ONE launch (projection, small-system chain, update on split-bf16 MFMAs:
@@ -85,7 +87,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy, conv_w1;
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy, conv_w1, gemm_w1;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -199,6 +201,8 @@ int uce_ensure(uce_ctx* h, int d, int n);
 // (the caller decides by UceSwitches::conv_dma whether to ask)
 int launch_conv_w1(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
                    hipStream_t st, int* rc, int sd, const void* res, int mode);
+int launch_linear_w1(const void* x, const void* w, const void* bias, const void* res, void* y, long M, int N, int K, int dtype,
+                     hipStream_t st, int* rc, int mode);
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
                     int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0, int wide = 1);
 

@@ -62,7 +62,9 @@ constexpr int W1_NA = W1_BM / 8 / 4;                 // A DMA instructions per w
 template <int TNW>
 constexpr size_t w1_smem() { return (size_t)2 * (W1_BM + 32 * TNW) * W1_ROWB; }
 
-template <int TNW, bool F16>
+// TAPS: 9 = the 3 x 3 convolution; 1 = its centre tap alone on a 1 x 1 "image" per row, i.e. a linear layer y = x Wt^T (+ bias)
+// (+ residual) over M contiguous rows of Cin columns (uce_linear_fwd sends its compute-bound shapes here: launch_linear_w1)
+template <int TNW, bool F16, int TAPS>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                        const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                        long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
   const int n0 = (int)(tile % ntiles) * BN;
   const int Hi = H * sd, Wi = W * sd;                // the image the taps index (before the >> up of the fused upsample)
   const int Hs = Hi >> up, Ws = Wi >> up;
-  const int cch = Cin / W1_BK, NK = 9 * cch;
-  const long K = 9L * Cin;
+  const int cch = Cin / W1_BK, NK = TAPS * cch;
+  const long K = (long)TAPS * Cin;
 
   // ---- staging coordinates (k-tile invariant): a wave instruction fills 8 rows x 128 B, lane = (row r, 16-byte piece p); the bank
   // swizzle - row R keeps source piece p ^ ((R >> 1) & 7) in slot p - is applied to the SOURCE address
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
   auto dma = [&](int st, int kt, int i) __attribute__((always_inline)) {
     unsigned char* sbase = smem + st * STAGE;
     if (i < W1_NA) {
-      const int tap = kt / cch, c0 = (kt - tap * cch) * W1_BK;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int tap = TAPS == 1 ? 0 : kt / cch, c0 = (kt - tap * cch) * W1_BK;
+      const int dy = TAPS == 1 ? 0 : tap / 3 - 1, dx = TAPS == 1 ? 0 : tap - (tap / 3) * 3 - 1;
       const int yy = (a_yx[i] >> 16) + dy, xx = (a_yx[i] & 0xffff) + dx;
       const bool ok = (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
       const unsigned off = a_base[i] + (unsigned)((((yy >> up) * Ws + (xx >> up)) * Cin + c0) * 2);
@@ -221,36 +223,45 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // every wave is past its last MFMA on LDS-fed registers: the ring is free
 
-  // ---- epilogue: 16-pixel slabs through this wave's LDS region.  acc[a][b] = channels n0 + wn BN/2 + 16 a + 4 lq + {0..3} of pixel
-  // m0 + wm 128 + 16 b + l16.  Slab row = one pixel, BN/2 channels (+ 16 bytes: rows two bank groups apart).
+  // ---- epilogue: 64-pixel slabs (four pixel tiles per pass, two passes) through this wave's LDS region.  acc[a][b] = channels
+  // n0 + wn BN/2 + 16 a + 4 lq + {0..3} of pixel m0 + wm 128 + 16 b + l16.  Slab row = one pixel, BN/2 channels (+ 16 bytes: rows
+  // two bank groups apart); the rows leave as 16-byte pieces, consecutive lanes on consecutive pieces of a row.
   constexpr int SROW = BN + 16;                      // bytes per slab row (BN / 2 channels of 2 bytes)
   constexpr int CPR = BN / 16;                       // 16-byte pieces per slab row
-  unsigned char* slab = smem + w * 16 * SROW;
+  constexpr int PB = 4;                              // pixel tiles per pass
+  unsigned char* slab = smem + w * (16 * PB) * SROW;
   const int ncol0 = n0 + wn * (BN / 2);
+  float bv[10][4];
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int a = 0; a < TNW; ++a) {
+    bv[a][0] = bv[a][1] = bv[a][2] = bv[a][3] = 0.f;
+    if (bias) {
+      const uint2_t b2 = *(const uint2_t*)(bias + ncol0 + 16 * a + 4 * lq);
+      bv[a][0] = w1_tof<F16>((unsigned short)(b2[0] & 0xffffu));
+      bv[a][1] = w1_tof<F16>((unsigned short)(b2[0] >> 16));
+      bv[a][2] = w1_tof<F16>((unsigned short)(b2[1] & 0xffffu));
+      bv[a][3] = w1_tof<F16>((unsigned short)(b2[1] >> 16));
+    }
+  }
 #pragma unroll
-    for (int a = 0; a < TNW; ++a) {
-      const int n = ncol0 + 16 * a + 4 * lq;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) {
-        const uint2_t b2 = *(const uint2_t*)(bias + n);
-        bv[0] = w1_tof<F16>((unsigned short)(b2[0] & 0xffffu));
-        bv[1] = w1_tof<F16>((unsigned short)(b2[0] >> 16));
-        bv[2] = w1_tof<F16>((unsigned short)(b2[1] & 0xffffu));
-        bv[3] = w1_tof<F16>((unsigned short)(b2[1] >> 16));
-      }
-      *(uint2_t*)(slab + l16 * SROW + (16 * a + 4 * lq) * 2) =
-          (uint2_t){w1_pack2<F16>(acc[a][b][0] + bv[0], acc[a][b][1] + bv[1]), w1_pack2<F16>(acc[a][b][2] + bv[2], acc[a][b][3] + bv[3])};
+  for (int pb = 0; pb < 8 / PB; ++pb) {
+#pragma unroll
+    for (int bb = 0; bb < PB; ++bb) {
+      const int b = pb * PB + bb;
+#pragma unroll
+      for (int a = 0; a < TNW; ++a)
+        *(uint2_t*)(slab + (16 * bb + l16) * SROW + (16 * a + 4 * lq) * 2) =
+            (uint2_t){w1_pack2<F16>(acc[a][b][0] + bv[a][0], acc[a][b][1] + bv[a][1]),
+                      w1_pack2<F16>(acc[a][b][2] + bv[a][2], acc[a][b][3] + bv[a][3])};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const long mrow0 = m0 + wm * 128 + 16 * b;
+    const long mrow0 = m0 + wm * 128 + 16 * PB * pb;
 #pragma unroll
-    for (int it = 0; it < (16 * CPR + 63) / 64; ++it) {
+    for (int it = 0; it < (16 * PB * CPR) / 64; ++it) {
       const int idx = it * 64 + lane;
       const int row = idx / CPR, ch = idx - row * CPR;
       const long m = mrow0 + row;
-      if (idx < 16 * CPR && m < M) {
+      if (m < M) {
         uint4_t v = *(const uint4_t*)(slab + row * SROW + ch * 16);
         const int n = ncol0 + ch * 8;
         if (Rs) {
@@ -260,11 +271,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
         *(uint4_t*)(Y + m * Cout + n) = v;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is read before the next pixel tile overwrites it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is read before the next pass overwrites it
   }
 }
 
-template <int TNW>
+template <int TNW, int TAPS>
 int launch_w1(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
               hipStream_t st, int sd, const void* res) {
   constexpr int BN = 32 * TNW;
@@ -275,16 +286,16 @@ int launch_w1(const void* x, const void* w, const void* bias, void* y, long M, i
   const size_t smem = w1_smem<TNW>();
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_w1<TNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_w1<TNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_w1<TNW, false, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_w1<TNW, true, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_conv3x3_w1<TNW, true>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x, (const unsigned short*)w,
+    hipLaunchKernelGGL((k_conv3x3_w1<TNW, true, TAPS>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x, (const unsigned short*)w,
                        (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up, (int)mtiles, ntiles, sd,
                        (const unsigned short*)res);
   else
-    hipLaunchKernelGGL((k_conv3x3_w1<TNW, false>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x, (const unsigned short*)w,
+    hipLaunchKernelGGL((k_conv3x3_w1<TNW, false, TAPS>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x, (const unsigned short*)w,
                        (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up, (int)mtiles, ntiles, sd,
                        (const unsigned short*)res);
   UCE_LAUNCH_CHECK();
@@ -303,12 +314,30 @@ int launch_conv_w1(const void* x, const void* w, const void* bias, void* y, long
   const int bn = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : 0;
   if (!bn) return 0;
   const long tiles = ((M + W1_BM - 1) / W1_BM) * (Cout / bn);
-  // measured at 64 prompts per call (tools/probe_r04.py conv, UCE_PROBE_B=128; us, 8-wave form | this one): 640 -> 640 @ 32^2 775 | 729,
-  // 1280 -> 1280 @ 16^2 743 | 671, 2560 -> 1280 1458 | 1311, 1920 -> 640 @ 32^2 2256 | 2090, 960 -> 320 @ 64^2 2383 | 2259,
-  // 320 -> 320 @ 64^2 858 | 865; with fewer than 256 tiles (the 8 x 8 level: 229 | 304) and for a stride-2 layer with ONE channel
-  // tile (320 -> 320: 225 | 241) the 8-wave form stays
-  if (mode == 1 && (tiles < 256 || (sd == 2 && Cout == bn))) return 0;
-  *rc = bn == 320 ? launch_w1<10>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res)
-                  : launch_w1<8>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res);
+  // measured at 64 prompts per call (tools/probe_r04.py conv, UCE_PROBE_B=128, one box; us, 8-wave form | this one): 320 -> 320 @ 64^2
+  // 903 | 853, 640 -> 640 @ 32^2 819 | 757, 1280 -> 1280 @ 16^2 780 | 704, 2560 -> 1280 1532 | 1410, 1920 -> 640 @ 32^2 2364 | 2175,
+  // 960 -> 320 @ 64^2 2484 | 2337, stride 2: 320 -> 320 234 | 231, 640 -> 640 205 | 186; with fewer than 256 tiles (the 8 x 8 level: 246 | 309,
+  // 1280 -> 1280 stride 2: 247 | 311) the 8-wave form stays
+  if (mode == 1 && tiles < 256) return 0;
+  *rc = bn == 320 ? launch_w1<10, 9>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res)
+                  : launch_w1<8, 9>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res);
+  return 1;
+}
+
+// The linear layer y [M, N] = x [M, K] w [N, K]^T (+ bias) (+ residual) on the same kernel (one tap, one pixel per "image"): contiguous
+// rows only (ldx = K, ldy = ldr = N).  0: not taken; 1: launched.  mode (UCE_GEMM_W1): 1 = the compute-bound shapes that fill the chip
+// (K >= 640, at least 256 tiles), 2 = wherever the shape allows.
+int launch_linear_w1(const void* x, const void* w, const void* bias, const void* res, void* y, long M, int N, int K, int dtype,
+                     hipStream_t st, int* rc, int mode) {
+  *rc = UCE_OK;
+  if (mode <= 0 || K % W1_BK || N % 8) return 0;
+  if (((uintptr_t)y & 15) || ((uintptr_t)res & 15) || ((uintptr_t)bias & 7) || ((uintptr_t)x & 15)) return 0;
+  const int bn = N % 320 == 0 ? 320 : N % 256 == 0 ? 256 : 0;
+  if (!bn) return 0;
+  const long tiles = ((M + W1_BM - 1) / W1_BM) * (N / bn);
+  if (mode == 1 && (tiles < 256 || K < 640)) return 0;
+  if (M * (long)K * 2 >= 0x7fffffffL) return 0;
+  *rc = bn == 320 ? launch_w1<10, 1>(x, w, bias, y, M, 1, 1, K, N, 0, dtype, st, 1, res)
+                  : launch_w1<8, 1>(x, w, bias, y, M, 1, 1, K, N, 0, dtype, st, 1, res);
   return 1;
 }
