@@ -24,5 +24,6 @@ g=d.get("generate",{}); print("generate", g.get("value"), g.get("prompts_per_une
 PY
 bash tools/prof_generate.sh $tag/gen 20 64 > $out/gen_prof.log 2>&1; tail -22 $out/gen_prof.log | cut -c1-150
 UCE_BENCH_SAME_DEVICE=1 UCE_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --gen-images 32 --gen-batch 16 --no-configs > $out/bench_n2_gloo_dryrun.json 2> $out/bench_n2_gloo_dryrun.log; echo "n2 rc=$?"; head -c 400 $out/bench_n2_gloo_dryrun.json
+bash tools/ab_gen.sh $tag/ab "default" "conv_w1_off UCE_CONV_W1=0" "default2"
 find $out -name "*counter_collection.csv" -size +3M -delete
 echo "total seconds=$(( $(date +%s) - start ))"; ls $out | head -80
