@@ -717,10 +717,11 @@ def main() -> None:
     ap.add_argument("--workload", default="sd14_erase50", choices=sorted(WORKLOADS))
     ap.add_argument("--algo", default="auto", choices=["auto", "primal", "dual"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gen-images", type=int, default=128,
+    ap.add_argument("--gen-images", type=int, default=256,
                     help="images per rank for the secondary images/s figure (0 = skip)")
-    ap.add_argument("--gen-batch", type=int, default=64, help="prompts denoised per U-Net call (measured on an MI355X: 16 -> 6.95, "
-                    "32 -> 7.75, 64 -> 8.17 images/s; the CLI keeps the reference's row-by-row default, reported as `rowwise`)")
+    ap.add_argument("--gen-batch", type=int, default=128, help="prompts denoised per U-Net call (measured on one MI355X with the final "
+                    "kernels of round 4: 64 -> 9.30, 96 -> 9.32, 128 -> 9.54 images/s; round 3: 16 -> 6.95, 32 -> 7.75; the CLI keeps the "
+                    "reference's row-by-row default, reported as `rowwise`)")
     ap.add_argument("--gen-rowwise", type=int, default=4, help="images of the row-by-row (one prompt per call) figure; 0 = skip")
     ap.add_argument("--gen-steps", type=int, default=50)
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs")
@@ -770,7 +771,9 @@ def main() -> None:
     from uce_amd import cli
     H = E.UceHandle.get(device)
     algo = cli.ALGO_IDS[args.algo]
-    gb = 2 * max(1, min(args.gen_batch, max(args.gen_images, 1)))
+    # CFG batch of the attention legs: that of the generation leg, capped at 128 - the batch the PMC passes of profiles/ were
+    # collected at (tools/prof_round.sh), so every shape keeps its traffic entry
+    gb = min(128, 2 * max(1, min(args.gen_batch, max(args.gen_images, 1))))
     if args.only == "xattn":            # fixed launch counts for the PMC passes (tools/pmc_fold.py splits by order)
         print(json.dumps(xattn_leg(device, (2, gb), iters=4)), flush=True)
         return
