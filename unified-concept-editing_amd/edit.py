@@ -400,6 +400,10 @@ class UceHandle:
         contiguous): slices of wider tensors are read and written in place.  `x2` [..., K2]: the layer applied to
         torch.cat([x, x2], dim=-1) without the concatenation (uce_linear_cat_fwd; weight [N, K + K2])."""
         if x2 is not None:
+            if geglu or out is not None:
+                raise ValueError("the two-source form has the plain epilogue and allocates its output")
+            if x2.shape[:-1] != x.shape[:-1] or x2.dtype != x.dtype:
+                raise ValueError("x and x2 must agree in every dimension but the last, and in dtype")
             K1, K2 = x.shape[-1], x2.shape[-1]
             N = weight.shape[0]
             dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
