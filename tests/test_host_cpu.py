@@ -397,3 +397,33 @@ def test_conv_dispatch_rule_and_padded_narrow_weights():
         conv.weight.mul_(2.0)
     w8b, _ = U._padded_out_channels(conv)
     assert w8b is not w8 and torch.equal(w8b[:3], conv.weight)
+
+
+@pytest.mark.parametrize("TNW", [8, 10])
+def test_one_wave_convolution_issue_schedule_and_lds_budget(TNW):
+    """CPU restatement of k_conv3x3_w1's hand-placed issue slots (csrc/uce_conv_w1.hip): in the first k-step of a tile every
+    fragment of the second k-step and every DMA of the outgoing k-tile goes out behind exactly one MFMA, no two of them behind the
+    same one; the barrier of the second k-step leaves exactly one MFMA per fragment of the next tile behind it; ring, epilogue
+    slabs and register budget fit the CU."""
+    BN = 32 * TNW
+    NMF, NFR = TNW * 8, 8 + TNW                       # MFMAs / fragment reads per k-step of 32
+    NA, NB = 256 // 8 // 4, BN // 8 // 4              # DMA instructions per wave and k-tile: A image, B image
+    PER = NA + NB
+    frag_slots = [((f + 1) * NMF) // NFR - 1 for f in range(NFR)]
+    dma_slots = [((g + 1) * NMF) // PER - 2 for g in range(PER)]
+    assert sorted(set(frag_slots)) == frag_slots and 0 <= frag_slots[0] and frag_slots[-1] == NMF - 1
+    assert sorted(set(dma_slots)) == dma_slots and 0 <= dma_slots[0] and dma_slots[-1] < NMF
+    assert not set(frag_slots) & set(dma_slots)
+    # the X fragments of the next step (needed by its first MFMAs) are requested before the W fragments
+    assert frag_slots[:8] == sorted(frag_slots[:8]) and frag_slots[7] < frag_slots[8]
+    # second k-step: barrier behind MFMA NMF - HOLD - 1, then one read of the next tile per remaining MFMA
+    HOLD = NFR
+    assert 0 < NMF - HOLD - 1 and NMF - (NMF - HOLD) == NFR
+    # LDS: two stages of (256 + BN) rows x 128 B; four 64-pixel slabs of BN / 2 channels (+ 16 B per row) inside the freed ring
+    stage = (256 + BN) * 128
+    assert 2 * stage <= 160 * 1024
+    assert 4 * 64 * (BN + 16) <= 2 * stage
+    assert (64 * (BN // 16)) % 64 == 0                # whole wave passes over a slab's 16-byte pieces
+    # registers: 8 x TNW accumulator tiles of 4; 64 tiles fill the AGPR file, the rest + double-buffered fragments are VGPRs
+    acc_vgpr = max(0, TNW * 8 - 64) * 4
+    assert min(TNW * 8, 64) * 4 == 256 and acc_vgpr + 2 * (8 + TNW) * 4 + 2 * NA + NB + 24 <= 256
