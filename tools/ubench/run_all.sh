@@ -11,4 +11,6 @@ echo "== potrf.hip (-DPK_STAMPS)" >> $out
 $HC -mllvm -amdgpu-mfma-vgpr-form -DPK_STAMPS -I include -I unified-concept-editing_amd/csrc tools/ubench/potrf.hip -o /tmp/ub_potrf && /tmp/ub_potrf >> $out 2>&1
 echo "== potrf.hip" >> $out
 $HC -mllvm -amdgpu-mfma-vgpr-form -I include -I unified-concept-editing_amd/csrc tools/ubench/potrf.hip -o /tmp/ub_potrf && /tmp/ub_potrf >> $out 2>&1
+echo "== gemm_w1.hip (one wave per SIMD: BN = 256 and BN = 320, BK = 64; accumulators in AGPRs: no -amdgpu-mfma-vgpr-form)" >> $out
+for bn in 256 320; do $HC -DBNV=$bn -DBKV=64 -DNSTV=2 tools/ubench/gemm_w1.hip -o /tmp/ub_gemm_w1 && /tmp/ub_gemm_w1 >> $out 2>&1; done
 cat $out
