@@ -428,3 +428,76 @@ def test_one_wave_convolution_issue_schedule_and_lds_budget(TNW):
     acc_vgpr = max(0, TNW * 8 - 64) * 4
     # (+ staging coordinates: 2 per A DMA, 1 per B DMA) - at least 16 VGPRs stay for addresses and epilogue temporaries
     assert min(TNW * 8, 64) * 4 == 256 and acc_vgpr + 2 * (8 + TNW) * 4 + 2 * NA + NB <= 256 - 16
+
+
+@pytest.mark.parametrize("TNW,stride,up", [(10, 1, 0), (8, 1, 0), (10, 2, 0), (8, 1, 1)])
+def test_one_wave_convolution_index_arithmetic_restated(TNW, stride, up):
+    """CPU restatement of k_conv3x3_w1's data movement (csrc/uce_conv_w1.hip), index for index: the LDS image an `buffer_load ... lds`
+    instruction leaves (lane = (row, 16-byte piece), bank swizzle on the source piece, taps outside the image as zeros), the fragment
+    a lane reads for a k-step (ONE piece offset per step, tiles at 16-row distances), the operand / result layout of
+    v_mfma_f32_16x16x32 with the weight fragment as A and the pixel fragment as B, and the accumulator -> (pixel, channel) map of the
+    epilogue - assembled into an output and compared with torch's convolution."""
+    import numpy as np
+    rng = np.random.default_rng(TNW + stride + up)
+    BN, Cin, cch = 32 * TNW, 64, 1
+    Ho, Wo = 16, 16                                    # output image: 256 pixels = one 256-pixel tile
+    Hi, Wi = Ho * stride, Wo * stride                  # the image the taps index
+    Hs, Ws = Hi >> up, Wi >> up                        # the stored image (before the fused 2x upsample)
+    X = rng.standard_normal((Hs, Ws, Cin)).astype(np.float32)
+    Wt = (rng.standard_normal((BN, 9 * Cin)) * 0.05).astype(np.float32)          # [Cout, tap * Cin + c]
+    lanes = np.arange(64)
+    acc = np.zeros((4, TNW, 8, 64, 4), np.float64)     # [wave][channel tile a][pixel tile b][lane][register]
+    for kt in range(9 * cch):
+        tap, c0 = kt // cch, (kt % cch) * 64
+        dy, dx = tap // 3 - 1, tap % 3 - 1
+        # ---- the LDS image of this k-tile: A rows 0..255 (pixels), B rows 0..BN-1 (channels), 8 slots of 8 elements
+        A = np.zeros((256, 8, 8), np.float32)
+        Bm = np.zeros((BN, 8, 8), np.float32)
+        r, p = lanes >> 3, lanes & 7
+        for w in range(4):
+            for j in range(8):                         # A DMA instructions of wave w
+                R = 8 * (4 * j + w) + r
+                c = p ^ ((R >> 1) & 7)
+                y, x = (R // Wo) * stride + dy, (R % Wo) * stride + dx
+                ok = (y >= 0) & (y < Hi) & (x >= 0) & (x < Wi)
+                for ln in lanes:
+                    if ok[ln]:
+                        A[R[ln], p[ln]] = X[y[ln] >> up, x[ln] >> up, c0 + 8 * c[ln]:c0 + 8 * c[ln] + 8]
+            for j in range(BN // 8 // 4):              # B DMA instructions
+                R = 8 * (4 * j + w) + r
+                c = p ^ ((R >> 1) & 7)
+                for ln in lanes:
+                    Bm[R[ln], p[ln]] = Wt[R[ln], kt * 64 + 8 * c[ln]:kt * 64 + 8 * c[ln] + 8]
+        # ---- two k-steps of 32: fragments and MFMAs
+        l16, lq = lanes & 15, lanes >> 4
+        key = (l16 >> 1) & 7
+        for w in range(4):
+            wm, wn = w & 1, w >> 1
+            for s in range(2):
+                po = (4 * s + lq) ^ key                # the step's ONE piece slot per lane
+                xf = np.stack([A[wm * 128 + 16 * f + l16, po] for f in range(8)])             # [8][lane][8]
+                wf = np.stack([Bm[wn * (BN // 2) + 16 * f + l16, po] for f in range(TNW)])    # [TNW][lane][8]
+                for a in range(TNW):
+                    # A operand (wf[a]): lane -> row i = lane % 16, k = 8 (lane // 16) ..; B operand (xf[b]): lane -> column j = lane % 16
+                    Am = np.zeros((16, 32))
+                    Am[l16[:, None], (8 * lq)[:, None] + np.arange(8)] = wf[a]
+                    for b in range(8):
+                        Bk = np.zeros((32, 16))
+                        Bk[(8 * lq)[:, None] + np.arange(8), l16[:, None]] = xf[b]
+                        D = Am @ Bk                     # [channel i][pixel j]
+                        # D layout: lane -> column j = lane % 16, rows i = 4 (lane // 16) + {0..3}
+                        acc[w, a, b] += D[(4 * lq)[:, None] + np.arange(4), l16[:, None]]
+    # ---- epilogue map: acc[a][b][i] = channel wn BN/2 + 16 a + 4 lq + i of pixel wm 128 + 16 b + l16
+    Y = np.zeros((256, BN))
+    l16, lq = lanes & 15, lanes >> 4
+    for w in range(4):
+        wm, wn = w & 1, w >> 1
+        for a in range(TNW):
+            for b in range(8):
+                Y[(wm * 128 + 16 * b + l16)[:, None], (wn * (BN // 2) + 16 * a + 4 * lq)[:, None] + np.arange(4)] = acc[w, a, b]
+    xin = torch.from_numpy(X).double().permute(2, 0, 1)[None]
+    if up:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2.0, mode="nearest")
+    wref = torch.from_numpy(Wt).double().view(BN, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xin, wref, None, stride=stride, padding=1)[0].permute(1, 2, 0).reshape(256, BN).numpy()
+    assert np.abs(Y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
