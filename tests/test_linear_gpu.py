@@ -67,12 +67,15 @@ def test_linear_matches_fp64(H, M, N, K, dtype, bias, res):
     assert torch.equal(y, H.linear(x, w, b, r))           # bit-repeatable
 
 
-@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128", "2128320", "3128256", "3256128", "64256320", "64256256", "64128320"])
+@pytest.mark.parametrize("tile", ["256320", "256256", "128320", "128256", "256128", "2128320", "3128256", "3256128", "64256320", "64256256", "64128320",
+                                  "9128064", "9128128"])
 @pytest.mark.parametrize("M,N,K", [(700, 960, 320), (256, 640, 96), (1500, 640, 1280)])
 def test_linear_every_tile_form_forced(tile, M, N, K):
-    """UCE_GEMM_TILE pins one tile form for every call (read at uce_create): each form - the last three are the shallow rings
-    that put two workgroups on a CU - on shapes with ragged row and column tiles, with bias + residual, and with the GEGLU
-    epilogue."""
+    """UCE_GEMM_TILE pins one tile form for every call (read at uce_create): each form - 2... / 3... / 64... are the shallow rings
+    that put two workgroups on a CU, 9... the few-tile forms with the split contraction - on shapes with ragged row and column
+    tiles, with bias + residual, and with the GEGLU epilogue."""
+    if tile.startswith("9") and K % 64:
+        pytest.skip("the few-tile forms move 128-byte k-tiles")
     Hv = _handle_with("UCE_GEMM_TILE", tile)
     g = torch.Generator().manual_seed(int(tile) + M)
     x, w = _rand((M, K), g, torch.bfloat16), _rand((N, K), g, torch.bfloat16, K ** -0.5)
@@ -396,3 +399,76 @@ def test_linear_on_the_one_wave_per_simd_kernel(M, N, K, dtype, bias, res):
     finally:
         torch.cuda.synchronize()
         Hv.close()
+
+
+# ------------------------------------------------------------------------------------ the few-tile regime (split contraction)
+
+@pytest.mark.parametrize("M,N,K,bias,res", [
+    (8192, 320, 320, True, True),          # to_out / proj_out at 64 x 64, ONE prompt per call (CFG batch 2): 128 x 64 tiles, no split
+    (8192, 960, 320, False, False),        # the packed q | k | v projection: 128 x 128 tiles
+    (8192, 320, 1280, True, True),         # ff_out at 64 x 64
+    (2048, 640, 2560, True, True),         # ff_out at 32 x 32: split 2
+    (512, 1280, 5120, True, True),         # ff_out at 16 x 16: split 4
+    (128, 1280, 1280, True, True),         # the 8 x 8 mid block: one row tile, split 10
+    (2, 1280, 320, True, False),           # the time embedding of one prompt
+    (154, 640, 768, False, False),         # to_k on the context of one prompt
+    (100, 72, 448, True, True),            # ragged everything: N not a multiple of 64, 7 k-tiles over 3 slabs
+])
+def test_linear_few_tile_forms_match_fp64_and_repeat_bit_for_bit(H, M, N, K, bias, res):
+    """Layers that cannot give every CU a 128 x 320 tile take 128 x 128 / 128 x 64 tiles and, below 200 of those, a split
+    contraction whose S slabs are summed in slab order by the last arriver (csrc/uce_splitk.h): against fp64, and twenty
+    runs give the same bits (the arrival order changes from run to run, the sum must not)."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = _rand((M, K), g, torch.bfloat16)
+    w = _rand((N, K), g, torch.bfloat16, K ** -0.5)
+    w[0, 1] += 2.0
+    b = _rand((N,), g, torch.bfloat16) if bias else None
+    r = _rand((M, N), g, torch.bfloat16) if res else None
+    y = H.linear(x, w, b, r)
+    want = x.double() @ w.double().T
+    if bias:
+        want = want + b.double()
+    if res:
+        want = want + r.double()
+    assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[torch.bfloat16]
+    for _ in range(20):
+        assert torch.equal(y, H.linear(x, w, b, r))
+
+
+def test_linear_few_tile_geglu_two_sources_and_graph_replay(H):
+    """The split forms with the GEGLU epilogue and with the two-source contraction; and a captured launch replays (the tickets
+    re-arm themselves, the slabs live in the handle)."""
+    from uce_amd.sd import unet as U
+    g = torch.Generator().manual_seed(11)
+    M, C = 512, 1280
+    x, w, b = _rand((M, C), g, torch.bfloat16), _rand((8 * C, C), g, torch.bfloat16, C ** -0.5), _rand((8 * C,), g, torch.bfloat16)
+    wi, bi = U.geglu_interleave(w, b)
+    y = H.linear(x, wi, bi, geglu=True)
+    p = x.double() @ w.double().T + b.double()
+    assert O.rel_fro(y.double().cpu(), (p[:, :4 * C] * F.gelu(p[:, 4 * C:])).cpu()) < TOL[torch.bfloat16]
+    # GEGLU at the 8 x 8 level of one prompt: split contraction under the gated epilogue
+    x8 = x[:128].contiguous()
+    y8 = H.linear(x8, wi, bi, geglu=True)
+    assert torch.equal(y8, y[:128]) or O.rel_fro(y8.double().cpu(), y[:128].double().cpu()) < 4e-3
+    # two sources (the 1 x 1 shortcut of an up block over x | skip)
+    xa, xb = _rand((512, 1280), g, torch.bfloat16), _rand((512, 640), g, torch.bfloat16)
+    ws, bs = _rand((1280, 1920), g, torch.bfloat16, 1920 ** -0.5), _rand((1280,), g, torch.bfloat16)
+    y2 = H.linear(xa, ws, bs, x2=xb)
+    want2 = torch.cat([xa, xb], 1).double() @ ws.double().T + bs.double()
+    assert O.rel_fro(y2.double().cpu(), want2.cpu()) < TOL[torch.bfloat16]
+    assert torch.equal(y2, H.linear(torch.cat([xa, xb], 1), ws, bs))          # same k-tile order, same slabs: same bits
+    # hipGraph replay
+    out = torch.empty_like(y2)
+    xc = torch.cat([xa, xb], 1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        H.linear(xc, ws, bs, out=out)                                         # (the scratch is allocated outside the capture)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            H.linear(xc, ws, bs, out=out)
+        for _ in range(3):
+            out.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, y2)

@@ -330,7 +330,8 @@ def test_conv3x3_stride2_matches_torch(H, N, Cin, Cout, Hh, Ww, dtype, res):
     assert O.rel_fro(y.double().cpu(), ref.cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
 
 
-@pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "128256", "256128", "128128", "64256320", "64128320", "64256256", "64128256"])
+@pytest.mark.parametrize("tile", ["0", "256320", "128320", "256256", "128256", "256128", "128128", "64256320", "64128320", "64256256", "64128256",
+                                  "9128064", "9128128"])
 @pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(2, 64, 1280, 12, 10), (3, 96, 256, 16, 16), (2, 192, 640, 20, 14)])
 def test_conv3x3_every_tile_form_with_residual(tile, N, Cin, Cout, Hh, Ww):
     """UCE_CONV_TILE pins the tile of the direct-to-LDS convolution: every form (where it divides Cout), with bias and the
@@ -461,3 +462,36 @@ def test_conv3x3_one_wave_per_simd_form(N, Cin, Cout, Hh, Ww, dtype, stride, up,
     assert torch.equal(y, again)
     other = E.UceHandle.get("cuda:0").conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r)      # the 8-wave form
     assert O.rel_fro(y.double().cpu(), other.double().cpu()) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,stride,up,res", [
+    (2, 320, 320, 64, 64, 1, False, True),          # ONE prompt per call (CFG batch 2): the 64 x 64 level, 128 x 64 tiles, no split
+    (2, 640, 640, 32, 32, 1, False, True),          # 32 x 32: split 2
+    (2, 1280, 1280, 16, 16, 1, False, True),        # 16 x 16: split 4
+    (2, 1280, 1280, 8, 8, 1, False, False),         # 8 x 8: one pixel tile, split 13
+    (2, 2560, 1280, 8, 8, 1, False, True),          # up block on x | skip
+    (2, 320, 320, 64, 64, 2, False, False),         # Downsample2D
+    (2, 1280, 1280, 16, 16, 2, False, False),
+    (2, 1280, 1280, 8, 8, 1, True, False),          # Upsample2D: taps gathered from the half-resolution tensor
+    (1, 512, 512, 64, 64, 1, False, True),          # the VAE decoder's mid block on one image
+    (1, 64, 72, 10, 6, 1, False, True),             # ragged pixels, Cout not a multiple of 64
+    (32, 1280, 1280, 8, 8, 1, False, True),         # the 8 x 8 level at a generation batch
+])
+def test_conv3x3_few_tile_forms_match_torch_and_repeat_bit_for_bit(H, N, Cin, Cout, Hh, Ww, stride, up, res):
+    """3x3 convolutions without 200 output tiles: 128 x 128 / 128 x 64 tiles and the 9 taps x channel chunks split over S
+    workgroups per tile (csrc/uce_splitk.h) - against F.conv2d in fp64; ten runs give the same bits."""
+    g = torch.Generator().manual_seed(Cin + Cout + Hh + stride)
+    x = torch.randn(N, Cin, Hh, Ww, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, generator=g).bfloat16().cuda()
+    Ho, Wo = (2 * Hh, 2 * Ww) if up else (Hh // stride, Ww // stride)
+    r = torch.randn(N, Cout, Ho, Wo, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last) if res else None
+    y = H.conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r)
+    xin = F.interpolate(x.double(), scale_factor=2.0, mode="nearest") if up else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), stride=stride, padding=1)
+    if res:
+        ref = ref + r.double()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert O.rel_fro(y.double().cpu(), ref.cpu()) < 6e-3
+    for _ in range(10):
+        assert torch.equal(y, H.conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r))

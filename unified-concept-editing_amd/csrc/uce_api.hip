@@ -155,6 +155,41 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems) {
   return UCE_OK;
 }
 
+int uce_ensure_sk(uce_ctx* h, size_t bytes, size_t tiles) {
+  if (bytes <= h->sk_bytes && tiles <= h->sk_tiles) return UCE_OK;
+  UCE_HIP_TRY(hipSetDevice(h->device));
+  auto retire = [&](void* p) -> int {
+    if (!p) return UCE_OK;
+    if (h->n_retired < 32) { h->retired[h->n_retired++] = p; return UCE_OK; }
+    UCE_HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(p);
+    return UCE_OK;
+  };
+  if (bytes > h->sk_bytes) {
+    size_t want = h->sk_bytes ? h->sk_bytes : (size_t)32 << 20;
+    while (want < bytes) want *= 2;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) return UCE_ENOMEM;
+    const int rc = retire(h->sk_ws);
+    if (rc != UCE_OK) return rc;
+    h->sk_ws = (float*)p;
+    h->sk_bytes = want;
+  }
+  if (tiles > h->sk_tiles) {
+    size_t want = h->sk_tiles ? h->sk_tiles : 4096;
+    while (want < tiles) want *= 2;
+    void* p = nullptr;
+    if (hipMalloc(&p, want * sizeof(unsigned)) != hipSuccess) return UCE_ENOMEM;
+    // (a blocking memset on the null stream: the tickets must be zero before the first launch on any stream reads them)
+    if (hipMemset(p, 0, want * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return UCE_EHIP; }
+    const int rc = retire(h->sk_tick);
+    if (rc != UCE_OK) return rc;
+    h->sk_tick = (unsigned*)p;
+    h->sk_tiles = want;
+  }
+  return UCE_OK;
+}
+
 constexpr size_t LA_FLAGS = 2 * 22 * 22 + 2 * 22 + 8;          // k_potrf_la: systems of up to 22 diagonal blocks
 
 static int env_int(const char* name, int dflt) {
@@ -218,6 +253,8 @@ int uce_destroy(uce_handle_t h) {
   if (h->status) (void)hipFree(h->status);
   if (h->T) (void)hipFree(h->T);
   if (h->Vt) (void)hipFree(h->Vt);
+  if (h->sk_ws) (void)hipFree(h->sk_ws);
+  if (h->sk_tick) (void)hipFree(h->sk_tick);
   for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->la_flags) (void)hipFree(h->la_flags);

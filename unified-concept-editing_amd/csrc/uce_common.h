@@ -171,7 +171,13 @@ struct uce_ctx {
   GramPrimalArgs bt_pending;
   void* Vt;       // V^T scratch of uce_sattn_fwd ([B, H, DVP, LkP] 16-bit elements)
   size_t Vt_elems;
-  void* retired[32];   // outgrown Vt buffers: kept alive until uce_destroy (captured hipGraphs may still name them)
+  // split-contraction scratch of the few-tile GEMM / convolution forms (uce_splitk.h): slabs + per-tile tickets (zero between launches).
+  // One launch at a time may use it: launches of one handle are ordered by the caller's stream (one handle per thread / stream).
+  float* sk_ws;
+  size_t sk_bytes;
+  unsigned* sk_tick;
+  size_t sk_tiles;
+  void* retired[32];   // outgrown Vt / split-contraction buffers: kept alive until uce_destroy (captured hipGraphs may still name them)
   int n_retired;
   struct uce_prof* prof;   // per-launch HIP-event brackets of uce_edit (uce_profile_begin / _end); null = off
 };
@@ -204,7 +210,8 @@ int launch_conv_w1(const void* x, const void* w, const void* bias, void* y, long
 int launch_linear_w1(const void* x, const void* w, const void* bias, const void* res, void* y, long M, int N, int K, int dtype,
                      hipStream_t st, int* rc, int mode);
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
-                    int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0, int wide = 1);
+                    int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0, int wide = 1,
+                    uce_ctx* h = nullptr);
 
 int launch_gram_primal(uce_ctx* h, const float* C, const float* G, const float* s, int N, int N_edit,
                        int d, float lamb, double* A, double* Bt, hipStream_t st, int which = 0);
@@ -262,6 +269,9 @@ int launch_lr_project_la(const float* W_old, const float* X, const float* Csub, 
 int uce_ensure_T(uce_ctx* h, long rows, int N_edit);
 int uce_ensure_T_floats(uce_ctx* h, size_t need);   // h->T holds >= need floats
 int uce_ensure_Vt(uce_ctx* h, size_t elems);
+// handle-owned scratch of the split-contraction forms: `bytes` of slabs and `tiles` tickets (zeroed when allocated; the kernels
+// leave them zero).  Grows geometrically; outgrown buffers are retired, not freed (captured hipGraphs may still name them).
+int uce_ensure_sk(uce_ctx* h, size_t bytes, size_t tiles);
 size_t sattn_vt_elems(int B, int H, int Lk, int dh);
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
                  float scale, int dtype, hipStream_t st, int qt_variant = 0, long ld = 0, int vti = 0, float lazy = 8.f);

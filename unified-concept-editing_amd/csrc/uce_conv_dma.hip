@@ -22,6 +22,7 @@
 // Measured against the register-staged 128 x 128 kernel in tools/probe_igemm.py; DESIGN.md section 4.
 #include "uce_common.h"
 #include "uce_epilogue.h"
+#include "uce_splitk.h"
 
 namespace {
 
@@ -68,11 +69,14 @@ __device__ __forceinline__ void cd_wait_two_tiles(int per) {
 
 // BK: input channels per k-tile (one tap x BK channels).  32 = 64-byte pixel segments and a ring of four stages; 64 = 128-byte
 // segments (whole cache lines, half the barriers) and a ring of two - 5-10 % ahead on uce_gemm.hip's shapes wherever Cin % 64 == 0.
-template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE, int BK = 32>
+// SK: split contraction for the few-tile regime (uce_splitk.h): grid = S x tiles, workgroup (s, tile) walks k-tiles
+// [s NK / S, (s + 1) NK / S) of the 9 taps x channel chunks; the last arriver of a tile sums the S slabs and runs the epilogue.
+template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE, int BK = 32, bool SK = false>
 __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                      long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
-                                                     int sd, const unsigned short* __restrict__ Rs) {
+                                                     int sd, const unsigned short* __restrict__ Rs,
+                                                     float* __restrict__ skws, unsigned* __restrict__ sktick, int S) {
   // sd: stride (1, or 2 = diffusers' Downsample2D: output pixel (y, x) reads source pixels (2y + dy, 2x + dx) of a [N, 2H, 2W, Cin]
   // tensor, pad 1); Rs: optional residual [M, Cout] added in the epilogue (the ResnetBlock2D's `x + conv2(.) + b`)
   static_assert(WGM * WGN == 8, "eight waves");
@@ -95,15 +99,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
 
   // tile of this block: the output-channel tiles of one pixel tile are consecutive on one XCD (they share the pixels)
   long tile = blockIdx.x;
+  int ks = 0;                                                          // this workgroup's slice of the contraction (SK)
   {
     const long T = (long)mtiles * ntiles;
-    if ((T & 7) == 0) tile = (long)(blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    if constexpr (SK) { ks = (int)(blockIdx.x / T); tile = blockIdx.x - ks * T; }
+    if ((T & 7) == 0) tile = (long)(tile & 7) * (T >> 3) + (tile >> 3);
   }
   const long m0 = (tile / ntiles) * CD_BM;
   const int n0 = (int)(tile % ntiles) * BN;
   const int Hi = H * sd, Wi = W * sd;                                 // the image the taps index (before the >> up of the fused upsample)
   const int Hs = Hi >> up, Ws = Wi >> up;
-  const int cch = Cin / CD_BK, NK = 9 * cch;
+  const int cch = Cin / CD_BK, NKall = 9 * cch;
+  const int kb = SK ? (int)((long)ks * NKall / S) : 0;
+  const int NK = SK ? (int)((long)(ks + 1) * NKall / S) : NKall;       // (one past the last k-tile of this workgroup)
   const long K = 9L * Cin;
 
   // ---- staging coordinates (k-tile invariant).  A wave instruction fills RPW rows x 2 BK bytes; lane = (row r, piece p); the
@@ -187,11 +195,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   const int last = NK - 1;                                             // (past the last tile the ring re-loads it: constant counts)
   constexpr int AHEAD = NST - 1;
 #pragma unroll
-  for (int i = 0; i < AHEAD; ++i) stage(i, i < last ? i : last);
+  for (int i = 0; i < AHEAD; ++i) stage(i, kb + i < last ? kb + i : last);
   wait_ring();
   __builtin_amdgcn_s_barrier();
   int slot = 0, fill = AHEAD;
-  for (int kt = 0; kt < NK; ++kt) {
+  for (int kt = kb; kt < NK; ++kt) {
     stage(fill, kt + AHEAD < last ? kt + AHEAD : last);
     const unsigned char* Ab = smem + slot * STAGE;
     const unsigned char* Bb = Ab + CD_BM * CD_BK * 2;
@@ -214,6 +222,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     fill = fill + 1 == NST ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
+
+  if constexpr (SK) {
+    if (S > 1) {
+      if (!uce_sk::reduce<TM, TN, CD_BM * BN>(acc, skws, sktick, tile, ks, S, smem, tid)) return;
+    }
+  }
 
   // ---- epilogue: + bias (+ residual), convert; whole rows through LDS (uce_epilogue.h) or 8-byte stores (a lane holds 4
   //      consecutive output channels of one pixel)
@@ -256,30 +270,43 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool WIDE, int BK = 32>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int BK = 32, bool SK = false>
 int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
-               hipStream_t st, int sd, const void* res) {
+               hipStream_t st, int sd, const void* res, uce_ctx* h = nullptr, int S = 1) {
   constexpr int BM = 32 * TM * WGM;
   constexpr int BN = 32 * TN * WGN;
   const long mtiles = (M + BM - 1) / BM;
   const int ntiles = (Cout + BN - 1) / BN;
-  const long nwg = mtiles * ntiles;
+  const long nwg = mtiles * ntiles * (SK ? S : 1);
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
-  const size_t smem = cd_smem<BM, BN, BK>();
+  float* skws = nullptr;
+  unsigned* sktick = nullptr;
+  if constexpr (SK) {
+    if (!h || S < 1 || S > 9 * (Cin / BK)) return UCE_EINVAL;
+    if (S > 1) {
+      const int rc = uce_ensure_sk(h, (size_t)mtiles * ntiles * S * BM * BN * sizeof(float), (size_t)mtiles * ntiles);
+      if (rc != UCE_OK) return rc;
+      skws = h->sk_ws;
+      sktick = h->sk_tick;
+    }
+  }
+  // (the whole-row epilogue parks 8 wave slabs in the drained ring: the small tiles' ring must hold them)
+  constexpr size_t slabs = WIDE ? (size_t)8 * uce_epi::wave_bytes<TN, false>() : 0;
+  const size_t smem = cd_smem<BM, BN, BK>() > slabs ? cd_smem<BM, BN, BK>() : slabs;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
-                       (int)mtiles, ntiles, sd, (const unsigned short*)res);
+                       (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S);
   else
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
-                       (int)mtiles, ntiles, sd, (const unsigned short*)res);
+                       (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
@@ -291,9 +318,31 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
 // still gives every CU a workgroup, else 128 pixels, else (the 8 x 8 layers: 2048 pixels at the generation batch) 128 x 128.
 // `force` (UCE_CONV_TILE = 1000 * BM + BN) pins one for measurements.
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
-                    int dtype, hipStream_t st, int* rc, int sd, const void* res, int force, int wide) {
+                    int dtype, hipStream_t st, int* rc, int sd, const void* res, int force, int wide, uce_ctx* h) {
   *rc = UCE_OK;
   if (Cin % 32 || Cout % 4) return 0;
+  // Few-tile regime (h != null): a layer without 200 tiles of 128 pixels x its widest exact tile - the whole U-Net at one prompt per
+  // call, the 16 x 16 / 8 x 8 levels at any batch - takes 128 x 128 or 128 x 64 tiles, two or three workgroups per CU, and below 200
+  // of those the 9 taps x channel chunks are split S ways (uce_splitk.h).  Any Cout % 8 == 0 (ragged last tile masked).
+  // UCE_CONV_TILE = 9128064 / 9128128 pins a form (S by rule).
+  if (h && wide && Cin % 64 == 0 && Cout % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)res & 15) && (!force || force / 1000000 == 9)) {
+    const long mt = (M + 127) / 128;
+    const int bw = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : 128;
+    const long tw = mt * ((Cout + bw - 1) / bw), t128 = mt * ((Cout + 127) / 128), t64 = mt * ((Cout + 63) / 64);
+    int bnS = 0;
+    if (force) bnS = force % 1000;
+    else if (tw < 200) bnS = t128 >= 200 ? 128 : 64;
+    if (bnS == 128) {
+      *rc = launch_dma<4, 2, 1, 2, true, 64, true>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res, h,
+                                                   uce_sk::choose_split(t128, 9 * (Cin / 64), 3));
+      return 1;
+    }
+    if (bnS == 64) {
+      *rc = launch_dma<4, 2, 1, 1, true, 64, true>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res, h,
+                                                   uce_sk::choose_split(t64, 9 * (Cin / 64), 3));
+      return 1;
+    }
+  }
   int bn = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : Cout % 128 == 0 ? 128 : 0;
   if (!bn) return 0;
   const long t256 = ((M + 255) / 256) * (Cout / bn), t128 = ((M + 127) / 128) * (Cout / bn);

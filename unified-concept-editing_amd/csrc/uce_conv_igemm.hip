@@ -261,7 +261,7 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
         launch_conv_w1(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual, h->sw.conv_w1))
       return rc;
     if (h->sw.conv_dma != 0 && launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual,
-                                               h->sw.conv_tile, h->sw.wide_epilogue))
+                                               h->sw.conv_tile, h->sw.wide_epilogue, h))
       return rc;
   }
   if (stride != 1 || residual) return UCE_ENOSYS;            // only the direct-to-LDS form has them

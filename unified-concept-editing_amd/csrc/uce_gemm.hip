@@ -19,6 +19,7 @@
 // registers 0..7 (hidden) pair with its registers 8..15 (gate).
 #include "uce_common.h"
 #include "uce_epilogue.h"
+#include "uce_splitk.h"
 
 namespace {
 
@@ -78,14 +79,21 @@ __device__ __forceinline__ void gd_wait_dma(int n) {
 // BK: contraction elements per k-tile.  32 = 64-byte row segments (16 rows per DMA instruction) with the deep ring; 64 = 128-byte
 // segments - whole cache lines, 8 rows per instruction, half the barriers per contraction - with a two-stage ring (one k-tile of
 // ~2500 MFMA cycles in flight covers the DMA latency).
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32>
+// SK: split contraction (the few-tile regime: a layer whose output tiles cannot give every CU a workgroup - every layer of the
+// U-Net at the CLI's one prompt per call, the 16 x 16 / 8 x 8 levels at any batch).  The grid is S x the tiles; workgroup (s, tile)
+// contracts k-tiles [s NK / S, (s + 1) NK / S) and parks its f32 accumulators, in register order, in its slab of `skws`
+// (write-through stores); a per-tile ticket (`sktick`, zero between launches: re-armed by the last arriver, so the launch can be
+// captured and replayed) picks the workgroup that arrives LAST, which re-reads all S slabs past the L1 in slab order (bit-
+// repeatable whatever the arrival order) and runs the one epilogue.  The hand-off is the sc1 form of uce_lowrank_riders.h.
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false>
 __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
                                                   const unsigned short* __restrict__ Wt,
                                                   const unsigned short* __restrict__ bias,
                                                   const unsigned short* __restrict__ R, long ldr,
                                                   unsigned short* __restrict__ Y, long ldy, long M, int N, int K,
                                                   int mtiles, int ntiles, int outf32,
-                                                  const unsigned short* __restrict__ X2, long ldx2, int K1) {
+                                                  const unsigned short* __restrict__ X2, long ldx2, int K1,
+                                                  float* __restrict__ skws, unsigned* __restrict__ sktick, int S) {
   static_assert(WGM * WGN == 8, "eight waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(BM == 128 || BM == 256, "A image: whole DMA instructions per wave");
@@ -104,13 +112,17 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
 
   // the column tiles of one row tile are consecutive on one XCD (they share the rows of X)
   long tile = blockIdx.x;
+  int ks = 0;                                                          // this workgroup's slice of the contraction (SK)
   {
     const long T = (long)mtiles * ntiles;
-    if ((T & 7) == 0) tile = (long)(blockIdx.x & 7) * (T >> 3) + (blockIdx.x >> 3);
+    if constexpr (SK) { ks = (int)(blockIdx.x / T); tile = blockIdx.x - ks * T; }
+    if ((T & 7) == 0) tile = (long)(tile & 7) * (T >> 3) + (tile >> 3);
   }
   const long m0 = (tile / ntiles) * BM;
   const int n0 = (int)(tile % ntiles) * BN;
-  const int NK = K / BK;
+  const int NKall = K / BK;
+  const int kb = SK ? (int)((long)ks * NKall / S) : 0;
+  const int NK = SK ? (int)((long)(ks + 1) * NKall / S) : NKall;       // (one past the last k-tile of this workgroup)
 
   // ---- staging coordinates (k-tile invariant).  A wave instruction fills RPW rows x 2 BK bytes; lane = (row r, piece p).
   // Bank swizzle on the SOURCE piece: row R stores piece p ^ swz(R) at slot p - (R >> 2) & 3 for the 64-byte rows, (R >> 1) & 7 for
@@ -189,11 +201,11 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
   const int last = NK - 1;                                             // (past the last tile the ring re-loads it: constant counts)
   constexpr int AHEAD = NST - 1;                                       // k-tiles in flight
 #pragma unroll
-  for (int i = 0; i < AHEAD; ++i) stage(i, i < last ? i : last);
+  for (int i = 0; i < AHEAD; ++i) stage(i, kb + i < last ? kb + i : last);
   gd_wait_dma((AHEAD - 1) * per);
   __builtin_amdgcn_s_barrier();
   int slot = 0, fill = AHEAD;                                          // ring positions of tile kt and of tile kt + AHEAD
-  for (int kt = 0; kt < NK; ++kt) {
+  for (int kt = kb; kt < NK; ++kt) {
 #if !defined(UCE_GEMM_ABLATE) || (UCE_GEMM_ABLATE != 3 && UCE_GEMM_ABLATE != 5)
     stage(fill, kt + AHEAD < last ? kt + AHEAD : last);
 #endif
@@ -230,6 +242,12 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
     fill = fill + 1 == NST ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's tail re-loads
+
+  if constexpr (SK) {
+    if (S > 1) {
+      if (!uce_sk::reduce<TM, TN, BM * BN>(acc, skws, sktick, tile, ks, S, smem, tid)) return;
+    }
+  }
 
   // ---- epilogue.  Register 4 g + i of tile a = column n0 + (wn TN + a) 32 + 8 g + 4 lh + i, row m0 + (wm TM + b) 32 + li
   if constexpr (WIDE) {
@@ -293,17 +311,28 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32>
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false>
 int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                int K, hipStream_t st, int outf32 = 0, const void* x2 = nullptr, long ldx2 = 0,
-               int K1 = 0) {
+               int K1 = 0, uce_ctx* h = nullptr, int S = 1) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   if (x2 && K1 % BK) return UCE_EINVAL;
   static_assert(NST == 4 || WIDE, "the shallow rings exist with the whole-row epilogue only");
   const long mtiles = (M + BM - 1) / BM;
   const int ntiles = (N + BN - 1) / BN;
-  const long nwg = mtiles * ntiles;
+  const long nwg = mtiles * ntiles * (SK ? S : 1);
   if (nwg > 0x7fffffffL || mtiles > 0x7fffffffL) return UCE_EINVAL;
+  float* skws = nullptr;
+  unsigned* sktick = nullptr;
+  if constexpr (SK) {
+    if (!h || S < 1 || S > K / BK) return UCE_EINVAL;
+    if (S > 1) {
+      const int rc = uce_ensure_sk(h, (size_t)mtiles * ntiles * S * BM * BN * sizeof(float), (size_t)mtiles * ntiles);
+      if (rc != UCE_OK) return rc;
+      skws = h->sk_ws;
+      sktick = h->sk_tick;
+    }
+  }
   constexpr size_t ring = (size_t)NST * (BM + BN) * BK * 2;
   constexpr size_t slabs = WIDE ? (size_t)8 * uce_epi::wave_bytes<(NST == 4 || TN < 2) ? TN : 2, GEGLU>() : 0;
   constexpr size_t smem = ring > slabs ? ring : slabs;
@@ -311,26 +340,26 @@ int launch_one(const void* x, long ldx, const void* w, const void* bias, const v
   static_assert(smem <= 160 * 1024, "LDS");
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
     attr_once.commit(tok);
   }
-  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
                      ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
-                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, (const unsigned short*)x2, ldx2, K1);
+                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, (const unsigned short*)x2, ldx2, K1, skws, sktick, S);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4, int BK = 32>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4, int BK = 32, bool SK = false>
 int launch_shape(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                  int K, int geglu, int dtype, hipStream_t st, int outf32 = 0, const void* x2 = nullptr,
-                 long ldx2 = 0, int K1 = 0) {
+                 long ldx2 = 0, int K1 = 0, uce_ctx* h = nullptr, int S = 1) {
   if (dtype == UCE_DTYPE_F16)
-    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1);
-  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st)
-               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1);
+    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, 0, nullptr, 0, 0, h, S)
+                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1, h, S);
+  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, 0, nullptr, 0, 0, h, S)
+               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1, h, S);
 }
 
 // padded MFMA work of an N-wide output on BN-wide tiles, relative
@@ -342,7 +371,29 @@ inline long waste(int N, int BN) { return (long)((N + BN - 1) / BN) * BN; }
 // 256 the VAE's and the text encoder's widths), and 128-row tiles when 256-row tiles would leave CUs without a workgroup
 int launch_linear(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                   int K, int geglu, int dtype, hipStream_t st, int force_tile, int wide, int outf32,
-                  const void* x2 = nullptr, long ldx2 = 0, int K1 = 0) {
+                  const void* x2 = nullptr, long ldx2 = 0, int K1 = 0, uce_ctx* h = nullptr) {
+  // whole-row epilogue where the rows allow 16-byte accesses (every layer of the U-Net); `wide` = 0 keeps the per-lane stores
+  const int nout = geglu ? N / 2 : N;
+  const bool wide_ok = wide && !outf32 && nout % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && (!res || (ldr % 8 == 0 && !((uintptr_t)res & 15)));
+  // Few-tile regime (h != null): a layer that cannot give 200 CUs a 128 x 320 tile takes 128 x 128 or 128 x 64 tiles (two or three
+  // workgroups per CU: 48 KB of ring each), and below 200 of those the contraction is split S ways (uce_splitk.h) - the 64 x 64
+  // level at one prompt per call (M = 8192: 64 row tiles), the 16 x 16 / 8 x 8 levels, the time MLP, the context projections.
+  // UCE_GEMM_TILE = 9128064 / 9128128 pins a form (S by rule).
+  if (h && wide_ok && K % 64 == 0 && !(x2 && K1 % 64) && (!force_tile || force_tile / 1000000 == 9)) {
+    const long mt = (M + 127) / 128;
+    const long t320 = mt * ((N + 319) / 320), t128 = mt * ((N + 127) / 128), t64 = mt * ((N + 63) / 64);
+    int bnS = 0;
+    if (force_tile) bnS = force_tile % 1000;
+    else if (t320 < 200 && ((M + 255) / 256) * ((N + 255) / 256) < 200) bnS = t128 >= 200 ? 128 : 64;
+    if (bnS == 128) {
+      const int S = uce_sk::choose_split(t128, K / 64, 2);
+      return launch_shape<4, 2, 1, 2, true, 2, 64, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1, h, S);
+    }
+    if (bnS == 64) {
+      const int S = uce_sk::choose_split(t64, K / 64, 2);
+      return launch_shape<4, 2, 1, 1, true, 2, 64, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1, h, S);
+    }
+  }
   // Tile: the one whose padded work per CU - ceil(tiles / 256) x BM x BN, over the tile's measured efficiency (256 x 320: 1,
   // 256 x 256: 0.95, 128 x 320: 0.8; tools/probe_r04.py) - is smallest: 320-wide tiles for SD's 320-multiples unless a narrower or
   // shorter tile fills the chip's last round better (M = 8192: N = 1280 -> 128 x 320, N = 3840 -> 256 x 256); N that only 128
@@ -373,9 +424,6 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   else if (K <= 320 && M >= 65536 && N >= 2560 && N % 256 == 0) { nst = 3; bm = 128; bn = 256; }
   else if (K % 64 == 0 && bn != 128 && !(x2 && K1 % 64)) nst = 64;         // 128-byte k-tiles, two stages: 5-10 % ahead of the 64-byte ring wherever K allows
   if (force_tile > 0) { nst = force_tile >= 1000000 ? force_tile / 1000000 : 4; bm = (force_tile / 1000) % 1000; bn = force_tile % 1000; }
-  // whole-row epilogue where the rows allow 16-byte accesses (every layer of the U-Net); `wide` = 0 keeps the per-lane stores
-  const int nout = geglu ? N / 2 : N;
-  const bool wide_ok = wide && !outf32 && nout % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && (!res || (ldr % 8 == 0 && !((uintptr_t)res & 15)));
   if (!wide_ok) nst = 4;
   // 64-wide k-tiles, two stages (UCE_GEMM_TILE = 64256320 / 64256256 / 64128320; K % 64 == 0, whole-row epilogue)
   if (nst == 64 && K % 64 == 0 && wide_ok) {
@@ -433,7 +481,7 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
                                  residual ? (const void*)((const unsigned short*)residual + m0 * ldr) : nullptr, ldr,
                                  (unsigned char*)y + m0 * ldy * ybytes, ldy, mb, N, K, geglu, dtype, (hipStream_t)stream, force,
                                  h->sw.wide_epilogue, outf32,
-                                 x2 ? (const void*)((const unsigned short*)x2 + m0 * ldx2) : nullptr, ldx2, K1);
+                                 x2 ? (const void*)((const unsigned short*)x2 + m0 * ldx2) : nullptr, ldx2, K1, h);
     if (rc != UCE_OK) return rc;
   }
   return UCE_OK;
