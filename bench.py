@@ -435,6 +435,99 @@ def _scalar_device(device):
     return torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
+def count_generation_flops(pipe, device, steps: int):
+    """Algorithmic FLOPs of ONE 512 x 512 image through the build's own pipeline ("recount from the build's own
+    U-Net"): every matrix product the U-Net issues for one prompt's CFG pair (counted by wrapping the UceHandle entry points during
+    one call: 2 M N K per linear layer, 2 M 9 Cin Cout per 3x3 convolution, 4 B L^2 C / 4 B Lq Lk C for self- / cross-attention),
+    x (steps + 1) U-Net calls of the PNDM schedule, + one VAE decode.  Norms, activations and the text encoder are not counted (the
+    figure is the MFMA work the roofline fraction is quoted against)."""
+    from uce_amd import edit as E
+    fam = {"conv": 0.0, "linear": 0.0, "sattn": 0.0, "xattn": 0.0}
+    depth = [0]
+    orig = {}
+
+    def prod(shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return n
+
+    def account(name, a, k):
+        if name == "linear":
+            x, w = a[0], a[1]
+            K = w.shape[1]
+            fam["linear"] += 2.0 * (prod(x.shape) // x.shape[-1]) * w.shape[0] * K
+            if k.get("x2") is not None:
+                pass                                                        # (the weight already spans both sources)
+        elif name == "linear_f32":
+            x, w = a[0], a[1]
+            fam["linear"] += 2.0 * x.shape[0] * w.shape[0] * x.shape[1]
+        elif name in ("conv3x3_nhwc", "conv3x3_igemm"):
+            x, w = a[0], a[1]
+            up = bool(k.get("upsample", False))
+            st = int(k.get("stride", 1))
+            Hh, Ww = (2 * x.shape[2], 2 * x.shape[3]) if up else (x.shape[2] // st, x.shape[3] // st)
+            fam["conv"] += 2.0 * x.shape[0] * Hh * Ww * 9 * x.shape[1] * w.shape[0]
+        elif name == "conv3x3_c4":
+            x, w = a[0], a[1]
+            fam["conv"] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 36 * w.shape[0]
+        elif name == "sattn_packed":
+            B, L, C3 = a[0].shape
+            fam["sattn"] += 4.0 * B * L * L * (C3 // 3)
+        elif name == "sattn":
+            q, kk = a[0], a[1]
+            fam["sattn"] += 4.0 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
+        elif name == "xattn":
+            q, kk = a[0], a[1]
+            fam["xattn"] += 4.0 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
+
+    def wrap(name):
+        f = getattr(E.UceHandle, name)
+        orig[name] = f
+
+        def g(self, *a, **k):
+            if depth[0] == 0:
+                account(name, a, k)
+            depth[0] += 1
+            try:
+                return f(self, *a, **k)
+            finally:
+                depth[0] -= 1
+        setattr(E.UceHandle, name, g)
+
+    names = ("linear", "linear_f32", "conv3x3_nhwc", "conv3x3_igemm", "conv3x3_c4", "sattn_packed", "sattn", "xattn")
+    for n in names:
+        wrap(n)
+    try:
+        x = torch.randn(2, 4, 64, 64, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        t = torch.tensor([500.0, 500.0], device=device)
+        ctx = torch.randn(2, 77, pipe.unet.cfg.cross_attention_dim, device=device).to(torch.bfloat16)
+        saved = [(m, m.kv_cache) for m in pipe.unet.modules() if hasattr(m, "kv_cache")]
+        pipe.unet.cache_context(ctx)                                        # hoisted: once per image, not per call
+        once = dict(fam)
+        for kf in fam:
+            fam[kf] = 0.0
+        pipe.unet(x, t, ctx)
+        for m, c in saved:
+            m.kv_cache = c
+        unet = dict(fam)
+        for kf in fam:
+            fam[kf] = 0.0
+        vae = {}
+        if getattr(pipe, "vae", None) is not None:
+            pipe.vae.decode(torch.randn(1, 4, 64, 64, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+            vae = dict(fam)
+    finally:
+        for n, f in orig.items():
+            setattr(E.UceHandle, n, f)
+    torch.cuda.synchronize()
+    per_call = sum(unet.values())
+    per_image = per_call * (steps + 1) + sum(vae.values()) + sum(once.values())
+    tot = {k: unet[k] * (steps + 1) + vae.get(k, 0.0) + once.get(k, 0.0) for k in unet}
+    return {"unet_call_cfg_pair": per_call, "unet_calls": steps + 1, "vae_decode": sum(vae.values()),
+            "context_projections_once": sum(once.values()), "per_image": per_image, "per_image_by_family": tot}
+
+
 def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_id="CompVis/stable-diffusion-v1-4",
                    dtype=torch.bfloat16, vae=True, rowwise_images=0, keep_pipe=None):
     """Secondary figure (BASELINE.json's second metric): images/s of the edited SD-1.4 pipeline,

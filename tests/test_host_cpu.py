@@ -365,21 +365,16 @@ def test_projection_live_tile_wave_map_covers_every_tile_once():
 
 
 def test_conv_dispatch_rule_and_padded_narrow_weights():
-    """Host logic of the convolution dispatch: which layers go to the implicit-GEMM kernels (measured rule), and the
-    zero-padded copy of a narrow-output weight (VAE conv_out) follows in-place updates of the parameters."""
+    """Host logic of the convolution dispatch: which layers the implicit-GEMM kernels take (shape rule only - no batch-size
+    rule, no library path), and the zero-padded copy of a narrow-output weight (VAE conv_out) follows in-place updates of the parameters."""
     from uce_amd.sd import conv_dispatch as E
     from uce_amd.sd import unet as U
-    if E.CONV_IGEMM == "auto":
-        assert E.conv_prefers_igemm(64, 64, 320, 320, 32)            # U-Net 64 x 64 at the generation batch
-        assert E.conv_prefers_igemm(32, 32, 320, 640, 32)            # 32 x 32, 320-multiple output: direct-to-LDS form
-        assert E.conv_prefers_igemm(32, 32, 1920, 640, 32)
-        assert E.conv_prefers_igemm(16, 16, 1280, 1280, 32)          # 64 x 4 tiles of 128 x 320: every CU has one
-        assert not E.conv_prefers_igemm(16, 16, 1280, 1280, 8)       # too few pixel tiles: im2col + library GEMM
-        assert not E.conv_prefers_igemm(8, 8, 1280, 1280, 32)
-        assert E.conv_prefers_igemm(512, 512, 128, 128, 16)          # VAE decoder
-        assert E.conv_prefers_igemm(32, 32, 320, 320, 32, stride=2)      # Downsample2D at the generation batch: own kernel
-        assert not E.conv_prefers_igemm(8, 8, 1280, 1280, 2, stride=2)   # one prompt: too few pixel tiles
-    assert not E.conv_prefers_igemm(64, 64, 4, 320, 32)              # conv_in: 4 channels (its own patch-matrix path)
+    # every layer of SD-1.x / SDXL / their VAEs has an implicit-GEMM kernel, whatever the batch (few tiles: the split-contraction forms)
+    for cin, cout in ((320, 320), (320, 640), (1920, 640), (1280, 1280), (2560, 1280), (960, 320), (128, 128), (512, 256), (128, 8)):
+        assert E.conv_takes_igemm(cin, cout) and E.conv_takes_igemm(cin, cout, stride=2, residual=True)
+    assert E.conv_takes_igemm(96, 256) and not E.conv_takes_igemm(96, 72)      # 64-byte k-tiles: only outputs a wide tile divides
+    assert not E.conv_takes_igemm(64, 4)                             # (sd.unet pads a 3- / 4-channel output to 8)
+    assert not E.conv_takes_igemm(4, 320)                            # conv_in: 4 channels (its own patch-matrix path)
     conv = torch.nn.Conv2d(128, 3, 3, padding=1)
     w8, b8 = U._padded_out_channels(conv)
     assert w8.shape == (8, 128, 3, 3) and torch.equal(w8[:3], conv.weight) and not w8[3:].any()

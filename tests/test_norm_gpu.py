@@ -80,7 +80,7 @@ def test_unet_uses_the_kernel_and_matches_torch_groupnorm():
         E.UceHandle.groupnorm_nhwc = orig
     assert calls["n"] == 61                     # 22 resnets x 2 + 16 transformer norms + conv_norm_out
     from tests.torch_twin import torch_ops
-    with torch_ops("_hip_nhwc_ok"):
+    with torch_ops():                           # (every kernel off: a 16-bit GPU convolution has no library path to fall to)
         b = pipe.unet(x, t, ctx).float()
     assert O.rel_fro(a.cpu(), b.cpu()) < 3e-2
 
@@ -495,3 +495,66 @@ def test_conv3x3_few_tile_forms_match_torch_and_repeat_bit_for_bit(H, N, Cin, Co
     assert O.rel_fro(y.double().cpu(), ref.cpu()) < 6e-3
     for _ in range(10):
         assert torch.equal(y, H.conv3x3_igemm(x, w, b, upsample=up, stride=stride, residual=r))
+
+
+@pytest.mark.parametrize("N,C,Hh,Ww,C2,silu,addend", [
+    (2, 320, 64, 64, 0, True, True),            # ONE prompt per call (CFG batch 2): every GroupNorm of the U-Net is one launch
+    (2, 640, 32, 32, 0, True, False),
+    (2, 1280, 16, 16, 0, True, True),
+    (2, 1280, 8, 8, 0, False, False),
+    (2, 1280, 8, 8, 1280, True, True),          # up block on x | skip (two sources, two channel octets per thread)
+    (2, 640, 64, 64, 320, True, False),
+    (1, 512, 64, 64, 0, True, False),           # the VAE decoder's mid block on one image
+    (3, 96, 7, 5, 0, True, True),               # ragged pixels: a last chunk shorter than the others
+    (16, 1280, 8, 8, 0, True, True),            # a generation batch on the 8 x 8 level
+])
+def test_groupnorm_one_launch_form_matches_the_two_kernel_form(N, C, Hh, Ww, C2, silu, addend):
+    """Small activations take k_gn_fused (one launch; the chunk stays in registers across a grid-wide wait inside each sample):
+    against fp64, against the stats + apply kernels (UCE_GN_FUSED=0; same arithmetic, another chunking of the f32 partial sums),
+    bit-repeatable over twenty runs and replayed from a hipGraph (the counters re-arm themselves)."""
+    import os
+    from uce_amd import edit as E
+    g = torch.Generator().manual_seed(N * C + Hh)
+    mk = lambda c: (torch.randn(N, c, Hh, Ww, generator=g) * 1.5 + 0.3).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    x, x2 = mk(C), (mk(C2) if C2 else None)
+    Ct = C + C2
+    w = (torch.rand(Ct, generator=g) + 0.5).bfloat16().cuda()
+    b = (torch.randn(Ct, generator=g) * 0.2).bfloat16().cuda()
+    ad = (torch.randn(N, Ct, generator=g) * 0.5).bfloat16().cuda() if addend else None
+    Hf = E.UceHandle("cuda:0")
+    old = os.environ.get("UCE_GN_FUSED")
+    os.environ["UCE_GN_FUSED"] = "0"
+    try:
+        H2 = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_GN_FUSED"]
+        else:
+            os.environ["UCE_GN_FUSED"] = old
+    try:
+        y = Hf.groupnorm_nhwc(x, w, b, 32, 1e-5, silu, ad, x2=x2)
+        y2 = H2.groupnorm_nhwc(x, w, b, 32, 1e-5, silu, ad, x2=x2)
+        xin = (x if x2 is None else torch.cat([x, x2], 1)).double()
+        if ad is not None:
+            xin = xin + ad.double()[:, :, None, None]
+        ref = F.group_norm(xin, 32, w.double(), b.double(), 1e-5)
+        ref = F.silu(ref) if silu else ref
+        assert torch.isfinite(y.float()).all()
+        assert O.rel_fro(y.double().cpu(), ref.cpu()) < 4e-3
+        assert O.rel_fro(y.double().cpu(), y2.double().cpu()) < 1e-3          # (one bf16 ulp here and there: another partition of the sums)
+        for _ in range(20):
+            assert torch.equal(y, Hf.groupnorm_nhwc(x, w, b, 32, 1e-5, silu, ad, x2=x2))
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                yg = Hf.groupnorm_nhwc(x, w, b, 32, 1e-5, silu, ad, x2=x2)
+            for _ in range(3):
+                yg.zero_()
+                gr.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(yg, y)
+    finally:
+        torch.cuda.synchronize()
+        Hf.close()
+        H2.close()

@@ -75,8 +75,9 @@ EXTRA_EDIT_FLAGS = [
 EXTRA_GENERATE_FLAGS = [
     ("--latents_only", dict(action="store_true", help="skip VAE decode / PNG encode, save latents (.pt)")),
     ("--skip_existing", dict(action="store_true", help="resume: skip rows whose first PNG exists")),
-    ("--batch_prompts", dict(type=int, default=1, help="CSV rows denoised per U-Net call (1 = row by row, as "
-                                                       "the reference does; each row keeps its own seeded latents)")),
+    ("--batch_prompts", dict(type=int, default=0, help="CSV rows denoised per U-Net call: 0 = as many as half of the free HBM "
+                                                       "holds, at most 128 images (rows are independent: each keeps its own "
+                                                       "seeded latents); 1 = row by row, as the reference does")),
 ]
 
 ART_TEMPLATES = ["painting by {}", "art by {}", "artwork by {}", "picture by {}", "style of {}"]

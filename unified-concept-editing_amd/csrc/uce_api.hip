@@ -232,7 +232,7 @@ int uce_create(uce_handle_t* out, int device) {
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
                         want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
                         env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30),
-                        env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1), env_int("UCE_EDIT_FUSED", 0), env_int("UCE_SATTN_LAZY", 8), env_int("UCE_CONV_W1", 1), env_int("UCE_GEMM_W1", 0)};
+                        env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1), env_int("UCE_EDIT_FUSED", 0), env_int("UCE_SATTN_LAZY", 8), env_int("UCE_CONV_W1", 1), env_int("UCE_GEMM_W1", 0), env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
@@ -241,6 +241,13 @@ int uce_create(uce_handle_t* out, int device) {
   (void)hipMemset(h->ticket, 0, 4 * sizeof(unsigned));
   if (hipMalloc((void**)&h->la_flags, LA_FLAGS * sizeof(unsigned)) == hipSuccess) (void)hipMemset(h->la_flags, 0, LA_FLAGS * sizeof(unsigned));
   else h->la_flags = nullptr;                                  // (the launch chain is used instead)
+  // (k_gn_fused: 1024 workgroups x 64 groups x 2 floats, 2 counters x 1024 samples; without them the two-kernel form runs)
+  if (hipMalloc((void**)&h->gn_partial, (size_t)1024 * 64 * 2 * sizeof(float)) != hipSuccess) h->gn_partial = nullptr;
+  if (h->gn_partial) {
+    if (hipMalloc((void**)&h->gn_counters, 2 * 1024 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(h->gn_counters, 0, 2 * 1024 * sizeof(unsigned));
+    else { (void)hipFree(h->gn_partial); h->gn_partial = nullptr; h->gn_counters = nullptr; }
+  }
+  (void)hipDeviceSynchronize();                                // the zeroed hand-off words are in memory before any stream launches
   *out = h;
   return UCE_OK;
 }
@@ -253,6 +260,8 @@ int uce_destroy(uce_handle_t h) {
   if (h->status) (void)hipFree(h->status);
   if (h->T) (void)hipFree(h->T);
   if (h->Vt) (void)hipFree(h->Vt);
+  if (h->gn_partial) (void)hipFree(h->gn_partial);
+  if (h->gn_counters) (void)hipFree(h->gn_counters);
   if (h->sk_ws) (void)hipFree(h->sk_ws);
   if (h->sk_tick) (void)hipFree(h->sk_tick);
   for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);

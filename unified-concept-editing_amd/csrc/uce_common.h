@@ -83,11 +83,13 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       uce_lowrank_fused.hip) | 1 = one launch, exact-f32 MFMA update | 0 = projection launch + update launch
 //   UCE_WIDE_EPILOGUE   1: GEMM / convolution tiles leave through LDS in whole rows | 0: 8 bytes per lane from the accumulators
 //   UCE_GEMM_TILE       0: tile of uce_linear_fwd by rule | 1000 * BM + BN (256320, 256256, 128320, 128256, 256128): forced
+//   UCE_GN_FUSED        1: GroupNorm of small activations in ONE launch (grid-wide wait inside a sample) | 0: always stats + apply
+//   UCE_SK_SPLIT        0: slabs per tile of the few-tile GEMM / convolution forms by rule (uce_splitk.h) | S: forced
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy, conv_w1, gemm_w1;
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy, conv_w1, gemm_w1, sk_split, gn_fused;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -173,6 +175,10 @@ struct uce_ctx {
   size_t Vt_elems;
   // split-contraction scratch of the few-tile GEMM / convolution forms (uce_splitk.h): slabs + per-tile tickets (zero between launches).
   // One launch at a time may use it: launches of one handle are ordered by the caller's stream (one handle per thread / stream).
+  // one-launch GroupNorm of small activations (uce_norm.hip: k_gn_fused): partial sums [<= 1024 workgroups][64 groups][2] and the
+  // arrive / depart counters of up to 1024 samples (zero between launches); allocated at uce_create
+  float* gn_partial;
+  unsigned* gn_counters;
   float* sk_ws;
   size_t sk_bytes;
   unsigned* sk_tick;

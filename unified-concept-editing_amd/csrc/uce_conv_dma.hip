@@ -56,8 +56,8 @@ __device__ __forceinline__ float cd_tof(unsigned short v) {
   else return __builtin_bit_cast(float, (unsigned)v << 16);
 }
 
-template <int BM, int BN, int BK>
-constexpr size_t cd_smem() { return (size_t)(BK == 32 ? 4 : 2) * (BM + BN) * BK * 2; }
+template <int BM, int BN, int BK, int NSTP = 0>
+constexpr size_t cd_smem() { return (size_t)(NSTP ? NSTP : BK == 32 ? 4 : 2) * (BM + BN) * BK * 2; }
 
 // waits until at most `2 * per` of this wave's LDS-DMAs are outstanding (per = its DMAs per k-tile: 2 .. 5)
 __device__ __forceinline__ void cd_wait_two_tiles(int per) {
@@ -67,30 +67,40 @@ __device__ __forceinline__ void cd_wait_two_tiles(int per) {
   else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 }
 
+__device__ __forceinline__ void cd_wait_one_tile(int per) {
+  if (per == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+  else if (per == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else if (per == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+}
+
 // BK: input channels per k-tile (one tap x BK channels).  32 = 64-byte pixel segments and a ring of four stages; 64 = 128-byte
 // segments (whole cache lines, half the barriers) and a ring of two - 5-10 % ahead on uce_gemm.hip's shapes wherever Cin % 64 == 0.
 // SK: split contraction for the few-tile regime (uce_splitk.h): grid = S x tiles, workgroup (s, tile) walks k-tiles
 // [s NK / S, (s + 1) NK / S) of the 9 taps x channel chunks; the last arriver of a tile sums the S slabs and runs the epilogue.
-template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE, int BK = 32, bool SK = false>
-__global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
+// NSTP: ring stages (0: four for the 64-byte k-tiles, two for the 128-byte ones); the few-tile forms run ONE workgroup per CU
+// and keep three 128-byte k-tiles in flight (NSTP = 4)
+// NW: waves per workgroup (8 in every form that ships; see uce_gemm.hip for the four-wave form that was measured and left out)
+template <int WGM, int WGN, int TM, int TN, bool F16, bool WIDE, int BK = 32, bool SK = false, int NSTP = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void k_conv3x3_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                      long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
                                                      int sd, const unsigned short* __restrict__ Rs,
                                                      float* __restrict__ skws, unsigned* __restrict__ sktick, int S) {
   // sd: stride (1, or 2 = diffusers' Downsample2D: output pixel (y, x) reads source pixels (2y + dy, 2x + dx) of a [N, 2H, 2W, Cin]
   // tensor, pad 1); Rs: optional residual [M, Cout] added in the epilogue (the ResnetBlock2D's `x + conv2(.) + b`)
-  static_assert(WGM * WGN == 8, "eight waves");
+  static_assert(WGM * WGN == NW && (NW == 8 || (NW == 4 && BK == 64 && NSTP == 2)), "waves (the four-wave form: two-stage ring only - its wait counts)");
   constexpr int CD_BM = 32 * TM * WGM;
   static_assert(CD_BM == 128 || CD_BM == 256, "128 or 256 pixels");
   constexpr int CD_BK = BK;
-  constexpr int NST = BK == 32 ? 4 : 2;                               // ring stages
+  constexpr int NST = NSTP ? NSTP : BK == 32 ? 4 : 2;                 // ring stages
   constexpr int PPR = BK / 8;                                         // 16-byte pieces per pixel segment
   constexpr int RPW = 64 / PPR;                                       // rows per DMA wave instruction (16 / 8)
-  constexpr int NA = CD_BM / (RPW * 8);                               // A wave instructions per wave and k-tile
+  constexpr int NA = CD_BM / (RPW * NW);                               // A wave instructions per wave and k-tile
   constexpr int BN = 32 * TN * WGN;
   constexpr int STAGE = (CD_BM + BN) * CD_BK * 2;
   constexpr int NB = BN / RPW;                                        // wave instructions per B image
-  constexpr int NBJ = (NB + 7) / 8;
+  constexpr int NBJ = (NB + NW - 1) / NW;
   static_assert(NA <= 4 && NBJ <= 5 && NST * STAGE <= 160 * 1024, "staging");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   unsigned a_base[4];                                                  // byte offset of (image, channel piece); OOB: no pixel
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int R = RPW * (8 * j + w) + r;
+    const int R = RPW * (NW * j + w) + r;
     const int c = p ^ swz(R);
     const long m = m0 + R;
     if (m < M) {
@@ -142,14 +152,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
   unsigned b_base[5];
 #pragma unroll
   for (int j = 0; j < NBJ; ++j) {
-    const int g = 8 * j + w;
+    const int g = NW * j + w;
     const int R = RPW * g + r;
     const int c = p ^ swz(R);
     b_base[j] = (g < NB && n0 + R < Cout) ? (unsigned)(((long)(n0 + R) * K + c * 8) * 2) : OOB;
   }
   int per = NA;                                                        // this wave's DMAs per k-tile
 #pragma unroll
-  for (int j = 0; j < NBJ; ++j) per += (8 * j + w < NB) ? 1 : 0;
+  for (int j = 0; j < NBJ; ++j) per += (NW * j + w < NB) ? 1 : 0;
   const long x_bytes = (M / ((long)H * W)) * (long)Hs * Ws * Cin * 2;
   const long w_bytes = (long)Cout * K * 2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
@@ -164,18 +174,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
       const int yy = a_y[j] + dy, xx = a_x[j] + dx;
       const bool ok = (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
       const unsigned off = a_base[j] + (unsigned)((((yy >> up) * Ws + (xx >> up)) * Cin + c0) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16, ok ? off : OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (NW * j + w) * 1024), 16, ok ? off : OOB, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
-      if (8 * j + w < NB)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + CD_BM * CD_BK * 2 + (8 * j + w) * 1024), 16,
+      if (NW * j + w < NB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + CD_BM * CD_BK * 2 + (NW * j + w) * 1024), 16,
                                                  b_base[j] == OOB ? OOB : b_base[j] + (unsigned)(kt * CD_BK * 2), 0, 0, 0);
     }
   };
   // waits until this wave's DMAs of every k-tile but the last (NST - 2) issued have landed
   auto wait_ring = [&]() {
     if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NST == 3) cd_wait_one_tile(per);
     else cd_wait_two_tiles(per);
   };
 
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
 
   if constexpr (SK) {
     if (S > 1) {
-      if (!uce_sk::reduce<TM, TN, CD_BM * BN>(acc, skws, sktick, tile, ks, S, smem, tid)) return;
+      if (!uce_sk::reduce<TM, TN, CD_BM * BN, 64 * NW>(acc, skws, sktick, tile, ks, S, smem, tid)) return;
     }
   }
 
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_dma(const unsigned short* __res
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool WIDE, int BK = 32, bool SK = false>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int BK = 32, bool SK = false, int NSTP = 0, int NW = 8>
 int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
                hipStream_t st, int sd, const void* res, uce_ctx* h = nullptr, int S = 1) {
   constexpr int BM = 32 * TM * WGM;
@@ -291,20 +302,20 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
     }
   }
   // (the whole-row epilogue parks 8 wave slabs in the drained ring: the small tiles' ring must hold them)
-  constexpr size_t slabs = WIDE ? (size_t)8 * uce_epi::wave_bytes<TN, false>() : 0;
-  const size_t smem = cd_smem<BM, BN, BK>() > slabs ? cd_smem<BM, BN, BK>() : slabs;
+  constexpr size_t slabs = WIDE ? (size_t)NW * uce_epi::wave_bytes<TN, false>() : 0;
+  const size_t smem = cd_smem<BM, BN, BK, NSTP>() > slabs ? cd_smem<BM, BN, BK, NSTP>() : slabs;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK, NSTP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK, NSTP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK, NSTP, NW>), dim3((unsigned)nwg), dim3(64 * NW), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
                        (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S);
   else
-    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+    hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK, NSTP, NW>), dim3((unsigned)nwg), dim3(64 * NW), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
                        (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S);
   UCE_LAUNCH_CHECK();
@@ -324,24 +335,27 @@ int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, lon
   // Few-tile regime (h != null): a layer without 200 tiles of 128 pixels x its widest exact tile - the whole U-Net at one prompt per
   // call, the 16 x 16 / 8 x 8 levels at any batch - takes 128 x 128 or 128 x 64 tiles, two or three workgroups per CU, and below 200
   // of those the 9 taps x channel chunks are split S ways (uce_splitk.h).  Any Cout % 8 == 0 (ragged last tile masked).
-  // UCE_CONV_TILE = 9128064 / 9128128 pins a form (S by rule).
-  if (h && wide && Cin % 64 == 0 && Cout % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)res & 15) && (!force || force / 1000000 == 9)) {
+  // UCE_CONV_TILE = 9128064 / 9128128 pins a form (S by rule; 8... / 7...: its three- / two-stage ring).
+  if (h && wide && Cin % 64 == 0 && Cout % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)res & 15) && (!force || force / 1000000 >= 7)) {
     const long mt = (M + 127) / 128;
     const int bw = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : 128;
     const long tw = mt * ((Cout + bw - 1) / bw), t128 = mt * ((Cout + 127) / 128), t64 = mt * ((Cout + 63) / 64);
-    int bnS = 0;
-    if (force) bnS = force % 1000;
-    else if (tw < 200) bnS = t128 >= 200 ? 128 : 64;
+    int bnS = 0, nstS = 2;
+    const bool exact = Cout % 128 == 0 || Cout % 320 == 0;              // a wide tile divides Cout (the forms below this block)
+    if (force) { bnS = force % 1000; nstS = force / 1000000 - 5; }                      // 7 / 8 / 9: ring of 2 / 3 / 4 stages
+    else if (tw < 200) bnS = t128 >= 400 ? 128 : 64;
+    else if (!exact && (sd != 1 || res)) bnS = Cout > 64 ? 128 : 64;   // (only this kernel has the stride-2 taps and the residual)
+#define UCE_CSK(TN, NSTV) \
+  { *rc = launch_dma<4, 2, 1, TN, true, 64, true, NSTV>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res, h, S); return 1; }
     if (bnS == 128) {
-      *rc = launch_dma<4, 2, 1, 2, true, 64, true>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res, h,
-                                                   uce_sk::choose_split(t128, 9 * (Cin / 64), 3));
-      return 1;
+      const int S = uce_sk::choose_split(t128, 9 * (Cin / 64), 10, h->sw.sk_split);
+      if (nstS == 2) UCE_CSK(2, 2) else if (nstS == 3) UCE_CSK(2, 3) else UCE_CSK(2, 4)
     }
     if (bnS == 64) {
-      *rc = launch_dma<4, 2, 1, 1, true, 64, true>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res, h,
-                                                   uce_sk::choose_split(t64, 9 * (Cin / 64), 3));
-      return 1;
+      const int S = uce_sk::choose_split(t64, 9 * (Cin / 64), 10, h->sw.sk_split);
+      if (nstS == 2) UCE_CSK(1, 2) else if (nstS == 3) UCE_CSK(1, 3) else UCE_CSK(1, 4)
     }
+#undef UCE_CSK
   }
   int bn = Cout % 320 == 0 ? 320 : Cout % 256 == 0 ? 256 : Cout % 128 == 0 ? 128 : 0;
   if (!bn) return 0;

@@ -85,8 +85,12 @@ __device__ __forceinline__ void gd_wait_dma(int n) {
 // (write-through stores); a per-tile ticket (`sktick`, zero between launches: re-armed by the last arriver, so the launch can be
 // captured and replayed) picks the workgroup that arrives LAST, which re-reads all S slabs past the L1 in slab order (bit-
 // repeatable whatever the arrival order) and runs the one epilogue.  The hand-off is the sc1 form of uce_lowrank_riders.h.
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false>
-__global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
+// NW: waves per workgroup (8 in every form that ships).  A four-wave 128 x 128 form with 64 x 64 wave tiles (one fragment read per
+// MFMA instead of two) was built for the few-tile regime and measured SLOWER than eight waves on 128 x 64 at every layer of the
+// one-prompt U-Net (conv 320 -> 320 @ 64 x 64 x 2: 35.2 us against 33.0; 1280 @ 16 x 16: 38.9 against 32.7 -
+// profiles/r05/sk_sweep_b1.jsonl): with one wave per SIMD and a two-stage ring nothing covers the DMA latency.  Not instantiated.
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : ((NST == 4 || BK == 64) ? 2 : 4)) void k_gemm_dma(const unsigned short* __restrict__ X, long ldx,
                                                   const unsigned short* __restrict__ Wt,
                                                   const unsigned short* __restrict__ bias,
                                                   const unsigned short* __restrict__ R, long ldr,
@@ -94,15 +98,15 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
                                                   int mtiles, int ntiles, int outf32,
                                                   const unsigned short* __restrict__ X2, long ldx2, int K1,
                                                   float* __restrict__ skws, unsigned* __restrict__ sktick, int S) {
-  static_assert(WGM * WGN == 8, "eight waves");
+  static_assert(WGM * WGN == NW && (NW == 8 || (NW == 4 && BK == 64 && NST == 2)), "waves (the four-wave form: two-stage ring only - its wait counts)");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(BM == 128 || BM == 256, "A image: whole DMA instructions per wave");
   static_assert(BK == 32 || BK == 64, "k-tile");
   constexpr int PPR = BK / 8;                                          // 16-byte pieces per row segment
   constexpr int RPW = 64 / PPR;                                        // rows per DMA wave instruction (16 / 8)
-  constexpr int NA = BM / (RPW * 8);                                   // A wave instructions per wave and k-tile (1, 2 / 2, 4)
+  constexpr int NA = BM / (RPW * NW);                                   // A wave instructions per wave and k-tile (1, 2 / 2, 4)
   constexpr int NB = BN / RPW;                                         // B wave instructions per k-tile (all waves)
-  constexpr int NBJ = (NB + 7) / 8;
+  constexpr int NBJ = (NB + NW - 1) / NW;
   static_assert(NA <= 4 && NBJ <= 5, "staging registers");
   constexpr int STAGE = (BM + BN) * BK * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
   unsigned a_base[4];          // (fixed sizes: a lambda capturing an array of template-dependent size loses the kernel's host handle - clang, ROCm 7.2)
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int Rr = RPW * (8 * j + w) + r;
+    const int Rr = RPW * (NW * j + w) + r;
     const int c = p ^ swz(Rr);
     const long m = m0 + Rr;
     a_base[j] = (m < M) ? (unsigned)((m * ldx + c * 8) * 2) : OOB;
@@ -141,14 +145,14 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
   unsigned b_base[5];
 #pragma unroll
   for (int j = 0; j < NBJ; ++j) {
-    const int g = 8 * j + w;
+    const int g = NW * j + w;
     const int Rr = RPW * g + r;
     const int c = p ^ swz(Rr);
     b_base[j] = (g < NB && n0 + Rr < N) ? (unsigned)(((long)(n0 + Rr) * K + c * 8) * 2) : OOB;
   }
   int per = NA;
 #pragma unroll
-  for (int j = 0; j < NBJ; ++j) per += (8 * j + w < NB) ? 1 : 0;       // this wave's DMAs per k-tile
+  for (int j = 0; j < NBJ; ++j) per += (NW * j + w < NB) ? 1 : 0;       // this wave's DMAs per k-tile
   // two-source contraction (X2 != nullptr): columns [0, K1) of a row come from X (row stride ldx), columns [K1, K) from X2 (row
   // stride ldx2) - the 1x1 shortcut convolution of an up block reading x and the skip connection in place (K1 % BK == 0)
   const long x_bytes = X2 ? ((M - 1) * ldx + K1) * 2 : ((M - 1) * ldx + K) * 2;
@@ -167,20 +171,20 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
       const unsigned koff2 = koff - (unsigned)(K1 * 2);
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        const unsigned mrow = (unsigned)(m0 + RPW * (8 * j + w) + r);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (lds_void*)(sbase + (8 * j + w) * 1024), 16,
+        const unsigned mrow = (unsigned)(m0 + RPW * (NW * j + w) + r);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (lds_void*)(sbase + (NW * j + w) * 1024), 16,
                                                  a_base[j] == OOB ? OOB : a_base[j] + mrow * dl2 + koff2, 0, 0, 0);
       }
     } else {
 #pragma unroll
     for (int j = 0; j < NA; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (8 * j + w) * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sbase + (NW * j + w) * 1024), 16,
                                                a_base[j] == OOB ? OOB : a_base[j] + koff, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
-      if (8 * j + w < NB)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + BM * BK * 2 + (8 * j + w) * 1024), 16,
+      if (NW * j + w < NB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + BM * BK * 2 + (NW * j + w) * 1024), 16,
                                                  b_base[j] == OOB ? OOB : b_base[j] + koff, 0, 0, 0);
     }
   };
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
 
   if constexpr (SK) {
     if (S > 1) {
-      if (!uce_sk::reduce<TM, TN, BM * BN>(acc, skws, sktick, tile, ks, S, smem, tid)) return;
+      if (!uce_sk::reduce<TM, TN, BM * BN, 64 * NW>(acc, skws, sktick, tile, ks, S, smem, tid)) return;
     }
   }
 
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(512, (NST == 4 || BK == 64) ? 2 : 4) void k_gemm_dm
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false>
+template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false, int NW = 8>
 int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                int K, hipStream_t st, int outf32 = 0, const void* x2 = nullptr, long ldx2 = 0,
                int K1 = 0, uce_ctx* h = nullptr, int S = 1) {
@@ -334,32 +338,32 @@ int launch_one(const void* x, long ldx, const void* w, const void* bias, const v
     }
   }
   constexpr size_t ring = (size_t)NST * (BM + BN) * BK * 2;
-  constexpr size_t slabs = WIDE ? (size_t)8 * uce_epi::wave_bytes<(NST == 4 || TN < 2) ? TN : 2, GEGLU>() : 0;
+  constexpr size_t slabs = WIDE ? (size_t)NW * uce_epi::wave_bytes<(NST == 4 || TN < 2) ? TN : 2, GEGLU>() : 0;
   constexpr size_t smem = ring > slabs ? ring : slabs;
   static_assert(NST == 4 || BK == 64 || smem <= 80 * 1024, "two workgroups per CU");
   static_assert(smem <= 160 * 1024, "LDS");
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
     attr_once.commit(tok);
   }
-  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK>), dim3((unsigned)nwg), dim3(512), smem, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK, NW>), dim3((unsigned)nwg), dim3(64 * NW), smem, st, (const unsigned short*)x,
                      ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
                      (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, (const unsigned short*)x2, ldx2, K1, skws, sktick, S);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4, int BK = 32, bool SK = false>
+template <int WGM, int WGN, int TM, int TN, bool WIDE, int NST = 4, int BK = 32, bool SK = false, int NW = 8>
 int launch_shape(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                  int K, int geglu, int dtype, hipStream_t st, int outf32 = 0, const void* x2 = nullptr,
                  long ldx2 = 0, int K1 = 0, uce_ctx* h = nullptr, int S = 1) {
   if (dtype == UCE_DTYPE_F16)
-    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, 0, nullptr, 0, 0, h, S)
-                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1, h, S);
-  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, 0, nullptr, 0, 0, h, S)
-               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK, SK>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1, h, S);
+    return geglu ? launch_one<WGM, WGN, TM, TN, true, true, WIDE, NST, BK, SK, NW>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, 0, nullptr, 0, 0, h, S)
+                 : launch_one<WGM, WGN, TM, TN, true, false, WIDE, NST, BK, SK, NW>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1, h, S);
+  return geglu ? launch_one<WGM, WGN, TM, TN, false, true, WIDE, NST, BK, SK, NW>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, 0, nullptr, 0, 0, h, S)
+               : launch_one<WGM, WGN, TM, TN, false, false, WIDE, NST, BK, SK, NW>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, st, outf32, x2, ldx2, K1, h, S);
 }
 
 // padded MFMA work of an N-wide output on BN-wide tiles, relative
@@ -378,26 +382,25 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   // Few-tile regime (h != null): a layer that cannot give 200 CUs a 128 x 320 tile takes 128 x 128 or 128 x 64 tiles (two or three
   // workgroups per CU: 48 KB of ring each), and below 200 of those the contraction is split S ways (uce_splitk.h) - the 64 x 64
   // level at one prompt per call (M = 8192: 64 row tiles), the 16 x 16 / 8 x 8 levels, the time MLP, the context projections.
-  // UCE_GEMM_TILE = 9128064 / 9128128 pins a form (S by rule).
-  if (h && wide_ok && K % 64 == 0 && !(x2 && K1 % 64) && (!force_tile || force_tile / 1000000 == 9)) {
+  // UCE_GEMM_TILE = 9128064 / 9128128 pins a form (S by rule; 8... / 7...: its three- / two-stage ring).
+  if (h && wide_ok && K % 64 == 0 && !(x2 && K1 % 64) && (!force_tile || force_tile / 1000000 >= 7)) {
     const long mt = (M + 127) / 128;
     const long t320 = mt * ((N + 319) / 320), t128 = mt * ((N + 127) / 128), t64 = mt * ((N + 63) / 64);
-    int bnS = 0;
-    if (force_tile) bnS = force_tile % 1000;
-    else if (t320 < 200 && ((M + 255) / 256) * ((N + 255) / 256) < 200) bnS = t128 >= 200 ? 128 : 64;
+    int bnS = 0, nstS = 2;
+    if (force_tile) { bnS = force_tile % 1000; nstS = force_tile / 1000000 - 5; }      // 7 / 8 / 9: ring of 2 / 3 / 4 stages
+    else if (t320 < 200 && ((M + 255) / 256) * ((N + 255) / 256) < 200) bnS = t128 >= 400 ? 128 : 64;
+#define UCE_GSK(TN, NSTV) \
+  return launch_shape<4, 2, 1, TN, true, NSTV, 64, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1, h, S);
     if (bnS == 128) {
-      const int S = uce_sk::choose_split(t128, K / 64, 2);
-      return launch_shape<4, 2, 1, 2, true, 2, 64, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1, h, S);
+      const int S = uce_sk::choose_split(t128, K / 64, 10, h->sw.sk_split);
+      if (nstS == 2) { UCE_GSK(2, 2) } else if (nstS == 3) { UCE_GSK(2, 3) } else { UCE_GSK(2, 4) }
     }
     if (bnS == 64) {
-      const int S = uce_sk::choose_split(t64, K / 64, 2);
-      return launch_shape<4, 2, 1, 1, true, 2, 64, true>(x, ldx, w, bias, res, ldr, y, ldy, M, N, K, geglu, dtype, st, 0, x2, ldx2, K1, h, S);
+      const int S = uce_sk::choose_split(t64, K / 64, 10, h->sw.sk_split);
+      if (nstS == 2) { UCE_GSK(1, 2) } else if (nstS == 3) { UCE_GSK(1, 3) } else { UCE_GSK(1, 4) }
     }
+#undef UCE_GSK
   }
-  // Tile: the one whose padded work per CU - ceil(tiles / 256) x BM x BN, over the tile's measured efficiency (256 x 320: 1,
-  // 256 x 256: 0.95, 128 x 320: 0.8; tools/probe_r04.py) - is smallest: 320-wide tiles for SD's 320-multiples unless a narrower or
-  // shorter tile fills the chip's last round better (M = 8192: N = 1280 -> 128 x 320, N = 3840 -> 256 x 256); N that only 128
-  // divides (the VAE's narrow layers) keeps 256 x 128
   const long w320 = waste(N, 320), w256 = waste(N, 256), w128 = waste(N, 128);
   int bm = 256, bn = 320;
   if (w128 < w320 && w128 < w256) {

@@ -283,6 +283,208 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
   }
 }
 
+
+// ---- ONE launch for small activations (one prompt per call: every GroupNorm of the U-Net; the small levels at any batch).
+// The two-kernel form costs two launches and reads x twice; at a CFG batch of 2 a launch (~4-5 us of ramp, latency-bound
+// round trips) is longer than the data takes (5 MB).  Here a workgroup keeps its chunk of pixels in REGISTERS (KR rows per
+// thread), publishes its partial sums, waits until the chunks of its sample have all arrived, folds them and normalises its rows
+// from the registers.  The whole grid must be resident at once (grid <= GNF_MAX_WG workgroups of 256 threads, <= 128 VGPRs - the
+// launch bounds - and <= 32 KB of LDS: 4 per CU fit) - a grid-wide wait inside a sample; the spin is bounded (GNF_SPIN_MAX polls, ~1 s: a device that cannot
+// hold the grid poisons the output with NaN rather than hanging).
+//   partial [N][chunks][G][2] floats and arrive / depart [N] counters live in the HANDLE (zero between launches: the workgroup that
+//   departs last re-arms both - nothing of the protocol is in the kernel arguments, so the launch can be captured and replayed).
+// Hand-off: write-through (sc1) stores -> vmcnt(0) -> barrier -> relaxed agent-scope ticket; poll -> barrier -> sc1 loads
+// (uce_lowrank_riders.h has the reasoning).
+constexpr int GNF_MAX_WG = 1024;
+constexpr int GNF_MAX_N = 1024;
+constexpr unsigned GNF_SPIN_MAX = 1u << 24;
+
+template <bool F16, int NOT>
+__global__ __launch_bounds__(256, 4) void k_gn_fused(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int C1,
+                                                  const unsigned short* __restrict__ addend, const unsigned short* __restrict__ gamma,
+                                                  const unsigned short* __restrict__ beta, float* __restrict__ partial,
+                                                  unsigned* __restrict__ counters, unsigned short* __restrict__ y, int HW, int C,
+                                                  int G, int chunks, float eps, int silu, long ald) {
+  constexpr int KR = 8 / NOT;                                           // pixel rows a thread keeps
+  extern __shared__ __attribute__((aligned(16))) float red[];          // [RPI][C][2]
+  __shared__ float mean_s[64], rstd_s[64];
+  __shared__ double fold_s[2][8][64];
+  __shared__ unsigned flag_s;
+  const GnMap mp = gn_map(C);
+  const int tpr = mp.active / mp.RPI;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, ch = blockIdx.x;
+  const int P = mp.RPI * KR;
+  const int p0 = ch * P, p1 = (p0 + P < HW) ? p0 + P : HW;
+  const int oc0 = tid % tpr, prow = tid / tpr;
+  const int cpg = C / G;
+  const bool live = tid < mp.active;
+  uint4_t v[KR][NOT];
+  float ad[NOT][8];
+  const unsigned short* src[NOT];
+  int pst[NOT];
+  bool has[NOT];
+#pragma unroll
+  for (int j = 0; j < NOT; ++j) {
+    const int oc = oc0 + j * tpr;
+    has[j] = live && j < mp.NO && oc < mp.OC;
+    const bool second = oc * 8 >= C1;
+    pst[j] = second ? C - C1 : C1;
+    src[j] = second ? x2 + (size_t)n * HW * (C - C1) + (oc * 8 - C1) : x + (size_t)n * HW * C1 + oc * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ad[j][i] = 0.f;
+    if (addend && has[j]) unpack8<F16>(*(const uint4_t*)(addend + (size_t)n * ald + oc * 8), ad[j]);
+  }
+  // ---- the chunk into registers (every load in flight at once), then the per-channel sums in pixel order
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+#pragma unroll
+    for (int j = 0; j < NOT; ++j) {
+      const int p = p0 + prow + k * mp.RPI;
+      v[k][j] = (uint4_t){0u, 0u, 0u, 0u};
+      if (has[j] && p < p1) v[k][j] = *(const uint4_t*)(src[j] + (size_t)p * pst[j]);
+    }
+  {
+    float s[NOT][8], q[NOT][8];
+#pragma unroll
+    for (int j = 0; j < NOT; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[j][i] = q[j][i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+      for (int j = 0; j < NOT; ++j) {
+        const int p = p0 + prow + k * mp.RPI;
+        if (has[j] && p < p1) {
+          float f[8];
+          unpack8<F16>(v[k][j], f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float w = f[i] + ad[j][i];
+            s[j][i] += w;
+            q[j][i] = fmaf(w, w, q[j][i]);
+          }
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < NOT; ++j) {
+      const int oc = oc0 + j * tpr;
+      if (has[j]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[((size_t)prow * C + oc * 8 + i) * 2] = s[j][i];
+          red[((size_t)prow * C + oc * 8 + i) * 2 + 1] = q[j][i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // (two threads per group - sums and sums of squares - in a fixed order: pixel rows outer, channels inner)
+  if (tid < 2 * G) {
+    const int g = tid >> 1, which = tid & 1;
+    double a = 0.0;
+    for (int r = 0; r < mp.RPI; ++r)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += (double)red[((size_t)r * C + c) * 2 + which];
+    __hip_atomic_store(partial + (((size_t)n * chunks + ch) * G + g) * 2 + which, (float)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- wait for the sample's other chunks
+  unsigned* arrive = counters + 2 * n;
+  unsigned* depart = arrive + 1;
+  if (tid == 0) {
+    unsigned polls = 0;
+    if (__hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)chunks - 1)   // (the last arriver need not poll)
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)chunks && ++polls < GNF_SPIN_MAX)
+        __builtin_amdgcn_s_sleep(1);
+    flag_s = polls < GNF_SPIN_MAX ? 1u : 0u;
+    if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)chunks - 1) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // everybody is past the poll: re-arm
+      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  const bool ok = flag_s != 0u;
+  // ---- fold the partials of this sample (k_gn_apply's order: thread (sub, g) takes chunks sub, sub + nsub, ..; then the nsub sums)
+  const int nsub = G <= 32 ? 8 : 4;
+  {
+    const int g = tid % (256 / nsub), sub = tid / (256 / nsub);
+    double a = 0.0, b = 0.0;
+    if (g < G) {
+      const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)(partial + (size_t)n * chunks * G * 2), 0,
+                                                                          (int)((size_t)chunks * G * 2 * sizeof(float)), 0x00020000);
+      typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+      constexpr int FU = 16;                                             // independent round trips in flight (one round up to 16 nsub chunks)
+      for (int c0 = sub; c0 < chunks; c0 += FU * nsub) {
+        uint2v t[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+          const int c = c0 + u * nsub;
+          t[u] = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(pr, c < chunks ? (unsigned)(((size_t)c * G + g) * 8) : 0x80000000u, 0, 16 /* sc1 */));
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+          if (c0 + u * nsub < chunks) {
+            a += (double)__uint_as_float(t[u][0]);
+            b += (double)__uint_as_float(t[u][1]);
+          }
+      }
+    }
+    if (g < 64) {
+      fold_s[0][sub][g] = a;
+      fold_s[1][sub][g] = b;
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, b = 0.0;
+    for (int sub = 0; sub < nsub; ++sub) {
+      a += fold_s[0][sub][tid];
+      b += fold_s[1][sub][tid];
+    }
+    const double cnt = (double)HW * cpg;
+    const double mu = a / cnt;
+    double var = b / cnt - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean_s[tid] = ok ? (float)mu : __builtin_nanf("");
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!live) return;
+  // ---- normalise the rows held in registers
+  unsigned short* yb = y + (size_t)n * HW * C;
+#pragma unroll
+  for (int j = 0; j < NOT; ++j) {
+    if (!has[j]) continue;
+    const int oc = oc0 + j * tpr;
+    float g8[8], b8[8], sa[8], sb[8];
+    unpack8<F16>(*(const uint4_t*)(gamma + oc * 8), g8);
+    unpack8<F16>(*(const uint4_t*)(beta + oc * 8), b8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int grp = (oc * 8 + i) / cpg;
+      sa[i] = g8[i] * rstd_s[grp];
+      sb[i] = fmaf(ad[j][i] - mean_s[grp], sa[i], b8[i]);              // ((x + a) - mean) * rstd * gamma + beta
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int p = p0 + prow + k * mp.RPI;
+      if (p < p1) {
+        float f[8];
+        unpack8<F16>(v[k][j], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float w = fmaf(f[i], sa[i], sb[i]);
+          if (silu) w = w * __builtin_amdgcn_rcpf(1.0f + __expf(-w));
+          f[i] = w;
+        }
+        const uint4_t o = {pack2<F16>(f[0], f[1]), pack2<F16>(f[2], f[3]), pack2<F16>(f[4], f[5]), pack2<F16>(f[6], f[7])};
+        *(uint4_t*)(yb + (size_t)p * C + oc * 8) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int uce_groupnorm_chunks(int HW) {
@@ -307,6 +509,23 @@ static int groupnorm_launch(uce_handle_t h, const void* x, const void* x2, int C
   if (smem > 64 * 1024) return UCE_EINVAL;
   const dim3 grid(chunks, N), block(256);
   hipStream_t st = (hipStream_t)stream;
+  // small activations: ONE launch, the chunk held in registers across a grid-wide wait inside each sample (k_gn_fused)
+  if (h->gn_partial && h->sw.gn_fused && smem <= 32 * 1024 && N <= GNF_MAX_N) {
+    const int P = mp.RPI * (8 / mp.NO);
+    const long fch = ((long)HW + P - 1) / P;
+    if (fch * N <= GNF_MAX_WG) {
+      const dim3 fgrid((unsigned)fch, N);
+#define UCE_GNF(F16V, NOV)                                                                                                          \
+  hipLaunchKernelGGL((k_gn_fused<F16V, NOV>), fgrid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,       \
+                     (const unsigned short*)addend, (const unsigned short*)gamma, (const unsigned short*)beta, h->gn_partial,       \
+                     h->gn_counters, (unsigned short*)y, HW, C, G, (int)fch, eps, silu, ald)
+      if (dtype == UCE_DTYPE_F16) { if (mp.NO == 1) UCE_GNF(true, 1); else UCE_GNF(true, 2); }
+      else { if (mp.NO == 1) UCE_GNF(false, 1); else UCE_GNF(false, 2); }
+#undef UCE_GNF
+      UCE_LAUNCH_CHECK();
+      return UCE_OK;
+    }
+  }
   if (dtype == UCE_DTYPE_F16) {
     hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
                        (const unsigned short*)addend, ws, HW, C, G, chunks, ald);

@@ -1003,7 +1003,10 @@ int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int
 static bool sattn_use_h(int qt_variant, int dh, int Lq, int Lk, int H, int B) {
   if (dh > 48) return false;
   if (qt_variant == 4) return true;
-  return qt_variant == 0 && (long)((Lq + 255) / 256) * H * B >= 1024 && Lk >= 512;
+  // (one prompt per call - 256 workgroups at L = 4096 - takes it too: 97 us against 113 for k_sattn behind the V^T pre-pass,
+  // profiles/r05/sattn_b1.jsonl; the 1024 / 256-token layers of that batch are launch-bound on every form)
+  const long wg = (long)((Lq + 255) / 256) * H * B;
+  return qt_variant == 0 && ((wg >= 1024 && Lk >= 512) || (wg >= 256 && Lk >= 2048));
 }
 
 // the kernel for one shape, with (VTI) or without the V^T pre-pass already run

@@ -41,7 +41,7 @@ def _f32c(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-from .sd.conv_dispatch import CONV_COLS_BYTES, conv_prefers_igemm, even_chunk  # noqa: E402  (rule of the convolution wrappers below)
+from .sd.conv_dispatch import CONV_COLS_BYTES, conv_takes_igemm, even_chunk  # noqa: E402  (rule of the convolution wrappers below)
 
 
 class UceHandle:
@@ -321,16 +321,22 @@ class UceHandle:
     def conv3x3_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                      max_cols_bytes: int = CONV_COLS_BYTES, upsample: bool = False, stride: int = 1,
                      residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """3x3 / pad 1 convolution of a channels-last [N, C, H, W] tensor: the implicit-GEMM kernels where the measured rule
-        (sd.conv_dispatch) says so or for stride 2, else patch matrix through uce_im2col3x3_nhwc + ONE library GEMM against the
-        channels-last weight viewed as [Cout, 9*C] (+ the residual join by uce_add_bias_nhwc_fwd); the batch is walked in
-        evenly sized chunks whose patch matrix stays under `max_cols_bytes`.
+        """3x3 / pad 1 convolution of a channels-last [N, C, H, W] tensor: ONE implicit-GEMM launch (uce_conv3x3_nhwc_fwd: stride 2,
+        fused upsample and the residual epilogue live there) for every shape that kernel family takes (sd.conv_dispatch), else the
+        patch matrix through uce_im2col3x3_nhwc + uce_linear_fwd against the channels-last weight viewed as [Cout, 9*C] (+ the
+        residual join by uce_add_bias_nhwc_fwd), the batch walked in evenly sized chunks whose patch matrix stays under
+        `max_cols_bytes`.  No library GEMM / convolution on either path.
         upsample: convolve the 2x nearest-neighbour upsampling of x (output [N, Cout, 2H, 2W]) without materialising it."""
         N, Cc, Hs, Ws = x.shape
         Hh, Ww = (2 * Hs, 2 * Ws) if upsample else (Hs // stride, Ws // stride)
         Cout = weight.shape[0]
-        if stride != 1 or conv_prefers_igemm(Hh, Ww, Cc, Cout, N):
+        if conv_takes_igemm(Cc, Cout, stride, residual is not None) and max_cols_bytes == CONV_COLS_BYTES:
             return self.conv3x3_igemm(x, weight, bias, upsample=upsample, stride=stride, residual=residual)
+        if stride != 1:
+            raise ValueError(f"stride-2 convolution {Cc} -> {Cout}: the implicit-GEMM kernels need Cin % 64 == 0 (or Cin % 32 == 0 "
+                             "with an output that 128 / 320-wide tiles divide)")
+        if (9 * Cc) % 32 or Cout % 4:
+            raise ValueError(f"3x3 convolution {Cc} -> {Cout}: the patch-matrix path needs 9 * Cin % 32 == 0 and Cout % 4 == 0")
         wmat = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc)      # a view for channels_last weights
         y = torch.empty((N, Cout, Hh, Ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         y_rows = y.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cout)     # NHWC view of the same storage
@@ -343,9 +349,7 @@ class UceHandle:
             _lib.check(self.lib.uce_im2col3x3_nhwc(self._h, xs[n0].data_ptr(), _ptr(cols), nb, Hh, Ww, Cc, int(upsample),
                                                    _stream_ptr(self.device)), "uce_im2col3x3_nhwc")
             rows = nb * Hh * Ww
-            dst = y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows]
-            # few pixel rows, a long contraction (the 16 x 16 / 8 x 8 layers): the GEMM library's stream-K kernels
-            torch.addmm(bias, cols[:rows], wmat.t(), out=dst) if bias is not None else torch.mm(cols[:rows], wmat.t(), out=dst)
+            self.linear(cols[:rows], wmat, bias, out=y_rows[n0 * Hh * Ww:n0 * Hh * Ww + rows])
         if residual is not None:
             return self.add_bias_nhwc(y, residual, None)
         return y
@@ -408,11 +412,14 @@ class UceHandle:
             N = weight.shape[0]
             dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
             xa, xb = x.reshape(-1, K1), x2.reshape(-1, K2)
-            xa = xa if xa.stride(1) == 1 else xa.contiguous()
-            xb = xb if xb.stride(1) == 1 else xb.contiguous()
+            def aligned(t):
+                return t if (t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0) else t.contiguous()
+            xa, xb = aligned(xa), aligned(xb)
             M = xa.shape[0]
             y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
             r2 = None if residual is None else residual.reshape(-1, N)
+            if r2 is not None and (r2.stride(1) != 1 or r2.stride(0) % 4 or r2.data_ptr() % 8):
+                r2 = r2.contiguous()
             ldr = 0 if r2 is None else r2.stride(0)
             w = weight if weight.is_contiguous() else weight.contiguous()
             _lib.check(self.lib.uce_linear_cat_fwd(self._h, _ptr(xa), xa.stride(0), _ptr(xb), xb.stride(0), K1, _ptr(w), _ptr(bias),
@@ -426,9 +433,9 @@ class UceHandle:
 
         def rows2d(t: torch.Tensor, cols: int):
             """(tensor, row stride) of a [..., cols] tensor as M rows: contiguous, or a 2-D view with a contiguous last dim"""
-            if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= cols:
+            if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= cols and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0:
                 return t, t.stride(0)
-            t = t.contiguous()
+            t = t.contiguous()                       # (also: a view at an odd offset / row stride - the kernel moves 16-byte pieces)
             return t, cols
 
         x2, ldx = rows2d(x, K)

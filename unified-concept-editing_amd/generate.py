@@ -82,14 +82,36 @@ def select_rows(df, from_case: int, till_case: int, rank: int, world: int):
     return [(i, r) for j, (i, r) in enumerate(picked) if j % world == rank]
 
 
+# activation + workspace footprint of one 512 x 512 image in flight through the build's own pipeline (CFG pair through the U-Net,
+# VAE decode, PNG staging), rounded up from the bench's 128 prompts per call on a 288 GB MI355X; the automatic batch keeps half of
+# the free HBM untouched
+AUTO_BATCH_BYTES_PER_IMAGE = 3 << 29          # 1.5 GB
+AUTO_BATCH_MAX_IMAGES = 128
+
+
+def auto_batch_prompts(pipe, dev: torch.device, num_images_per_prompt: int, n_rows: int) -> int:
+    """Rows per `pipe()` call when the caller left `--batch_prompts` at its default (0): rows are independent (each keeps its own
+    CPU-seeded latents, the draw of generate-images-sd.py:36,41), so the build's own pipeline on a GPU denoises as many per call as
+    half of the free HBM holds, at most 128 images - at one row per call (the reference's loop) the U-Net's layers have too few
+    output tiles to fill 256 CUs (2.2-3 images/s against 9.5 batched).  A foreign pipeline object (real diffusers, a test double)
+    and CPU runs keep the reference's one row per call."""
+    if dev.type != "cuda" or not isinstance(pipe, sdp.StableDiffusionPipeline) or n_rows <= 1:
+        return 1
+    free, _ = torch.cuda.mem_get_info(dev)
+    side = getattr(getattr(pipe.unet, "cfg", None), "sample_size", 64) / 64.0          # (SDXL: 128 x 128 latents, 4x the pixels)
+    images = max(1, min(AUTO_BATCH_MAX_IMAGES, int(free // 2 // int(AUTO_BATCH_BYTES_PER_IMAGE * side * side))))
+    return max(1, min(n_rows, images // max(1, int(num_images_per_prompt))))
+
+
 def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name="test", device="cuda:0",
                     torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=100,
                     num_images_per_prompt=10, from_case=0, till_case=1000000, model_dir=None, synthetic=False,
-                    latents_only=False, skip_existing=False, pipe=None, batch_prompts: int = 1,
+                    latents_only=False, skip_existing=False, pipe=None, batch_prompts: int = 0,
                     png_workers: int = 4) -> Dict[str, float]:
     """evalscripts/generate-images-sd.py:10-46.  `batch_prompts` CSV rows are denoised as one batch (each row
     still draws its latents from its own CPU generator seeded with `evaluation_seed`, exactly the draw the
-    reference makes row by row); file names and contents per image are those of the row-by-row loop."""
+    reference makes row by row); file names and contents per image are those of the row-by-row loop.  0 (the default) picks the
+    batch from the free HBM (`auto_batch_prompts`); 1 is the reference's loop."""
     import pandas as pd
     rank, world, local = dist_env()
     dev = torch.device(device)
@@ -119,7 +141,9 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
     n_img = 0
     todo = [row for _, row in mine
             if not (skip_existing and os.path.exists(f"{folder_path}/{row.case_number}_0.png"))]
-    batch_prompts = max(1, int(batch_prompts))
+    batch_prompts = int(batch_prompts)
+    if batch_prompts <= 0:
+        batch_prompts = auto_batch_prompts(pipe, dev, num_images_per_prompt, len(todo))
     # PNG encoding (host, ~30 ms per 512x512 image) runs on worker threads behind the next batch's denoising
     writer = ThreadPoolExecutor(max_workers=png_workers) if (png_workers > 0 and not latents_only) else None
     pending = []
@@ -152,7 +176,8 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    stats = {"images": float(n_img), "seconds": elapsed, "rank": float(rank), "world": float(world)}
+    stats = {"images": float(n_img), "seconds": elapsed, "rank": float(rank), "world": float(world),
+             "batch_prompts": float(batch_prompts)}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([float(n_img), elapsed], dtype=torch.float64, device=dev)

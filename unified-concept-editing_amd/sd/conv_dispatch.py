@@ -1,7 +1,6 @@
-"""Which path a 3x3 / stride 1 / pad 1 convolution of the U-Net / VAE takes (sd/unet.py -> UceHandle.conv3x3_nhwc): the
-implicit-GEMM kernels (uce_conv3x3_nhwc_fwd) or im2col + one library GEMM, and how a batch is walked in chunks.  Host
-logic only - measured on an MI355X with tools/probe_igemm.py; UCE_CONV_IGEMM / UCE_CONV_COLS_MB override it for A/B runs
-(read once, at import)."""
+"""Which path a 3x3 / pad 1 convolution of the U-Net / VAE takes (sd/unet.py -> UceHandle.conv3x3_nhwc): the implicit-GEMM kernels
+(uce_conv3x3_nhwc_fwd) for every shape they exist for, the patch matrix + uce_linear_fwd for the rest, and how a batch is walked
+in chunks.  Host logic only; UCE_CONV_COLS_MB overrides the chunk size for measurements (read once, at import)."""
 from __future__ import annotations
 
 import os
@@ -10,38 +9,17 @@ import os
 CONV_COLS_BYTES = int(os.environ.get("UCE_CONV_COLS_MB", "4096")) << 20
 
 
-# which 3x3 convolutions go through the implicit-GEMM kernel instead of im2col + library GEMM: "auto" = where it measured
-# faster on an MI355X (tools/probe_igemm.py: the high-resolution, narrow layers of the VAE decoder - 2.7x at 128 -> 128
-# channels on 512 x 512 - where the patch matrix is all traffic and no arithmetic), "always", "never"
-CONV_IGEMM = os.environ.get("UCE_CONV_IGEMM", "auto")
-
-
-def conv_prefers_igemm(H: int, W: int, Cin: int, Cout: int, N: int = 32, stride: int = 1) -> bool:
-    """Measured on an MI355X (tools/probe_igemm.py, tools/probe_r04.py, bf16): the implicit-GEMM kernels run 800-1110 TF/s
-    (direct-to-LDS form, outputs of 128 / 256 / 320-multiples) or 600-820 TF/s (128 x 128 register-staged form) once there are
-    enough pixel tiles; the library GEMM (stream-K) reaches 0.85-1.25 PF/s on the small-spatial, wide layers but pays the
-    patch-matrix round trip everywhere.  (H, W) = OUTPUT size.  stride 2 (Downsample2D): the direct-to-LDS kernel against
-    MIOpen - 81-139 us against 167-191 at the generation batch, wherever there are at least 64 pixel tiles."""
-    if CONV_IGEMM == "never" or Cin % 32 or Cout % 8:
+def conv_takes_igemm(Cin: int, Cout: int, stride: int = 1, residual: bool = False) -> bool:
+    """uce_conv3x3_nhwc_fwd has a kernel for the layer (csrc/uce_conv_igemm.hip's dispatch, restated): 128-byte k-tiles
+    (Cin % 64 == 0) on any Cout % 8 == 0 - the wide direct-to-LDS forms where a 128 / 256 / 320-wide tile divides Cout, the few-tile
+    forms with the split contraction elsewhere - or 64-byte k-tiles (Cin % 32 == 0) on outputs that a 128- / 320-wide tile
+    divides.  Everything else (no layer of SD-1.x / SD-2.x / SDXL or their VAEs) goes through the patch matrix
+    (uce_im2col3x3_nhwc) + uce_linear_fwd, which has no stride-2 form.  No library convolution or GEMM is behind either path."""
+    if Cin % 32 or Cout % 8:
         return False
-    if CONV_IGEMM == "always":
+    if Cout % 128 == 0 or Cout % 320 == 0:
         return True
-    M = N * H * W
-    if stride == 2:
-        return (Cout % 128 == 0 or Cout % 320 == 0) and M >= 8192
-    if Cin % 64 and Cout % 128 and Cout % 320:       # (the register-staged fallback kernel needs 64-channel chunks)
-        return False
-    if M >= 128 * 1024:                              # U-Net 64 x 64 at the generation batch, every VAE layer >= 128^2
-        return True
-    # 32 x 32 layers: the direct-to-LDS form (outputs that are multiples of 256 / 320 channels: 835-1113 TF/s against
-    # 736-761 for im2col + GEMM) or a long contraction on the 128 x 128 kernel; 16 x 16 and 8 x 8 layers have too few
-    # pixel tiles for either (1280 -> 1280 @ 16 x 16 x 32: 284 us with 128-pixel tiles against 225 for im2col + library GEMM;
-    # @ 8 x 8: 141 against 93)
-    if M >= 32 * 1024 and (Cin >= 640 or Cout % 256 == 0 or Cout % 320 == 0):
-        return True
-    # 16 x 16 at 32 samples: with 128-byte k-tiles and 128-pixel tiles the direct-to-LDS kernel ties im2col + library GEMM (1280 ->
-    # 1280: 229 us against 221) as soon as every CU gets a 128 x 320 tile - and needs no patch matrix
-    return Cin % 64 == 0 and Cout % 320 == 0 and -(-M // 128) * (Cout // 320) >= 256
+    return Cin % 64 == 0
 
 
 def even_chunk(n: int, cap: int) -> int:

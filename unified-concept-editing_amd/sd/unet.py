@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv_dispatch import conv_prefers_igemm
+from .conv_dispatch import conv_takes_igemm
 
 
 @dataclass
@@ -156,18 +156,19 @@ def add_layer_norm(norm: nn.LayerNorm, a: torch.Tensor, x: torch.Tensor):
     return s, norm(s)
 
 
-def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
-    return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+def _conv3x3_fast_ok(conv: nn.Conv2d, x: torch.Tensor, strides=((1, 1),)) -> bool:
+    return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride in strides
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels >= 4
-            and conv.in_channels % 32 == 0 and conv.out_channels % 8 == 0
-            and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
+            and conv.in_channels % 32 == 0 and conv.out_channels % 8 == 0 and conv.weight.dtype == x.dtype)
 
 
-def _conv3x3_epilogue_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
-    """the direct-to-LDS kernel takes the layer (stride 2 and the residual epilogue exist only there)"""
-    return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.in_channels % 32 == 0 and (conv.out_channels % 128 == 0 or conv.out_channels % 320 == 0)
-            and conv.weight.dtype == x.dtype and conv.weight.is_contiguous(memory_format=torch.channels_last))
+def _w_cl(conv: nn.Conv2d) -> torch.Tensor:
+    """The convolution weight in channels-last memory format ([Cout, ky, kx, Cin] rows: what the kernels contract over) - the
+    parameter itself when the model was laid out that way (sd.pipeline does), else a cached copy."""
+    w = conv.weight
+    if w.is_contiguous(memory_format=torch.channels_last):
+        return w
+    return derived(conv, "w_cl", _pkey(w), lambda: w.detach().contiguous(memory_format=torch.channels_last))
 
 
 def conv_c4_weight(conv: nn.Conv2d):
@@ -185,8 +186,7 @@ def conv_c4_weight(conv: nn.Conv2d):
 def _conv3x3_narrow_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
     return (_hip_nhwc_ok(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels < 8
-            and conv.in_channels % 64 == 0 and conv.weight.dtype == x.dtype
-            and x.shape[0] * x.shape[2] * x.shape[3] >= 128 * 1024)
+            and conv.in_channels % 32 == 0 and conv.weight.dtype == x.dtype)
 
 
 def _padded_out_channels(conv: nn.Conv2d):
@@ -208,19 +208,24 @@ def _padded_out_channels(conv: nn.Conv2d):
 
 
 def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`conv(x)` (+ residual).  Channels-last 16-bit activations on a GPU: 3x3 / pad 1 convolutions (stride 1, stride 2 of
-    Downsample2D, the 4-channel conv_in) go through uce_conv3x3_nhwc_fwd / uce_im2col3x3_nhwc, 1x1 convolutions through
-    uce_linear_fwd on the pixel rows; everything else (CPU, fp32) is torch."""
+    """`conv(x)` (+ residual).  16-bit activations on a GPU: 3x3 / pad 1 convolutions (stride 1, stride 2 of Downsample2D, the
+    4-channel conv_in, the 3- / 4-channel conv_out) go through uce_conv3x3_nhwc_fwd / uce_im2col3x3_nhwc + uce_linear_fwd, 1x1
+    convolutions through uce_linear_fwd on the pixel rows; a 16-bit GPU convolution none of them takes RAISES - there is no
+    library convolution behind the product path.  CPU / fp32 tensors (tests, comparison runs): torch."""
     bias = conv.bias if with_bias else None
-    if (residual is not None or conv.stride == (2, 2)) and conv.stride in ((1, 1), (2, 2)) and _conv3x3_epilogue_ok(conv, x) \
-            and (x.shape[2] % conv.stride[0] == 0 and x.shape[3] % conv.stride[1] == 0) \
-            and conv_prefers_igemm(x.shape[2] // conv.stride[0], x.shape[3] // conv.stride[1], conv.in_channels, conv.out_channels,
-                                   x.shape[0], stride=conv.stride[0]):
+    if hip16(x) and x.dim() == 4 and x.shape[1] % 8 == 0 and not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)          # (the kernels read pixels as rows of channels)
+    if _conv3x3_fast_ok(conv, x, strides=((1, 1), (2, 2))) and x.shape[2] % conv.stride[0] == 0 and x.shape[3] % conv.stride[1] == 0:
         from .. import edit as _edit
-        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias, stride=conv.stride[0], residual=residual)
-    if _conv3x3_fast_ok(conv, x):
-        from .. import edit as _edit
-        y = _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, bias)
+        hd = _edit.UceHandle.get(x.device)
+        if conv_takes_igemm(conv.in_channels, conv.out_channels):
+            # ONE launch: stride-2 taps and the residual join live in the implicit-GEMM kernels
+            return hd.conv3x3_nhwc(x, _w_cl(conv), bias, stride=conv.stride[0], residual=residual)
+        # channel counts off those kernels' granules (no layer of SD): the patch matrix + uce_linear_fwd at stride 1; a stride-2
+        # output is every second pixel of it (pad 1: output (i, j) is centred on source (2 i, 2 j))
+        y = hd.conv3x3_nhwc(x, _w_cl(conv), bias)
+        if conv.stride == (2, 2):
+            y = y[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
         return y if residual is None else add_bias(y, residual, None)
     if hip16(x) and x.dim() == 4 and conv.in_channels == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) \
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels % 4 == 0 \
@@ -230,22 +235,26 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor, with_bias: bool = True, residual: O
         y = _edit.UceHandle.get(x.device).conv3x3_c4(x, conv_c4_weight(conv), bias)
         return y if residual is None else add_bias(y, residual, None)
     if _conv3x3_narrow_ok(conv, x):
-        # a 3- / 4-channel output (the VAE's conv_out): the implicit-GEMM kernel on the weight zero-padded to 8 output
-        # channels (its 16-byte store granule), result sliced back - 0.9 ms against 2.6 ms for the library's direct kernel
+        # a 3- / 4-channel output (the VAE's conv_out, the U-Net's conv_out): the implicit-GEMM kernel on the weight zero-padded to 8
+        # output channels (its 16-byte store granule), result sliced back - 0.9 ms against 2.6 ms for the library's direct kernel
         # at 16 x 512 x 512 x 128
         from .. import edit as _edit
         w8, b8 = _padded_out_channels(conv)
-        y8 = _edit.UceHandle.get(x.device).conv3x3_igemm(x, w8, b8 if with_bias else None)
+        y8 = _edit.UceHandle.get(x.device).conv3x3_nhwc(x, w8, b8 if with_bias else None)
         y = y8[:, :conv.out_channels]
         return y if residual is None else y + residual
-    if _hip_nhwc_ok(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) \
-            and conv.groups == 1 and conv.weight.dtype == x.dtype and conv.in_channels % 32 == 0 and conv.out_channels % 4 == 0:
-        # a 1x1 convolution of a channels-last tensor IS a linear layer over the pixel rows
+    if hip16(x) and x.dim() == 4 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) \
+            and conv.groups == 1 and conv.weight.dtype == x.dtype:
+        # a 1x1 convolution IS a linear layer over the pixel rows (a view for channels-last tensors)
         N, Cin, Hh, Ww = x.shape
         rows = x.permute(0, 2, 3, 1).reshape(N * Hh * Ww, Cin)
         res = None if residual is None else _nhwc_rows(residual)
         y = linear_w(rows, conv.weight.reshape(conv.out_channels, Cin), bias, res)
         return y.view(N, Hh, Ww, conv.out_channels).permute(0, 3, 1, 2)
+    if hip16(x):
+        raise RuntimeError(f"convolution {tuple(conv.weight.shape)} stride {conv.stride} padding {conv.padding} groups {conv.groups} of a "
+                           f"{tuple(x.shape)} {x.dtype} tensor has no HIP kernel (3x3 / pad 1 with stride 1 or 2, or 1x1; input channels 4 "
+                           "or a multiple of 32; channels-last activations and weights)")
     y = F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     return y if residual is None else y + residual
 
@@ -258,31 +267,59 @@ def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------ linear layers
 
-LINEAR_MIN_TILES = int(os.environ.get("UCE_LINEAR_MIN_TILES", "256"))     # (A/B runs only)
 # up blocks read x and the skip connection in place (two-source GroupNorm + two-source shortcut GEMM): no torch.cat.  Measured
 # on one box at 64 prompts per call: 8.76 / 8.79 -> 9.01 images/s (profiles/r04/ab_session2); UCE_CAT_FREE=0 keeps the copy
 CAT_FREE = os.environ.get("UCE_CAT_FREE", "1") != "0"
 
 
 def _hip_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
-    """uce_linear_fwd takes the layer.  Measured rule (tools/probe_r04.py, MI355X): its 128 / 256-row output tiles have no
-    split over the contraction, so a layer that cannot give every CU a 128 x 320 tile (the 8 x 8 mid block at the generation
-    batch; at the CLI's one-prompt batch everything but the widest 64 x 64 projections) stays with the GEMM library's stream-K
-    kernels, like the small-spatial convolutions (sd/conv_dispatch.py): row by row, 2.0 -> 3 images/s."""
-    if not (hip16(x) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
-            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0):
-        return False
-    rows = x.numel() // x.shape[-1]
-    return -(-rows // 128) * -(-weight.shape[0] // 320) >= LINEAR_MIN_TILES
+    """uce_linear_fwd takes the layer as it is: 16-bit operands of one dtype on a GPU, a contraction the 64-byte k-tiles divide, an
+    output the 8-byte epilogue accesses divide.  (Whatever the row count: layers with few output tiles take the kernel's split-
+    contraction forms, csrc/uce_splitk.h.)"""
+    return (hip16(x) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0)
+
+
+def _padded_linear(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """(weight, bias) zero-padded to a contraction of a multiple of 32 and an output of a multiple of 4 (the granules of
+    uce_linear_fwd), cached per source tensors."""
+    N, K = weight.shape
+    Np, Kp = -(-N // 4) * 4, -(-K // 32) * 32
+    w = torch.zeros(Np, Kp, dtype=weight.dtype, device=weight.device)
+    w[:N, :K] = weight.detach()
+    b = None
+    if bias is not None:
+        b = torch.zeros(Np, dtype=bias.dtype, device=bias.device)
+        b[:N] = bias.detach()
+    return w, b
+
+
+_PAD_CACHE: dict = {}
 
 
 def linear_w(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`x @ weight.T (+ bias) (+ residual)`: uce_linear_fwd (one launch, the residual join in its epilogue) for 16-bit
-    activations on a GPU, torch ops otherwise."""
+    """`x @ weight.T (+ bias) (+ residual)`: uce_linear_fwd (one launch, the residual join in its epilogue) for 16-bit activations on
+    a GPU - a contraction / output width off its granules runs zero-padded (the VAE's 4-channel post_quant_conv), operands of mixed
+    dtypes RAISE: there is no library GEMM behind the product path.  CPU / fp32 tensors (tests, comparison runs): torch."""
     if _hip_linear_ok(x, weight, bias):
         from .. import edit as _edit
         return _edit.UceHandle.get(x.device).linear(x, weight, bias, residual)
+    if hip16(x):
+        if weight.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype) or x.shape[-1] != weight.shape[1]:
+            raise RuntimeError(f"linear layer {tuple(weight.shape)} {weight.dtype} on a {tuple(x.shape)} {x.dtype} tensor has no HIP kernel "
+                               "(operands of one 16-bit dtype)")
+        from .. import edit as _edit
+        N, K = weight.shape
+        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), x.dtype)
+        ent = _PAD_CACHE.get(id(weight))
+        if ent is None or ent[0] != key or ent[1] is not weight:
+            ent = (key, weight, _padded_linear(weight, bias))
+            _PAD_CACHE[id(weight)] = ent
+        wp, bp = ent[2]
+        xp = x if wp.shape[1] == K else F.pad(x, (0, wp.shape[1] - K))
+        y = _edit.UceHandle.get(x.device).linear(xp.contiguous(), wp, bp)[..., :N]
+        return y if residual is None else y + residual
     y = F.linear(x, weight, bias)
     return y if residual is None else y + residual
 
@@ -291,17 +328,31 @@ def linear(lin: nn.Linear, x: torch.Tensor, residual: Optional[torch.Tensor] = N
     return linear_w(x, lin.weight, lin.bias, residual)
 
 
+class _SrcKey(tuple):
+    """Key of a derived tensor: (storage address, version, dtype) of every source parameter AND the source tensors themselves - an
+    entry holds its sources alive, so the allocator cannot hand their address to a replacement tensor while the entry exists, and a
+    replaced parameter (`module.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`) is a different object: no stale hit."""
+    srcs: tuple = ()
+
+    def same(self, other) -> bool:
+        return (isinstance(other, _SrcKey) and tuple.__eq__(self, other) and len(self.srcs) == len(other.srcs)
+                and all(a is b for a, b in zip(self.srcs, other.srcs)))
+
+
 def _pkey(*params) -> tuple:
-    return tuple((p.data_ptr(), p._version, p.dtype) for p in params if p is not None)
+    live = tuple(p for p in params if p is not None)
+    k = _SrcKey((p.data_ptr(), p._version, p.dtype) for p in live)
+    k.srcs = live
+    return k
 
 
 def derived(mod: nn.Module, name: str, key: tuple, build):
     """A tensor derived from a module's parameters (packed q|k|v rows, interleaved GEGLU rows, concatenated time projections),
-    cached on the module and rebuilt when `key` (storage + version of the sources) changes.  Writers that go around the version
-    counter (sd.pipeline.patch_unet) call clear_derived."""
+    cached on the module and rebuilt when `key` (identity + storage + version of the sources) changes.  Writers that go around the
+    version counter (sd.pipeline.patch_unet) call clear_derived."""
     cache = mod.__dict__.setdefault("_uce_derived", {})
     ent = cache.get(name)
-    if ent is None or ent[0] != key:
+    if ent is None or not (ent[0].same(key) if isinstance(ent[0], _SrcKey) else ent[0] == key):
         ent = (key, build())
         cache[name] = ent
     return ent[1]
@@ -334,7 +385,7 @@ def upsample2x_conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     matrix is gathered straight from the half-resolution tensor, the upsampled activation is never written."""
     if _conv3x3_fast_ok(conv, x):
         from .. import edit as _edit
-        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, conv.weight, conv.bias, upsample=True)
+        return _edit.UceHandle.get(x.device).conv3x3_nhwc(x, _w_cl(conv), conv.bias, upsample=True)
     return conv2d(conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
@@ -376,8 +427,7 @@ class ResnetBlock2D(nn.Module):
             return False
         rows = x.shape[0] * x.shape[2] * x.shape[3]
         w = sc.weight
-        return (sc.kernel_size == (1, 1) and w.dtype == x.dtype and w.shape[0] % 4 == 0
-                and -(-rows // 128) * -(-w.shape[0] // 320) >= LINEAR_MIN_TILES)
+        return sc.kernel_size == (1, 1) and w.dtype == x.dtype and w.shape[0] % 4 == 0 and rows > 0
 
     def forward(self, x, temb, skip: Optional[torch.Tensor] = None):
         """`skip`: the block runs on torch.cat([x, skip], dim=1) (up blocks) - read in place where the kernels allow it."""
@@ -665,7 +715,7 @@ class UNet2DConditionModel(nn.Module):
     def cache_context(self, context: Optional[torch.Tensor]) -> None:
         for m in self.modules():
             if isinstance(m, Attention) and m.is_cross:
-                m.kv_cache = None if context is None else (m.to_k(context), m.to_v(context))
+                m.kv_cache = None if context is None else (linear(m.to_k, context), linear(m.to_v, context))
 
     # -- the 22 (SDXL: 17 + ...) time projections of the ResnetBlock2Ds read the same `silu(temb)`: ONE linear launch over
     #    their weights stacked along the rows (bias = time_emb_proj.bias + conv1.bias, the addend norm2's kernel takes),
@@ -710,12 +760,19 @@ class UNet2DConditionModel(nn.Module):
             tid = timestep_embedding(time_ids.flatten(), self.cfg.addition_time_embed_dim).reshape(text_embeds.shape[0], -1)
             temb = temb + self.add_embedding(torch.cat([text_embeds, tid.to(text_embeds.dtype)], dim=-1).to(sample.dtype))
         self._hoist_time_projections(temb)
-        x = conv2d(self.conv_in, sample)
-        skips = [x]
-        for blk in self.down_blocks:
-            x, outs = blk(x, temb, encoder_hidden_states)
-            skips.extend(outs)
-        x = self.mid_block(x, temb, encoder_hidden_states)
-        for blk in self.up_blocks:
-            x = blk(x, skips, temb, encoder_hidden_states)
+        try:
+            x = conv2d(self.conv_in, sample)
+            skips = [x]
+            for blk in self.down_blocks:
+                x, outs = blk(x, temb, encoder_hidden_states)
+                skips.extend(outs)
+            x = self.mid_block(x, temb, encoder_hidden_states)
+            for blk in self.up_blocks:
+                x = blk(x, skips, temb, encoder_hidden_states)
+        finally:
+            # the slices belong to THIS call's time embedding: a block used on its own afterwards computes its projection itself
+            # (and the stacked projection is not kept alive between calls)
+            for m in self.modules():
+                if isinstance(m, ResnetBlock2D):
+                    m.temb_addend = None
         return conv2d(self.conv_out, group_norm_act(self.conv_norm_out, x, True))
