@@ -27,11 +27,14 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import shutil
+import tempfile
 import socket
 import statistics
 import subprocess
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -415,6 +418,14 @@ def config_leg(H, name: str, device, algo: int):
                kernels=[dict(kernel=k["kernel"], avg_ms=k["avg_ms"], launches_per_step=k["launches_per_step"], share=k["share"],
                              frac=k["frac"], bound=k["bound"], traffic=k["traffic"], **({"mfma_util": k["mfma_util"]} if "mfma_util" in k else {}))
                         for k in r["kernels"]])
+    # the arithmetic type of the leg's products (the headline's `dtype` covers the project + update form of the small configs)
+    names = " ".join(k["kernel"] for k in out["kernels"])
+    if "apply_h2" in names or "k_apply_h2" in names:
+        out["dtype"] = ("f64 Gram / Cholesky / inverse; dense apply W_old (I + Delta) in f32 via a two-term f16 split of both operands "
+                        "(2 x 11 significand bits per operand under per-row / per-column power-of-two scales, f32 accumulate; "
+                        "3.2e-7 from fp64 on this config)")
+    else:
+        out["dtype"] = "f32 products on the f32 matrix cores, f64 Gram / Cholesky / solves"
     del r
     torch.cuda.empty_cache()
     return out
@@ -528,6 +539,44 @@ def count_generation_flops(pipe, device, steps: int):
             "context_projections_once": sum(once.values()), "per_image": per_image, "per_image_by_family": tot}
 
 
+def generation_roofline(pipe, device, steps: int, seconds_per_image: float, batch: int):
+    """The images/s half of the metric against the chip: counted MFMA FLOPs per image (count_generation_flops) over the measured
+    seconds per image of ONE rank -> achieved PFLOP/s and its fraction of the dense bf16 peak; per kernel family, the counted FLOPs
+    over the family's share of the image time (shares from the committed steady-state rocprofv3 profile of the same loop at the
+    same prompts per call, profiles/r05/generate_families_b<batch>.json, when there is one)."""
+    fl = count_generation_flops(pipe, device, steps)
+    per_image = fl["per_image"]
+    ach = per_image / seconds_per_image / 1e15
+    out = {"bound": "mfma", "unit": "PFLOP/s", "algorithmic_flops_per_image": per_image,
+           "flops_per_unet_call_cfg_pair": fl["unet_call_cfg_pair"], "unet_calls_per_image": fl["unet_calls"],
+           "vae_decode_flops": fl["vae_decode"], "flops_per_image_by_family": fl["per_image_by_family"],
+           "seconds_per_image": round(seconds_per_image, 5), "achieved": round(ach, 4), "peak": BF16_MFMA_PEAK_TF / 1e3,
+           "frac": round(ach / (BF16_MFMA_PEAK_TF / 1e3), 4),
+           "floor_seconds_per_image": round(per_image / (BF16_MFMA_PEAK_TF * 1e12), 5),
+           "note": "FLOPs counted from the build's own U-Net / VAE (2 M N K per linear layer and convolution tap, 4 B L Lk C per attention); "
+                   "norms, activations, text encoder, host work are in the seconds but not in the FLOPs"}
+    for cand in (batch, 128, 64):
+        path = os.path.join(ROOT, "profiles", "r05", f"generate_families_b{cand}.json")
+        if os.path.exists(path):
+            try:
+                fam = json.load(open(path))
+                shares = {k: v["share"] for k, v in fam["families"].items()}
+                out["families"] = {
+                    k: {"time_share": shares.get(k), "flops_share": round(fl["per_image_by_family"].get(k, 0.0) / per_image, 4),
+                        "achieved_PFs": (round(fl["per_image_by_family"][k] / (shares[k] * seconds_per_image) / 1e15, 4)
+                                         if k in fl["per_image_by_family"] and shares.get(k) else None)}
+                    for k in sorted(set(shares) | set(fl["per_image_by_family"]))}
+                out["families_profile"] = os.path.relpath(path, ROOT)
+                out["families_profile_prompts_per_call"] = cand
+                out["families_note"] = ("time shares: kernel time of the steady denoising loop under rocprofv3 (eager launches); per-family PF/s = "
+                                        "counted FLOPs / (share x seconds per image), i.e. it charges the family with its share of the "
+                                        "host / VAE time too")
+            except Exception as err:  # noqa: BLE001
+                out["families"] = {"error": repr(err)}
+            break
+    return out
+
+
 def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_id="CompVis/stable-diffusion-v1-4",
                    dtype=torch.bfloat16, vae=True, rowwise_images=0, keep_pipe=None):
     """Secondary figure (BASELINE.json's second metric): images/s of the edited SD-1.4 pipeline,
@@ -589,6 +638,22 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
                 run(0, count, 2)
         except Exception as err:  # noqa: BLE001
             failure = f"warm-up: {err!r}"
+    # The reference's loop ends in `im.save(...)` (generate-images-sd.py:45-46): the PNGs are encoded and written INSIDE the timed
+    # region, on worker threads behind the next batch's denoising exactly as uce_amd.generate.generate_images does it (same default
+    # worker count, capped so that `world` ranks never ask for more threads than the node has cores), and the clock stops only
+    # when the last file is on disk.
+    png_dir = tempfile.mkdtemp(prefix="uce_bench_png_") if vae else None
+    ncores = os.cpu_count() or 8
+    png_workers = max(1, min(4, ncores // max(1, world) - 1))
+    writer = ThreadPoolExecutor(max_workers=png_workers) if vae else None
+    pending = []
+    png_cpu_s = [0.0]
+
+    def save_png(im, path):
+        t = time.thread_time()
+        im.save(path)
+        png_cpu_s[0] += time.thread_time() - t                       # (a float add under the GIL: good enough for a report)
+
     if world > 1:
         torch.distributed.barrier()
     _sync(device)
@@ -599,11 +664,24 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
             for lo, count in chunks:
                 if rank == fail_rank:
                     raise RuntimeError("injected failure (UCE_BENCH_FAIL_RANK)")
-                run(lo, count, steps)                             # -> PIL images on the host, as pipe(...).images
+                res = run(lo, count, steps)                       # -> PIL images on the host, as pipe(...).images
+                if writer is not None:
+                    for j, im in enumerate(res.images):
+                        pending.append(writer.submit(save_png, im, os.path.join(png_dir, f"{mine[lo + j][0]}_0.png")))
+            for f in pending:
+                f.result()
         except Exception as err:  # noqa: BLE001
             failure = f"timed loop: {err!r}"
     _sync(device)
     mine_s = time.perf_counter() - t0                             # this rank's own loop, before it waits for the others
+    if writer is not None:
+        writer.shutdown(wait=True)
+    png_bytes = 0
+    if png_dir is not None:
+        try:
+            png_bytes = sum(os.path.getsize(os.path.join(png_dir, f)) for f in os.listdir(png_dir))
+        finally:
+            shutil.rmtree(png_dir, ignore_errors=True)
     cpu1 = os.times()
     host_cpu_s = (cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)   # this process, all its threads (CPU RNG, tokenizer, image conversion)
     if world > 1:
@@ -649,9 +727,20 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
            # node needs 8 x this per wall second of generation from its host cores
            "host_cpu_seconds_per_image": round(host_cpu_s / max(n_images, 1), 4),
            "host_cpu_cores_busy": round(host_cpu_s / max(mine_s, 1e-9), 3)}
+    if vae:
+        out["png"] = {"in_timed_region": True, "workers_per_rank": png_workers, "cpu_seconds_per_image": round(png_cpu_s[0] / max(n_images, 1), 4),
+                      "bytes_per_image": int(png_bytes / max(n_images, 1)),
+                      "note": "im.save of every image (generate-images-sd.py:45-46) on worker threads; the clock stops after the last file"}
     if rowwise is not None:
         out["rowwise"] = {"value": round(world * rowwise, 4), "unit": "images/s", "prompts_per_unet_call": 1, "images": rowwise_images,
-                          "note": "the CLI default --batch_prompts 1: one pipe() call per CSV row like generate-images-sd.py:29-42"}
+                          "note": "--batch_prompts 1: one pipe() call per CSV row like generate-images-sd.py:29-42 (every layer on the "
+                                  "few-tile kernel forms; no library GEMM / convolution). The CLI default (--batch_prompts 0) batches rows "
+                                  "automatically and runs at `value` above" + (f"; rank 0's figure x {world}" if world > 1 else "")}
+    if rank == 0:
+        try:
+            out["roofline"] = generation_roofline(pipe, device, steps, el / max(world * n_images, 1) * world, batch)
+        except Exception as err:  # noqa: BLE001
+            out["roofline"] = {"error": repr(err)}
     if bcast_ms is not None:
         out["weight_broadcast_ms"] = round(bcast_ms, 3)
     if keep_pipe is not None:
@@ -875,7 +964,7 @@ def main() -> None:
         return
     if args.only == "generate":         # the images/s leg alone (unedited synthetic weights), for A/B runs
         g = generation_leg(device, world, args.gen_images, args.gen_steps, None, args.gen_batch,
-                           rowwise_images=args.gen_rowwise if world == 1 else 0)
+                           rowwise_images=args.gen_rowwise if world == 1 else min(args.gen_rowwise, 2))
         if rank == 0:
             print(json.dumps(g), flush=True)
         return
@@ -923,7 +1012,7 @@ def main() -> None:
         kept = []
         result["generate"] = generation_leg(device, world, args.gen_images, args.gen_steps,
                                             out if out.shape[1] == 768 else None, args.gen_batch,
-                                            rowwise_images=args.gen_rowwise if world == 1 else 0, keep_pipe=kept)
+                                            rowwise_images=args.gen_rowwise if world == 1 else min(args.gen_rowwise, 2), keep_pipe=kept)
         if rank == 0 and world == 1 and kept and not args.no_configs:
             import tempfile
             try:

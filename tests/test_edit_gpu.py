@@ -112,22 +112,24 @@ def _handle_with(env_name, value):
             os.environ[env_name] = old
 
 
-@pytest.mark.parametrize("variant", ["1", "0"])
-@pytest.mark.parametrize("rows_,d", [(128, 128), (1000, 768), (333, 1024)])
-def test_apply_other_forms_match_f64(variant, rows_, d):
-    """UCE_APPLY_VARIANT=1 (three-way bf16 split) and 0 (f32 MFMA): the forms the default two-way f16 split replaced stay
-    correct - they are what a shape outside its buffer descriptors falls back to."""
-    rng = np.random.Generator(np.random.PCG64(rows_ + 1))
-    W = O.linear_default_weight(rows_, d, rng)
-    DT = (rng.standard_normal((d, d)) * (0.5 / math.sqrt(d))).astype(np.float32)
+def test_apply_beyond_one_buffer_descriptor_walks_row_chunks(H):
+    """A slab of more than 2 GB (the reach of the dense apply's buffer descriptors): uce_apply walks it in row chunks - rows are
+    independent, so every block of the big result carries the bits the same rows give as a small slab of their own."""
+    d = 768
+    rows_ = (1 << 31) // (4 * d) + 5000                                   # 2.16 GB of f32 weights: two chunks
+    g = torch.Generator(device="cuda").manual_seed(5)
+    W = (torch.rand(rows_, d, device="cuda", generator=g) - 0.5) * (2.0 / math.sqrt(d))
+    DT = torch.randn(d, d, device="cuda", generator=g) * (0.5 / math.sqrt(d))
     DT[0, 1] += 3.0
-    Hv = _handle_with("UCE_APPLY_VARIANT", variant)
-    try:
-        out = Hv.apply(_dev(W), _dev(DT)).cpu()
-    finally:
-        Hv.close()
-    want = W.astype(np.float64) + W.astype(np.float64) @ DT.astype(np.float64).T
-    assert O.rel_fro(out, want) < 2e-6
+    out = H.apply(W, DT)
+    for r0 in (0, rows_ // 2 - 700, rows_ - 1500):                        # first chunk, across the chunk boundary, tail
+        blk = W[r0:r0 + 1400].contiguous()
+        small = H.apply(blk, DT)
+        assert torch.equal(out[r0:r0 + 1400], small)
+        want = blk.double() + blk.double() @ DT.double().T
+        assert O.rel_fro(small.cpu(), want.cpu()) < 2e-6
+    del out, W
+    torch.cuda.empty_cache()
 
 
 def test_apply_f16_split_scales_rows_and_columns(H):
@@ -265,23 +267,6 @@ def test_erase_golden(H, name, algo, tile):
         pytest.skip("dual form is for N < d")
     out = _run_case(H, c, algo, tile)
     _check_replicas(out, torch.cat(c.w_exact64()), torch.cat(c.w_ref32()), tile)
-
-
-@pytest.mark.parametrize("fused", ["1", "2"])
-@pytest.mark.parametrize("name", ["erase_n2p3_d768", "erase_n50_d768", "erase_quirks_d768", "erase_n12p4_d1024", "erase_n36p4_d2048"])
-def test_erase_golden_one_launch_forms(name, fused):
-    """The one-launch forms of the <= 128-concept edit (UCE_EDIT_FUSED = 1: exact-f32 MFMA update, 2: split-bf16 update from
-    the riders' pre-split R planes) against the reference's own outputs, on the tiled fixtures (1056 rows: ten 112-row
-    super-tiles, the last one ragged) - and twice on one handle (the hand-off words are re-armed by the last block)."""
-    c = Case(name)
-    Hv = _handle_with("UCE_EDIT_FUSED", fused)
-    try:
-        out = _run_case(Hv, c, L.ALGO_AUTO, TILE)
-        again = _run_case(Hv, c, L.ALGO_AUTO, TILE)
-    finally:
-        Hv.close()
-    _check_replicas(out, torch.cat(c.w_exact64()), torch.cat(c.w_ref32()), TILE)
-    assert torch.equal(out, again)
 
 
 @pytest.mark.parametrize("tile", [1, TILE])
@@ -521,16 +506,12 @@ def test_edit_slab_indefinite_system_matches_the_lu_solve(H, N_e, N_p, d, neg):
 
 
 @pytest.mark.parametrize("env,value,N_e,N_p", [("UCE_PROJECT_LA", "0", 100, 80), ("UCE_SPLIT_MAX_NE", "256", 200, 60),
-                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600),
-                                               ("UCE_EDIT_FUSED", "2", 50, 0), ("UCE_EDIT_FUSED", "2", 100, 20), ("UCE_EDIT_FUSED", "2", 3, 2),
-                                               ("UCE_EDIT_FUSED", "1", 50, 0), ("UCE_EDIT_FUSED", "1", 100, 20),
-                                               ("UCE_EDIT_FUSED", "1", 3, 2)])
+                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600)])
 def test_edit_forms_behind_the_switches(env, value, N_e, N_p):
     """The forms uce_edit no longer takes by default stay correct behind their switches: the dual system's Cholesky in a
     launch of its own in front of the projection, the two-pass project + update form for 129 ... 256 edit concepts, the
-    primal path without rider jobs, and the ONE-launch forms of the <= 128-concept edit (uce_lowrank_fused.hip: projection, rider
-    chain and update in the same workgroups, the update on exact-f32 MFMAs (1) or on split-bf16 MFMAs from pre-split R planes (2)) -
-    measured 2-4 us behind the projection + update launch pair, which stays the default."""
+    primal path without rider jobs.  (The one-launch forms of the <= 128-concept edit - measured 2-4 us behind the projection +
+    update launch pair in round 4 - are retired: tools/ubench/retired/lowrank_fused.hip, HISTORY.md.)"""
     d, rows_ = 768, 2500
     C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e)
     rng = np.random.Generator(np.random.PCG64(N_p))

@@ -383,40 +383,6 @@ def test_up_block_reads_the_skip_connection_in_place():
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("M,N,K,dtype,bias,res", [
-    (4096, 320, 1280, torch.bfloat16, True, True),          # ff out at 64 x 64 (B = 1): BN = 320, twenty k-tiles
-    (1000, 640, 640, torch.bfloat16, False, True),          # ragged rows, two channel tiles
-    (515, 1280, 64, torch.float16, True, False),            # one k-tile, f16, four channel tiles
-    (2048, 512, 512, torch.bfloat16, True, True),           # BN = 256 (the VAE attention's projections)
-    (300, 768, 256, torch.bfloat16, False, False),          # BN = 256, three channel tiles, ragged
-    (70000, 320, 128, torch.bfloat16, True, False),         # many row tiles
-])
-def test_linear_on_the_one_wave_per_simd_kernel(M, N, K, dtype, bias, res):
-    """UCE_GEMM_W1=2: uce_linear_fwd's plain epilogue on contiguous rows through k_conv3x3_w1 with one tap (4 waves, 128 x 160 /
-    128 x 128 wave tiles, accumulators pinned in AGPRs): against fp64, bit-repeatable, and next to the 8-wave kernel."""
-    Hv = _handle_with("UCE_GEMM_W1", "2")
-    try:
-        g = torch.Generator().manual_seed(M + N + K)
-        x = _rand((M, K), g, dtype)
-        w = _rand((N, K), g, dtype, K ** -0.5)
-        w[0, 1] += 2.0
-        b = _rand((N,), g, dtype) if bias else None
-        r = _rand((M, N), g, dtype) if res else None
-        y = Hv.linear(x, w, b, r)
-        want = x.double() @ w.double().T
-        if bias:
-            want = want + b.double()
-        if res:
-            want = want + r.double()
-        assert O.rel_fro(y.double().cpu(), want.cpu()) < TOL[dtype]
-        assert torch.equal(y, Hv.linear(x, w, b, r))
-        from uce_amd import edit as E
-        assert O.rel_fro(y.double().cpu(), E.UceHandle.get("cuda:0").linear(x, w, b, r).double().cpu()) < TOL[dtype]
-    finally:
-        torch.cuda.synchronize()
-        Hv.close()
-
-
 # ------------------------------------------------------------------------------------ the few-tile regime (split contraction)
 
 @pytest.mark.parametrize("M,N,K,bias,res", [

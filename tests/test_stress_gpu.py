@@ -200,7 +200,7 @@ def test_edit_and_attention_through_the_address_sanitizer_build(tmp_path):
     from uce_amd import REPO_ROOT, build as B, edit as E
     path = B.asan_lib_path()
     if not os.path.exists(path):
-        pytest.skip("the ASAN variant was not built (__graft_entry__.build() does)")
+        pytest.skip("the ASAN variant was not built (tests/test_abi_cpu.py builds it: uce_amd.build.build_asan)")
     H = E.UceHandle.get("cuda:0")
     g = torch.Generator().manual_seed(77)
     inputs = {}

@@ -109,7 +109,7 @@ int uce_ensure(uce_ctx* h, int d, int n) {
   alloc((void**)&h->Yg, (size_t)nc * dc * sizeof(double));
   alloc((void**)&h->Wi, nn * sizeof(double));
   alloc((void**)&h->DeltaT, dd * sizeof(float));
-  alloc((void**)&h->DeltaP, 3 * dd * sizeof(unsigned short));
+  alloc((void**)&h->DeltaP, 2 * dd * sizeof(unsigned short));
   alloc((void**)&h->Dm, (size_t)nc * dc * sizeof(float));
   alloc((void**)&h->R, (size_t)nc * dc * sizeof(float));
   if (e != hipSuccess) {
@@ -229,10 +229,11 @@ int uce_create(uce_handle_t* out, int device) {
   {
     const int cap = lr_rider_cap();
     const int want = env_int("UCE_RIDER_MAX_N", cap);
-    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_APPLY_VARIANT", 2), env_int("UCE_TRISOLVE_VARIANT", 1),
-                        want < cap ? want : cap, env_int("UCE_CONV_DMA", 1), env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
-                        env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30),
-                        env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1), env_int("UCE_EDIT_FUSED", 0), env_int("UCE_SATTN_LAZY", 8), env_int("UCE_CONV_W1", 1), env_int("UCE_GEMM_W1", 0), env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
+    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_TRISOLVE_VARIANT", 1), want < cap ? want : cap, env_int("UCE_CONV_DMA", 1),
+                        env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0), env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128),
+                        env_int("UCE_SPLIT_MAX_N", 1 << 30), env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0),
+                        env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1), env_int("UCE_SATTN_LAZY", 8), env_int("UCE_CONV_W1", 1),
+                        env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
@@ -348,20 +349,12 @@ int uce_apply(uce_handle_t h, const float* W_old, const float* DeltaT, float* W_
   if (!h || !W_old || !DeltaT || !W_new || rows < 0 || d <= 0 || d % 64 || W_old == W_new) return UCE_EINVAL;
   UCE_ENTER(h);
   if (rows == 0) return UCE_OK;
-  // default: f16 matrix cores with a two-way split of both operands (fp32-equivalent products from three f16 MFMAs,
-  // uce_apply_h2.hip); UCE_APPLY_VARIANT (read at uce_create) = 1: the three-way bf16 split (six MFMAs per product),
-  // 0: the exact-f32 MFMA kernel
-  if (h->sw.apply_variant == 0) {
-    UceProfScope ps(h, "k_apply", (hipStream_t)stream);
-    return launch_apply(W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
-  }
-  int rc = uce_ensure(h, d, 64);
+  // f16 matrix cores with a two-way split of both operands (fp32-equivalent products from three f16 MFMAs, uce_apply_h2.hip); slabs
+  // beyond its 2 GB buffer descriptors are walked in row chunks inside launch_apply_h2.  (The exact-f32 MFMA kernel and the three-way
+  // bf16 split it replaced are under tools/ubench/retired with their numbers in HISTORY.md.)
+  const int rc = uce_ensure(h, d, 64);
   if (rc) return rc;
-  if (h->sw.apply_variant == 2) {
-    rc = launch_apply_h2(h, W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
-    if (rc != 1) return rc;
-  }
-  return launch_apply_b3(W_old, DeltaT, h->DeltaP, W_new, rows, d, (hipStream_t)stream, h);
+  return launch_apply_h2(h, W_old, DeltaT, W_new, rows, d, (hipStream_t)stream);
 }
 
 int uce_dual_factors(uce_handle_t h, const float* C, const float* G, const float* s, int N, int N_edit,
@@ -463,7 +456,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
       //  factorisation and the "free" Bt would become the critical path of the launch - the Gram launch computes it then)
       if (ride_bt)
         h->bt_pending = GramPrimalArgs{C, G, s, N, N_edit, d, lamb, h->M, h->Bt, (N_edit + 31) / 32 * 32, (size_t)0};
-      if (h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d)) {
+      if (rows > 0 && apply_h2_fits(rows, d)) {
         h->h2_pending_src = W_old;
         h->h2_pending_rows = rows;
         h->h2_pending_d = d;
@@ -509,13 +502,6 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool riders = n_pad <= h->sw.rider_max_n;
-    if (riders && h->sw.edit_fused && N_edit <= 128) {
-      // ONE launch: projection || (Gram -> Cholesky -> triangular solves in rider blocks), then - in the same workgroups, the T
-      // tile still in LDS - the update of the rows just projected
-      UceProfScope ps(h, "k_lr_fused", st);
-      // DeltaP (the dense bf16 apply's plane scratch, 3 d^2 bf16) is idle on this path: R's planes (3 * 128 * d bf16) live there
-      return launch_lr_fused(W_old, G, C, s, W_new, rows, d, N, N_edit, lamb, h, st, h->sw.edit_fused >= 2 ? h->DeltaP : nullptr);
-    }
     if (riders) {
       // TWO launches: projection || (Gram -> Cholesky -> triangular solves, all in rider blocks of the same launch),
       // then the update
@@ -562,7 +548,7 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
   // the dense apply - whose f16 split of W_old again rides in the Cholesky launch
   RiderJobs jobs(h);
   const bool dense = !apply_lowrank_fits(d, N_edit) || (N_edit >= 1 && (N_edit > h->sw.split_max_ne || N > h->sw.split_max_n));
-  if (dense && h->sw.apply_variant == 2 && rows > 0 && apply_h2_fits(rows, d) && potrf_la_has_room(h, n_pad)) {
+  if (dense && rows > 0 && apply_h2_fits(rows, d) && potrf_la_has_room(h, n_pad)) {
     h->h2_pending_src = W_old;
     h->h2_pending_rows = rows;
     h->h2_pending_d = d;

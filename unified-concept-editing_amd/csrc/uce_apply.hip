@@ -2,8 +2,7 @@
 // (reference: `mat1 @ torch.inverse(mat2)` per module, uce_sd_erase.py:82; the host keeps all
 // modules' weights in one [rows, d] slab so one launch covers the whole U-Net).
 //
-// k_apply         : dense form, NT GEMM [rows,d] x DeltaT[d,d]^T on v_mfma_f32_32x32x2_f32 (exact
-//                   f32 products), residual folded into the accumulator init.  MFMA-bound.
+// (the dense form W_old (I + Delta) lives in uce_apply_h2.hip; the exact-f32 MFMA kernel it replaced is retired)
 // k_delta_factors : DeltaT = R^T Dm  (small TN GEMM, f32 MFMA) for the dual path with large N_edit.
 // k_cast_bf16     : f32 -> bf16 RNE cast of the edited slab into the U-Net's parameters.
 #include "uce_common.h"
@@ -19,112 +18,6 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = b & 7, local = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-}
-
-__global__ __launch_bounds__(256, 2) void k_apply(const float* __restrict__ W_old,
-                                                  const float* __restrict__ DeltaT,
-                                                  float* __restrict__ W_new, long rows, int d) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float (*As)[BM][TLD] = (float (*)[BM][TLD])smem_raw;                              // [2][128][36]
-  float (*Bs)[BN][TLD] = (float (*)[BN][TLD])(smem_raw + 2 * BM * TLD * sizeof(float));
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-  const int ncol = (d + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  const int lid = xcd_remap(blockIdx.x, nwg);
-  const long r0 = (long)(lid / ncol) * BM;
-  const int j0 = (lid % ncol) * BN;
-
-  // staging coordinates: 4 float4 per thread per operand per K step
-  const int srow = tid >> 3;        // 0..31 (+32p)
-  const int sc4 = (tid & 7) * 4;    // 0..28
-  const float* aptr[4];
-  const float* bptr[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    long gr = r0 + srow + 32 * p;
-    if (gr > rows - 1) gr = rows - 1;
-    int gj = j0 + srow + 32 * p;
-    if (gj > d - 1) gj = d - 1;
-    aptr[p] = W_old + gr * d + sc4;
-    bptr[p] = DeltaT + (long)gj * d + sc4;
-  }
-
-  // accumulators start at the residual W_old tile (D layout of 32x32 MFMA)
-  float16_t acc[2][2];
-  const int ccol = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long gr = r0 + wm + mt * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        const int gc = j0 + wn + nt * 32 + ccol;
-        acc[mt][nt][r] = (gr < rows && gc < d) ? W_old[gr * d + gc] : 0.f;
-      }
-
-  float4_t ra[4], rb[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = *(const float4_t*)(aptr[p]);
-    rb[p] = *(const float4_t*)(bptr[p]);
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    *(float4_t*)&As[0][srow + 32 * p][sc4] = ra[p];
-    *(float4_t*)&Bs[0][srow + 32 * p][sc4] = rb[p];
-  }
-  __syncthreads();
-
-  const int nk = d / BK;
-  const int fr = lane & 31, fk = 4 * (lane >> 5);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        ra[p] = *(const float4_t*)(aptr[p] + (kt + 1) * BK);
-        rb[p] = *(const float4_t*)(bptr[p] + (kt + 1) * BK);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BK / 8; ++u) {
-      // k permutation inside each 8-k group: MFMA t takes k = 8u + 4*(lane>>5) + t from BOTH operands
-      float4_t fa[2], fb[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const float4_t*)&As[cur][wm + mt * 32 + fr][u * 8 + fk];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) fb[nt] = *(const float4_t*)&Bs[cur][wn + nt * 32 + fr][u * 8 + fk];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][t], fb[nt][t], acc[mt][nt], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        *(float4_t*)&As[cur ^ 1][srow + 32 * p][sc4] = ra[p];
-        *(float4_t*)&Bs[cur ^ 1][srow + 32 * p][sc4] = rb[p];
-      }
-    }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long gr = r0 + wm + mt * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        const int gc = j0 + wn + nt * 32 + ccol;
-        if (gr < rows && gc < d) W_new[gr * d + gc] = acc[mt][nt][r];
-      }
 }
 
 // DeltaT[j][k] = sum_e R[e][j] * Dm[e][k]   (Delta = Dm^T R), 64x64 tile per workgroup, f32 MFMA 16x16x4
@@ -204,22 +97,6 @@ __global__ void k_cast_bf16(const float* __restrict__ src, unsigned short* __res
 }
 
 }  // namespace
-
-int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st) {
-  const size_t smem = (size_t)2 * (BM + BN) * TLD * sizeof(float);
-  static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-  if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_once.commit(tok);
-  }
-  const long row_tiles = (rows + BM - 1) / BM;
-  const int col_tiles = (d + BN - 1) / BN;
-  const long nwg = row_tiles * col_tiles;
-  if (nwg > 0x7fffffffL) return UCE_EINVAL;
-  hipLaunchKernelGGL(k_apply, dim3((unsigned)nwg), dim3(256), smem, st, W_old, DeltaT, W_new, rows, d);
-  UCE_LAUNCH_CHECK();
-  return UCE_OK;
-}
 
 int launch_delta_from_factors(const float* Dm, const float* R, int N_edit, int d, float* DeltaT,
                               hipStream_t st) {

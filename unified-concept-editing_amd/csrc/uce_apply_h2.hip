@@ -217,23 +217,23 @@ int apply_h2_workspace(uce_ctx* h, long rows, int d, unsigned short** Ap, float*
   return UCE_OK;
 }
 
-// 1: the shape does not fit this form (the caller takes the bf16 form); 0: launched; < 0: error.
+// Any row count: a slab beyond the 2 GB buffer descriptors is walked in row chunks (rows are independent: every chunk sees the same
+// planes of (I + Delta)^T and its own row scales - the same bits as one launch would give).  0: launched; < 0: error.
 int launch_apply_h2(uce_ctx* h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st) {
-  if (!apply_h2_fits(rows, d)) return 1;
-  const size_t wd = (size_t)rows * (size_t)d;
+  if ((size_t)d * d * 4 >= 0x7fffffffUL) return UCE_EINVAL;
+  long chunk = rows;
+  if (!apply_h2_fits(rows, d)) {
+    chunk = (long)((0x7fffffffUL - 1) / ((size_t)d * 4)) / H2_BM * H2_BM;       // whole row tiles under 2 GB
+    if (chunk <= 0) return UCE_EINVAL;
+  }
   unsigned short* Ap;
   float *rs, *cb;
-  const int rc = apply_h2_workspace(h, rows, d, &Ap, &rs, &cb);
+  const int rc = apply_h2_workspace(h, chunk, d, &Ap, &rs, &cb);
   if (rc) return rc;
   unsigned short* Bp = h->DeltaP;
-  // uce_edit: the planes of this W_old may already have been written by rider workgroups of the Cholesky launch
-  const bool split_done = h->h2_done_src == W_old && h->h2_done_rows == rows && h->h2_done_d == d;
+  // uce_edit: the planes of this W_old may already have been written by rider workgroups of the Cholesky launch (one-chunk slabs)
+  const bool split_done = chunk == rows && h->h2_done_src == W_old && h->h2_done_rows == rows && h->h2_done_d == d;
   h->h2_done_src = nullptr;
-  if (!split_done) {
-    UceProfScope ps(h, "k_split_h2", st);
-    hipLaunchKernelGGL(k_split_h2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, W_old, Ap, Ap + wd, rs, rows, d);
-    UCE_LAUNCH_CHECK();
-  }
   {
     UceProfScope ps(h, "k_split_h2d", st);
     hipLaunchKernelGGL(k_split_h2d, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st, DeltaT, Bp, Bp + (size_t)d * d, cb, d);
@@ -244,14 +244,22 @@ int launch_apply_h2(uce_ctx* h, const float* W_old, const float* DeltaT, float* 
     UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_apply_h2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
-  const long row_tiles = (rows + H2_BM - 1) / H2_BM;
   const int ncol = (d + H2_BN - 1) / H2_BN;
-  const long nwg = row_tiles * ncol;
-  if (nwg > 0x7fffffffL) return UCE_EINVAL;
-  {
+  for (long r0 = 0; r0 < rows; r0 += chunk) {
+    const long rb = rows - r0 < chunk ? rows - r0 : chunk;
+    const size_t wd = (size_t)rb * (size_t)d;
+    const float* Wc = W_old + (size_t)r0 * d;
+    if (!split_done) {
+      UceProfScope ps(h, "k_split_h2", st);
+      hipLaunchKernelGGL(k_split_h2, dim3((unsigned)((rb + 3) / 4)), dim3(256), 0, st, Wc, Ap, Ap + wd, rs, rb, d);
+      UCE_LAUNCH_CHECK();
+    }
+    const long row_tiles = (rb + H2_BM - 1) / H2_BM;
+    const long nwg = row_tiles * ncol;
+    if (nwg > 0x7fffffffL) return UCE_EINVAL;
     UceProfScope ps(h, "k_apply_h2", st);
-    hipLaunchKernelGGL(k_apply_h2, dim3((unsigned)nwg), dim3(512), 2 * H2_STAGE, st, Ap, Bp, rs, cb, W_new, rows, d, ncol);
+    hipLaunchKernelGGL(k_apply_h2, dim3((unsigned)nwg), dim3(512), 2 * H2_STAGE, st, Ap, Bp, rs, cb, W_new + (size_t)r0 * d, rb, d, ncol);
+    UCE_LAUNCH_CHECK();
   }
-  UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

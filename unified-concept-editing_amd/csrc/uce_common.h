@@ -63,7 +63,6 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_SPLIT_MAX_NE / UCE_SPLIT_MAX_N  uce_edit takes the project + update form up to this many edit concepts / concepts in all (beyond: Delta + dense apply)
 //   UCE_PROJECT_LA      1: N > 128 with <= 128 edit concepts: the persistent Cholesky inside the projection launch | 0: in front of it
 //   UCE_POTRF_RIDER_CUS workgroups (CUs) the persistent Cholesky launch may occupy with its riders included (default 250; 0: no riders)
-//   UCE_APPLY_VARIANT   2: f16 x 2 dense apply, direct-to-LDS | 1: bf16 x 3 dense apply | 0: the f32-MFMA kernel
 //   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
 //   UCE_RIDER_MAX_N     largest dual system (64 or 128) factored by rider blocks of the projection launch; 0: never
 //   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
@@ -75,12 +74,7 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //                       it by more than this many powers of two (default 8: P <= 256; 0: exact running maximum, rescale whenever it moves)
 //   UCE_CONV_W1         one-wave-per-SIMD convolution (uce_conv_w1.hip: 4 waves, 128 x 160 / 128 x 128 wave tiles, accumulators pinned in
 //                       AGPRs): 1 (default) = where a layer gives every CU a 256-pixel tile | 2 = wherever the shape allows | 0 = off
-//   UCE_GEMM_W1         the same kernel with one tap for uce_linear_fwd's plain epilogue on contiguous rows: 0 = off | 1 = compute-bound
-//                       shapes that fill the chip (K >= 640, >= 256 tiles) | 2 = wherever the shape allows
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
-//   UCE_EDIT_FUSED      uce_edit with at most 128 concepts (default 0: measured 62-64 us at 50 concepts against 64-66 for either one-launch
-//                       form - the update phase is bound by its weight traffic, not by the launch boundary or the MFMA type): 2 = ONE launch (projection, small-system chain, update on split-bf16 MFMAs:
-//                       uce_lowrank_fused.hip) | 1 = one launch, exact-f32 MFMA update | 0 = projection launch + update launch
 //   UCE_WIDE_EPILOGUE   1: GEMM / convolution tiles leave through LDS in whole rows | 0: 8 bytes per lane from the accumulators
 //   UCE_GEMM_TILE       0: tile of uce_linear_fwd by rule | 1000 * BM + BN (256320, 256256, 128320, 128256, 256128): forced
 //   UCE_GN_FUSED        1: GroupNorm of small activations in ONE launch (grid-wide wait inside a sample) | 0: always stats + apply
@@ -88,8 +82,8 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
-  int xattn_variant, apply_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue, edit_fused, sattn_lazy, conv_w1, gemm_w1, sk_split, gn_fused;
+  int xattn_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
+      gemm_tile, sattn_vti, conv_tile, wide_epilogue, sattn_lazy, conv_w1, sk_split, gn_fused;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -149,7 +143,7 @@ struct uce_ctx {
   double* Wi;     // [n_cap, n_cap] explicit L^-1 of the GEMM-shaped triangular solves (uce_trinv.hip)
   bool wi_valid;  // the last factorisation on this handle already formed the off-diagonal blocks of L^-1 in Wi (k_potrf_la)
   float* DeltaT;  // [d_cap, d_cap]
-  unsigned short* DeltaP;  // [3][d_cap, d_cap] bf16 planes of Delta^T (uce_apply_b3.hip)
+  unsigned short* DeltaP;  // [2][d_cap, d_cap] f16 planes (high, low) of (I + Delta)^T (uce_apply_h2.hip)
   float* Dm;      // [n_cap, d_cap]
   float* R;       // [n_cap, d_cap]
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
@@ -213,8 +207,6 @@ int uce_ensure(uce_ctx* h, int d, int n);
 // (the caller decides by UceSwitches::conv_dma whether to ask)
 int launch_conv_w1(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up, int dtype,
                    hipStream_t st, int* rc, int sd, const void* res, int mode);
-int launch_linear_w1(const void* x, const void* w, const void* bias, const void* res, void* y, long M, int N, int K, int dtype,
-                     hipStream_t st, int* rc, int mode);
 int launch_conv_dma(const void* x, const void* w, const void* bias, void* y, long M, int H, int W, int Cin, int Cout, int up,
                     int dtype, hipStream_t st, int* rc, int sd = 1, const void* res = nullptr, int force = 0, int wide = 1,
                     uce_ctx* h = nullptr);
@@ -243,10 +235,8 @@ int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* 
                     float* out, int out_rows, hipStream_t st, double* scratch = nullptr);
 int launch_trisolve_inv(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows, float* out,
                         int out_rows, double* scratch, hipStream_t st);
-int launch_apply(const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
-int launch_apply_b3(const float* W_old, const float* DeltaT, unsigned short* planes, float* W_new, long rows, int d,
-                    hipStream_t st, uce_ctx* h = nullptr);
-// f16 x 2 dense apply (uce_apply_h2.hip).  1: shape outside its buffer descriptors (take launch_apply_b3); 0: launched
+// f16 x 2 dense apply (uce_apply_h2.hip): any row count (slabs beyond a 2 GB buffer descriptor are walked in row chunks).
+// apply_h2_fits: the whole slab is ONE chunk (only then can rider workgroups pre-split it)
 bool apply_h2_fits(long rows, int d);
 int apply_h2_workspace(uce_ctx* h, long rows, int d, unsigned short** Ap, float** rs, float** cb);
 int launch_apply_h2(uce_ctx* h, const float* W_old, const float* DeltaT, float* W_new, long rows, int d, hipStream_t st);
@@ -265,10 +255,6 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
                       const float* s = nullptr, int N = 0, float lamb = 0.f, float* R = nullptr);
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
-// projection + rider chain + update in one launch (uce_lowrank_fused.hip): N <= 128 concepts, d in {768, 1024, 2048}
-// Rp != null: the update runs on the bf16 matrix cores (three-way split); Rp = scratch for R's planes, 3 * 128 * d * 2 bytes
-int launch_lr_fused(const float* W_old, const float* G, const float* C, const float* s, float* W_new, long rows, int d, int N,
-                    int N_edit, float lamb, uce_ctx* h, hipStream_t st, unsigned short* Rp = nullptr);
 // the projection with the persistent Cholesky of the dual system (la, own workgroups) in the first workgroups of the launch
 int launch_lr_project_la(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d, int N_edit,
                          const PotrfLaJob& la, int own, hipStream_t st);

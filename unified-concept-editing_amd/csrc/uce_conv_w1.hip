@@ -62,8 +62,8 @@ constexpr int W1_NA = W1_BM / 8 / 4;                 // A DMA instructions per w
 template <int TNW>
 constexpr size_t w1_smem() { return (size_t)2 * (W1_BM + 32 * TNW) * W1_ROWB; }
 
-// TAPS: 9 = the 3 x 3 convolution; 1 = its centre tap alone on a 1 x 1 "image" per row, i.e. a linear layer y = x Wt^T (+ bias)
-// (+ residual) over M contiguous rows of Cin columns (uce_linear_fwd sends its compute-bound shapes here: launch_linear_w1)
+// TAPS: 9 = the 3 x 3 convolution.  (1 = its centre tap alone on a 1 x 1 "image" per row, i.e. a linear layer over contiguous rows:
+// measured behind UCE_GEMM_W1 in round 4, level with or behind k_gemm_dma on every U-Net shape - no longer instantiated, HISTORY.md)
 template <int TNW, bool F16, int TAPS>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                        const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
@@ -321,23 +321,5 @@ int launch_conv_w1(const void* x, const void* w, const void* bias, void* y, long
   if (mode == 1 && tiles < 256) return 0;
   *rc = bn == 320 ? launch_w1<10, 9>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res)
                   : launch_w1<8, 9>(x, w, bias, y, M, H, W, Cin, Cout, up, dtype, st, sd, res);
-  return 1;
-}
-
-// The linear layer y [M, N] = x [M, K] w [N, K]^T (+ bias) (+ residual) on the same kernel (one tap, one pixel per "image"): contiguous
-// rows only (ldx = K, ldy = ldr = N).  0: not taken; 1: launched.  mode (UCE_GEMM_W1): 1 = the compute-bound shapes that fill the chip
-// (K >= 640, at least 256 tiles), 2 = wherever the shape allows.
-int launch_linear_w1(const void* x, const void* w, const void* bias, const void* res, void* y, long M, int N, int K, int dtype,
-                     hipStream_t st, int* rc, int mode) {
-  *rc = UCE_OK;
-  if (mode <= 0 || K % W1_BK || N % 8) return 0;
-  if (((uintptr_t)y & 15) || ((uintptr_t)res & 15) || ((uintptr_t)bias & 7) || ((uintptr_t)x & 15)) return 0;
-  const int bn = N % 320 == 0 ? 320 : N % 256 == 0 ? 256 : 0;
-  if (!bn) return 0;
-  const long tiles = ((M + W1_BM - 1) / W1_BM) * (N / bn);
-  if (mode == 1 && (tiles < 256 || K < 640)) return 0;
-  if (M * (long)K * 2 >= 0x7fffffffL) return 0;
-  *rc = bn == 320 ? launch_w1<10, 1>(x, w, bias, y, M, 1, 1, K, N, 0, dtype, st, 1, res)
-                  : launch_w1<8, 1>(x, w, bias, y, M, 1, 1, K, N, 0, dtype, st, 1, res);
   return 1;
 }

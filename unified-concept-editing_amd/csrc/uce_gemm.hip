@@ -472,11 +472,6 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
   if ((long)N * K * 2 >= (1L << 31)) return UCE_EINVAL;
   const int force = h->sw.gemm_tile;
   UceProfScope ps(h, name, (hipStream_t)stream);
-  // compute-bound plain layers on contiguous rows: the one-wave-per-SIMD kernel (uce_conv_w1.hip, one tap)
-  if (h->sw.gemm_w1 && !force && h->sw.wide_epilogue && !geglu && !outf32 && !x2 && ldx == K && ldy == N && (!residual || ldr == N)) {
-    int rc;
-    if (launch_linear_w1(x, w, bias, residual, y, M, N, K, dtype, (hipStream_t)stream, &rc, h->sw.gemm_w1)) return rc;
-  }
   const long ybytes = outf32 ? 4 : 2;
   for (long m0 = 0; m0 < M; m0 += max_rows) {
     const long mb = (M - m0 < max_rows) ? M - m0 : max_rows;
