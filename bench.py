@@ -642,9 +642,9 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
     # region, on worker threads behind the next batch's denoising exactly as uce_amd.generate.generate_images does it (same default
     # worker count, capped so that `world` ranks never ask for more threads than the node has cores), and the clock stops only
     # when the last file is on disk.
+    from uce_amd import generate as _gen
     png_dir = tempfile.mkdtemp(prefix="uce_bench_png_") if vae else None
-    ncores = os.cpu_count() or 8
-    png_workers = max(1, min(4, ncores // max(1, world) - 1))
+    png_workers = max(1, _gen.png_worker_count(8, world))                # (after the rank was pinned to its block of cores)
     writer = ThreadPoolExecutor(max_workers=png_workers) if vae else None
     pending = []
     png_cpu_s = [0.0]
@@ -762,7 +762,7 @@ def uce_wall_leg(pipe, device, tmpdir: str):
         pres = [f"kept artist {i}" for i in range(n_p)]
         guide = ["art"] * n_e
         ent = {"workload": name, "concepts": n_e + n_p}
-        for label, eb in (("per_string", 0), ("embed_batch_64", 64)):
+        for label, eb in (("default", None), ("per_string", 0)):        # default = automatic (64 strings per forward on this pipeline)
             tm = {}
             with contextlib.redirect_stdout(io.StringIO()):
                 E.UCE(pipe, edit, guide, pres, 1.0, 1.0, 0.5, tmpdir, f"wall_{name}_{label}", device=str(device), embed_batch=eb,
@@ -926,6 +926,10 @@ def main() -> None:
     dev_index = local if local < torch.cuda.device_count() else 0     # a launcher that masks one GPU per rank shows it as cuda:0
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    pinned_cores = 0
+    if world > 1:
+        from uce_amd import generate as _gen
+        pinned_cores = _gen.pin_rank_to_cores(local, world)           # each rank on its own block of cores (its GPU's NUMA node first)
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -986,6 +990,7 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "f32 (f64 Gram/solve)",
         "data": "synthetic",
+        "host_cores_per_rank": pinned_cores if world > 1 else len(os.sched_getaffinity(0)),
         "config": {"workload": f"{args.workload}: {n_e} erase + {n_p} preserve concepts, d={d}, "
                                f"{len(inp['mods'])} attn2 to_k/to_v modules = one {inp['rows']}x{d} fp32 slab, "
                                f"lambda 0.5, algo {args.algo}",

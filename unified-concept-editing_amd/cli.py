@@ -69,8 +69,9 @@ EXTRA_RUNTIME_FLAGS = [
 ]
 EXTRA_EDIT_FLAGS = [
     ("--algo", dict(type=str, default="auto", choices=["auto", "primal", "dual"], help="solver formulation")),
-    ("--embed_batch", dict(type=int, default=0, help="batch this many concept strings per text-encoder forward "
-                                                      "(0 = one string per call, as the reference does)")),
+    ("--embed_batch", dict(type=int, default=-1, help="concept strings per text-encoder forward: -1 (default) = 64 for this "
+                                                       "build's own pipeline on a GPU, one per call for any other pipeline object; "
+                                                       "0 = one string per call, as the reference does")),
 ]
 EXTRA_GENERATE_FLAGS = [
     ("--latents_only", dict(action="store_true", help="skip VAE decode / PNG encode, save latents (.pt)")),

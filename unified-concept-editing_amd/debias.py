@@ -15,7 +15,7 @@ all-reduced; the closed-form solve is replicated (it is < 1 ms; "replicas only")
 from __future__ import annotations
 
 import time
-from typing import Callable, Sequence
+from typing import Callable, Optional, Sequence
 
 import numpy as np
 import torch
@@ -89,7 +89,7 @@ def rank_device(device) -> str:
 def UCE(pipe, classify, edit_concepts, debias_concepts, preserve_concepts, edit_scale, preserve_scale, lamb, save_dir,
         exp_name, max_diff, step_size, num_images_per_prompt, num_inference_steps, guidance_scale,
         desired_ratios=(0.5, 0.5), max_iterations=30, device="cuda:0", ratios_fn=None, algo: int = 0,
-        embed_batch: int = 0):
+        embed_batch: Optional[int] = None):
     """Same positional signature as the reference's debias UCE() (:37); `desired_ratios`,
     `max_iterations`, `device` replace the module globals it reads; `ratios_fn` lets a test script
     the (unseeded, irreproducible) sampling step; `algo` / `embed_batch` as in edit.UCE."""

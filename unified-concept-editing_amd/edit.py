@@ -531,10 +531,32 @@ class WeightSlab:
 
 
 def save_uce_state(slab: WeightSlab, save_dir: str, exp_name: str) -> str:
-    """safetensors artifact `{save_dir}/{exp_name}.safetensors` (uce_sd_erase.py:85-88)."""
-    from safetensors.torch import save_file
+    """safetensors artifact `{save_dir}/{exp_name}.safetensors` (uce_sd_erase.py:85-88): keys `<module path>.weight`, fp32, the
+    module's [o, d] shape - what `load_file` + `load_state_dict(strict=False)` of generate-images-sd.py:17-19 consume.
+
+    The slab IS the file's data section (modules in row order, rows contiguous): ONE device -> host copy of the whole slab and one
+    write behind a hand-built header, instead of a copy per module, a dict of host tensors and the serializer's own copy of all of
+    them (safetensors format: 8-byte little-endian header length, JSON {name: {dtype, shape, data_offsets}}, raw little-endian
+    data).  A slab whose modules are not packed back to back in order takes safetensors' save_file."""
+    import json as _json
     path = os.path.join(save_dir, exp_name + ".safetensors")
-    save_file({k: v.detach().cpu().contiguous() for k, v in slab.state_dict().items()}, path)
+    d = int(slab.data.shape[1])
+    packed = (slab.data.dtype == torch.float32 and slab.data.is_contiguous() and len(set(slab.names)) == len(slab.names)
+              and all(o == sum(slab.rows[:i]) for i, o in enumerate(slab.offsets)) and sum(slab.rows) == slab.data.shape[0])
+    if not packed:
+        from safetensors.torch import save_file
+        save_file({k: v.detach().cpu().contiguous() for k, v in slab.state_dict().items()}, path)
+        return path
+    header = {}
+    for n, o, r in zip(slab.names, slab.offsets, slab.rows):
+        header[n + ".weight"] = {"dtype": "F32", "shape": [int(r), d], "data_offsets": [int(o) * d * 4, int(o + r) * d * 4]}
+    hb = _json.dumps(header, separators=(",", ":")).encode("utf-8")
+    hb += b" " * ((8 - len(hb) % 8) % 8)                               # (the data section starts 8-byte aligned, as save_file pads)
+    host = slab.data.detach().to("cpu")                                 # one copy (synchronises with the edit's stream)
+    with open(path, "wb") as f:
+        f.write(len(hb).to_bytes(8, "little"))
+        f.write(hb)
+        f.write(memoryview(host.numpy()).cast("B"))
     return path
 
 
@@ -542,8 +564,11 @@ def save_uce_state(slab: WeightSlab, save_dir: str, exp_name: str) -> str:
 # concept embeddings  (uce_sd_erase.py:25-42)
 # --------------------------------------------------------------------------------------------
 
+AUTO_EMBED_BATCH = 64
+
+
 def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[Dict[str, torch.Tensor]] = None,
-                          batch_size: int = 0) -> Dict[str, torch.Tensor]:
+                          batch_size: Optional[int] = 0) -> Dict[str, torch.Tensor]:
     """Per UNIQUE string: text-encoder hidden state at index `attention_mask.sum() - 2`
     (the last real token; '' -> the BOS position).  Returns {prompt: [d] fp32 on `device`}.
 
@@ -551,12 +576,15 @@ def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[
     string, uce_sd_erase.py:26-42).  batch_size > 0 is SURVEY.md section 8(f) row 1: all unique
     strings go through the text encoder in batches of that size and the last-token rows are
     gathered on the device - the text encoder, not the closed-form solve, is what a 1 500-concept
-    edit spends its wall-clock on."""
+    edit spends its wall-clock on.  batch_size None / < 0: automatic (64 for the build's own pipeline on a GPU, else per string)."""
     out = {} if cache is None else cache
-    todo = []
-    for e in prompts:
-        if e not in out and e not in todo:
-            todo.append(e)
+    todo = list(dict.fromkeys(e for e in prompts if e not in out))     # unique, first-seen order
+    if batch_size is None or batch_size < 0:
+        # automatic: the build's own pipeline on a GPU batches (64 strings per forward - the rows of a batch are independent and the
+        # gather is bit-exact, tests/test_host_cpu.py, test_edit_gpu.py); a foreign pipe object keeps the reference's call pattern
+        from .sd import pipeline as _sdp
+        own = isinstance(pipe, _sdp.StableDiffusionPipeline) and torch.device(device).type == "cuda"
+        batch_size = AUTO_EMBED_BATCH if own else 0
     if batch_size and batch_size > 1 and len(todo) > 1:
         for i in range(0, len(todo), batch_size):
             chunk = todo[i:i + batch_size]
@@ -659,7 +687,7 @@ def edit_slab(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: Optional[
 
 def UCE(pipe, edit_concepts, guide_concepts, preserve_concepts, erase_scale, preserve_scale, lamb, save_dir,
         exp_name, device: str = "cuda:0", algo: int = _lib.ALGO_AUTO, return_slab: bool = False,
-        embed_batch: int = 0, timings: Optional[Dict[str, float]] = None):
+        embed_batch: Optional[int] = None, timings: Optional[Dict[str, float]] = None):
     """Same positional signature and artifact as the reference's UCE() (uce_sd_erase.py:12);
     `device` replaces the module global the reference reads.  `timings` (optional dict) receives the wall seconds of the
     stages - slab (module discovery + packing), embed (text encoder, uce_sd_erase.py:25-42), edit (:45-82, device-synchronised),

@@ -40,6 +40,57 @@ def init_distributed(device: torch.device) -> Tuple[int, int]:
     return rank, world
 
 
+def pin_rank_to_cores(local: int, world: int) -> int:
+    """One process per GPU on one node: rank `local` of `world` keeps to its own contiguous block of the cores this process may run
+    on - preferring, when the node exposes it, the cores of the NUMA node its GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node) -
+    so that eight ranks' host work (CPU-seeded latent draws, tokenizer, graph replays, PNG encoding on worker threads) never migrates
+    across sockets or piles onto the same cores.  Returns the number of cores the rank ended up with (0: nothing changed - one rank,
+    or a platform without sched_setaffinity).  The torch intra-op pool is sized to the block."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return 0
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        block = []
+        try:                                                        # cores of the GPU's NUMA node, split among the ranks that share it
+            bdf = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
+            if isinstance(bdf, int) or bdf is None:
+                bdf = None
+            if bdf:
+                node = int(open(f"/sys/bus/pci/devices/{bdf.lower()}/numa_node").read())
+                if node >= 0:
+                    txt = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+                    cpus = []
+                    for part in txt.split(","):
+                        a, _, b = part.partition("-")
+                        cpus += list(range(int(a), int(b or a) + 1))
+                    cpus = [c for c in cpus if c in set(allowed)]
+                    nodes = max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]))
+                    per_node = max(1, -(-world // nodes))               # ranks sharing this node (GPUs spread evenly over the nodes)
+                    k = local % per_node
+                    step = max(1, len(cpus) // per_node)
+                    block = cpus[k * step:(k + 1) * step]
+        except Exception:  # noqa: BLE001
+            block = []
+        if not block:
+            step = max(1, len(allowed) // world)
+            block = allowed[local * step:(local + 1) * step] or allowed
+        os.sched_setaffinity(0, set(block))
+        torch.set_num_threads(max(1, min(len(block), 8)))
+        return len(block)
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def png_worker_count(requested: int, world: int) -> int:
+    """PNG-encoding threads of one rank: the caller's number, capped so that `world` ranks x (workers + the rank's own thread) never
+    ask for more threads than the cores the process may run on."""
+    try:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count() or 8
+    return max(0, min(int(requested), max(1, cores - 1)))
+
+
 def broadcast_uce_weights(path: Optional[str], keys_like, device: torch.device, rank: int, world: int,
                           force_collective: bool = False) -> Optional[Dict[str, torch.Tensor]]:
     """Rank 0 loads the safetensors artifact; everyone ends up with the same {name: fp32 tensor}.
@@ -107,7 +158,7 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
                     torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=100,
                     num_images_per_prompt=10, from_case=0, till_case=1000000, model_dir=None, synthetic=False,
                     latents_only=False, skip_existing=False, pipe=None, batch_prompts: int = 0,
-                    png_workers: int = 4) -> Dict[str, float]:
+                    png_workers: int = 8) -> Dict[str, float]:
     """evalscripts/generate-images-sd.py:10-46.  `batch_prompts` CSV rows are denoised as one batch (each row
     still draws its latents from its own CPU generator seeded with `evaluation_seed`, exactly the draw the
     reference makes row by row); file names and contents per image are those of the row-by-row loop.  0 (the default) picks the
@@ -119,6 +170,9 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
     rank, world = init_distributed(dev)
+    if world > 1 and dev.type == "cuda":
+        pin_rank_to_cores(local, world)                               # (before the worker threads exist: they inherit the mask)
+    png_workers = png_worker_count(png_workers, world)
 
     # 1. the pipeline (every rank builds its own replica)
     if pipe is None:
@@ -144,7 +198,8 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
     batch_prompts = int(batch_prompts)
     if batch_prompts <= 0:
         batch_prompts = auto_batch_prompts(pipe, dev, num_images_per_prompt, len(todo))
-    # PNG encoding (host, ~30 ms per 512x512 image) runs on worker threads behind the next batch's denoising
+    # PNG encoding (host, ~30 ms per 512x512 image) runs on worker threads behind the next batch's denoising (eight by default, fewer
+    # when the rank's block of cores is smaller: the tail after the LAST batch is batch x 30 ms / workers)
     writer = ThreadPoolExecutor(max_workers=png_workers) if (png_workers > 0 and not latents_only) else None
     pending = []
     for lo in range(0, len(todo), batch_prompts):
