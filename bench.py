@@ -860,8 +860,13 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
 
 def time_kernel(fn, iters: int):
     """Average duration (ms) of `fn`'s launches on the current stream, HIP events around `iters`
-    back-to-back launches (the library enqueues on torch's current stream)."""
-    fn()
+    back-to-back launches (the library enqueues on torch's current stream).  The launches of an untimed warm-up burst come first
+    (as many as are timed, at most 100): after an idle gap the first handful of launches of an HBM-bound kernel run ~15 % faster
+    than the hundredth (k_xattn_g<40> at B = 128: 137 us for launches 2-5, 165 us median over the first hundred, 145-150 us from
+    there on while the shader clock settles from 2.40 to ~2.15 GHz - profiles/r05/xattn_timing_bursts.json; rocprofv3's four-launch
+    passes see the first figure), the steady state is what a generation loop runs at."""
+    for _ in range(max(1, min(iters, 100))):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

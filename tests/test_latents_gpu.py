@@ -122,19 +122,19 @@ def test_latents_at_sd14_size_match_fp32_within_stated_tolerance():
     assert final_prod <= 1.25 * final_torch + 0.01, (final_prod, final_torch)
 
 
-def test_unet_call_at_the_generation_batch_matches_fp32_within_the_per_call_tolerance():
-    """The dispatch of sd/unet.py depends on the batch: at one prompt per call (the test above) the small layers stay with the
-    GEMM library, at the generation batch every linear layer, every 64 x 64 / 32 x 32 / 16 x 16 convolution, the packed q|k|v
-    attention and the fused epilogues are the hand-written kernels.  ONE U-Net evaluation at SD-1.4 size with 16 prompts (CFG
-    batch 32) - the same bf16-rounded weights through fp32 torch ops, through the product path and through torch's own bf16
-    ops - under the per-call tolerance stated above."""
+@pytest.mark.parametrize("n", [16, 128])
+def test_unet_call_at_the_generation_batch_matches_fp32_within_the_per_call_tolerance(n):
+    """The tile rules of the kernels follow the batch: at one prompt per call (the test above) every layer takes the few-tile forms
+    with the split contraction, at 16 prompts the wide forms of most layers, at the bench's 128 prompts per call (CFG batch 256)
+    the 256 x 256 GEGLU tiles, the 128-byte k-tiles from M >= 196 608 and k_conv3x3_w1 on every convolution.  ONE U-Net evaluation at
+    SD-1.4 size per batch - the same bf16-rounded weights through fp32 torch ops, through the product path and through torch's own
+    bf16 ops - under the per-call tolerance stated above."""
     from uce_amd.sd import pipeline as sdp
     dev = "cuda:0"
     pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.float32, dev, synthetic=True, vae=False, seed=0)
     for p in pipe.unet.parameters():
         p.data.copy_(p.data.to(torch.bfloat16).float())
     g = torch.Generator().manual_seed(7)
-    n = 16
     lat = torch.randn((n, 4, 64, 64), generator=g).to(torch.bfloat16)
     ctx = (torch.randn((2 * n, 77, 768), generator=g) * 0.5).to(torch.bfloat16)
     t = torch.tensor([481], device=dev)
