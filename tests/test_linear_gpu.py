@@ -164,7 +164,7 @@ def test_packed_self_attention(H, B, heads, L, dh, dtype):
     assert O.rel_fro(o.double().cpu(), ref.cpu()) < (8e-3 if dtype == torch.bfloat16 else 1.5e-3)
 
 
-@pytest.mark.parametrize("vti", ["1", "2"])
+@pytest.mark.parametrize("vti", ["1", "2", "3"])
 @pytest.mark.parametrize("B,heads,Lq,Lk,dh,dtype", [(2, 8, 1024, 1024, 40, torch.bfloat16), (1, 8, 300, 130, 40, torch.bfloat16),
                                                     (2, 8, 512, 200, 80, torch.bfloat16), (1, 4, 200, 130, 128, torch.float16),
                                                     (2, 8, 256, 256, 160, torch.bfloat16), (1, 7, 70, 191, 56, torch.bfloat16),

@@ -179,3 +179,44 @@ def test_sattn_half_tile_pipeline_rising_max_and_packed():
     finally:
         torch.cuda.synchronize()
         Hv.close()
+
+
+@pytest.mark.parametrize("vti", ["1", "3"])
+@pytest.mark.parametrize("B,H_,Lq,Lk,dh,dtype", [
+    (2, 8, 1024, 1024, 40, torch.bfloat16), (1, 8, 300, 130, 40, torch.bfloat16), (3, 4, 77, 64, 40, torch.float16),
+    (2, 4, 100, 33, 40, torch.bfloat16), (2, 4, 260, 97, 40, torch.bfloat16), (1, 8, 256, 4000, 48, torch.bfloat16),
+    (1, 2, 40, 1, 40, torch.bfloat16),
+])
+def test_sattn_half_tile_pipeline_both_inline_v_forms(vti, B, H_, Lq, Lk, dh, dtype):
+    """k_sattn_h (UCE_SATTN_QT=4) with V transposed on its way into LDS by 2-byte stores (UCE_SATTN_VTI=1) and with V kept row-major
+    and read through ds_read_b64_tr_b16 (3; what the by-shape rule takes): the same shapes, against fp64 - and the two agree with each
+    other to the last bit (same fragments, same MFMA order)."""
+    import os
+    from uce_amd import edit as E
+    hs = {}
+    for val in ("1", vti):
+        old = {k: os.environ.get(k) for k in ("UCE_SATTN_QT", "UCE_SATTN_VTI")}
+        os.environ.update(UCE_SATTN_QT="4", UCE_SATTN_VTI=val)
+        try:
+            hs[val] = E.UceHandle("cuda:0")
+        finally:
+            for k, v_ in old.items():
+                if v_ is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v_
+    g = torch.Generator().manual_seed(Lq * 3 + dh + Lk)
+    C = H_ * dh
+    q = torch.randn(B, Lq, C, generator=g).to(dtype).cuda()
+    k = torch.randn(B, Lk, C, generator=g).to(dtype).cuda()
+    v = torch.randn(B, Lk, C, generator=g).to(dtype).cuda()
+    try:
+        o = hs[vti].sattn(q, k, v, H_)
+        o1 = hs["1"].sattn(q, k, v, H_)
+    finally:
+        torch.cuda.synchronize()
+        for h_ in set(hs.values()):
+            h_.close()
+    ref = _ref_gpu(q, k, v, H_)
+    assert O.rel_fro(o.double().cpu(), ref.cpu()) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
+    assert torch.equal(o, o1)

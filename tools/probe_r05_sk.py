@@ -141,7 +141,7 @@ def sattn(B):
         qkv = torch.randn(2 * B, L, 3 * C, device="cuda").bfloat16()
         ent = {"sattn": [2 * B, L, C], "gflop": round(4e-9 * 2 * B * L * L * C, 2)}
         for qt in (0, 1, 2, 3, 4):
-            for vti in (0, 1, 2):
+            for vti in (0, 1, 2, 3):
                 Hv = handle(UCE_SATTN_QT=qt, UCE_SATTN_VTI=vti)
                 try:
                     ent[f"qt{qt}_vti{vti}"] = round(timeit_graph(lambda: Hv.sattn_packed(qkv, 8)), 1)

@@ -69,7 +69,8 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_SATTN_QT        0: self-attention kernel by measured rule | 1: k_sattn, one query tile per wave | 2: two query tiles
 //                       wherever dh <= 48 | 3: the software-pipelined k_sattn_p wherever it exists
 //   UCE_SATTN_VTI       0: V^T of the self-attention transposed on the way into LDS up to 1024 keys, by the k_vt pre-pass beyond |
-//                       1: always inline | 2: always the pre-pass
+//                       1: always inline (2-byte transposing stores) | 2: always the pre-pass | 3: always inline (k_sattn_h: row-major V +
+//                       ds_read_b64_tr_b16, also what 0 takes there)
 //   UCE_SATTN_LAZY      self-attention: the running maximum of the online softmax is raised only when a key tile's maximum exceeds
 //                       it by more than this many powers of two (default 8: P <= 256; 0: exact running maximum, rescale whenever it moves)
 //   UCE_CONV_W1         one-wave-per-SIMD convolution (uce_conv_w1.hip: 4 waves, 128 x 160 / 128 x 128 wave tiles, accumulators pinned in

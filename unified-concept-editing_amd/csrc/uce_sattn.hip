@@ -610,7 +610,13 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 // 896 of matrix pipe).  P V trails by one half so the rescale of O still covers it; K is staged two tiles ahead and V^T
 // one behind: three LDS buffers each.  dh < DVP only (the denominator comes out of the ones row of V^T).
 // ---------------------------------------------------------------------------------------------
-template <int DHP, bool F16, bool VTI>
+// VTR (with VTI): V stays ROW-MAJOR in LDS ([key][64 dims], 192-byte rows) - stored as it arrives, 16 bytes per lane - and the P V
+// fragments (4 consecutive keys of one dim per lane) come out of `ds_read_b64_tr_b16`, gfx950's transposing LDS read: per 16-lane
+// group the hardware reads a [4 keys][16 dims] block (lane 4 j + c supplies the address of key j, dims 4 c .. 4 c + 3) and hands
+// lane l the column l & 15.  Replaces the inline transpose's eight 2-byte scattered stores per 16-byte chunk (LDS bank conflicts on
+// 0.32 of the LDS cycles, profiles/r04/session2_sattn_h_pmc_sq.txt).  The 192-byte row stride puts the four key rows of a
+// 32-lane half on four disjoint 16-bank sets ((a / 4) % 64: 0, 48, 32, 16); the ones column (dim DVP - 1) replaces the ones row.
+template <int DHP, bool F16, bool VTI, bool VTR = false>
 __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                  int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
@@ -625,7 +631,9 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   constexpr int NKL = (KT * KCH + 255) / 256;
   constexpr int VCH = KT / 8;
   constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;
-  constexpr int KB = KT * KLD, VB = DVP * VLD;
+  static_assert(!VTR || VTI, "the transposing reads replace the inline transpose");
+  constexpr int VRS = 96;                                              // VTR: elements per key row of V (64 dims + 32: see above)
+  constexpr int KB = KT * KLD, VB = VTR ? KT * VRS : DVP * VLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Kbuf = (unsigned short*)smem_raw;                  // [3][KB]
   unsigned short* Vbuf = Kbuf + 3 * KB;                              // [3][VB]
@@ -691,7 +699,10 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      if constexpr (VTI) {
+      if constexpr (VTR) {
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        if (e < KT * KCH && dim < dh) *(uint4_t*)(Vs + key * VRS + dim) = rv[i];
+      } else if constexpr (VTI) {
         const int key = e / KCH, dim = (e - key * KCH) * 8;
         if (e < KT * KCH && dim < dh) {
 #pragma unroll
@@ -709,13 +720,39 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
       }
     }
   };
-  if constexpr (VTI) {
+  if constexpr (VTR) {
+    for (int e = tid; e < 3 * DVP * KT; e += 256) {                    // the padding dims of every key row: zeros, dim DVP - 1 = 1
+      const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
+      const int key = rem / DVP, dv = rem - key * DVP;
+      if (dv >= dh) Vbuf[buf * VB + key * VRS + dv] = (dv == DVP - 1) ? one : (unsigned short)0;
+    }
+  } else if constexpr (VTI) {
     for (int e = tid; e < 3 * DVP * KT; e += 256) {
       const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
       const int dv = rem / KT, key = rem - dv * KT;
       if (dv >= dh) Vbuf[buf * VB + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
     }
   }
+  // the P V fragment of dim tile nt, key group s2 of a 32-key half whose first key row / column is at Vp:
+  // keys 16 s2 + 4 lh + {0..3, 8..11} of dim 32 nt + lq (the key order of the P fragments)
+  const int tr_off = (4 * lh + ((lane & 15) >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  auto v_frag = [&](const unsigned short* Vp, int nt, int s2) -> uint4_t {
+    if constexpr (VTR) {
+      typedef short v4s_t __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+      const unsigned short* a = Vp + tr_off + 16 * s2 * VRS + 32 * nt;
+      const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)a);
+      const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(a + 8 * VRS));
+      const uint2_t l2 = __builtin_bit_cast(uint2_t, lo), h2 = __builtin_bit_cast(uint2_t, hi);
+      return (uint4_t){l2[0], l2[1], h2[0], h2[1]};
+    } else {
+      const unsigned short* vrow = Vp + (nt * 32 + lq) * VLD + 4 * lh + 16 * s2;
+      const uint2_t lo = *(const uint2_t*)(vrow);
+      const uint2_t hi = *(const uint2_t*)(vrow + 8);
+      return (uint4_t){lo[0], lo[1], hi[0], hi[1]};
+    }
+  };
+  constexpr int VHALF = VTR ? 32 * VRS : 32;                           // the upper 32 keys of a V buffer
 
   float m[2] = {-INFINITY, -INFINITY};
   float16_t oacc[2][NDV];
@@ -782,12 +819,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
 #pragma unroll
       for (int nt = 0; nt < NDV; ++nt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const unsigned short* vrow = Vp + (nt * 32 + lq) * VLD + 4 * lh + 16 * s2;
-          const uint2_t lo = *(const uint2_t*)(vrow);
-          const uint2_t hi = *(const uint2_t*)(vrow + 8);
-          vf[nt][s2] = (uint4_t){lo[0], lo[1], hi[0], hi[1]};
-        }
+        for (int s2 = 0; s2 < 2; ++s2) vf[nt][s2] = v_frag(Vp, nt, s2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4 * NDV; ++i) {
@@ -865,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
       g_load_v(t + 1);
     }
     // half 2t: P V of half 2t - 1 (tile t - 1, upper keys; before the first tile: zeros times tile 0), S^T of half 2t + 1
-    sub_head(mask_c, 2 * t, sA, t ? Vbuf + vbp * VB + 32 : Vbuf + vb * VB);
+    sub_head(mask_c, 2 * t, sA, t ? Vbuf + vbp * VB + VHALF : Vbuf + vb * VB);
     sub_tail(std::true_type{}, sA, sB, Kbuf + kb * KB + (32 + lq) * KLD + 8 * lh);
     // half 2t + 1: P V of half 2t, S^T of half 2t + 2
     sub_head(mask_c, 2 * t + 1, sB, Vbuf + vb * VB);
@@ -887,15 +919,12 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
     tile(std::true_type{}, std::false_type{}, ntiles - 1);
   // P V of the last half
   {
-    const unsigned short* Vp = Vbuf + vb * VB + 32;
+    const unsigned short* Vp = Vbuf + vb * VB + VHALF;
 #pragma unroll
     for (int nt = 0; nt < NDV; ++nt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const unsigned short* vrow = Vp + (nt * 32 + lq) * VLD + 4 * lh + 16 * s2;
-        const uint2_t lo = *(const uint2_t*)(vrow);
-        const uint2_t hi = *(const uint2_t*)(vrow + 8);
-        const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
+        const uint4_t vf = v_frag(Vp, nt, s2);
 #pragma unroll
         for (int x = 0; x < 2; ++x) oacc[x][nt] = mfma32<F16>(vf, pf[x][s2], oacc[x][nt]);
       }
@@ -923,25 +952,25 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   }
 }
 
-template <int DHP, bool VTI>
+template <int DHP, bool VTI, bool VTR = false>
 int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                  float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 255) / 256, H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
-  const size_t smem = (size_t)3 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  const size_t smem = (size_t)3 * (KT * (DHP + 8) + (VTR ? KT * 96 : NDV * 32 * (KT + 4))) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
-    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -1012,11 +1041,17 @@ static bool sattn_use_h(int qt_variant, int dh, int Lq, int Lk, int H, int B) {
 // the kernel for one shape, with (VTI) or without the V^T pre-pass already run
 template <bool VTI>
 int launch_body(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh, float scale,
-                int dtype, hipStream_t st, int qt_variant, long ld, float lazy) {
+                int dtype, hipStream_t st, int qt_variant, long ld, float lazy, int vti = 0) {
   // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
   //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
   //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
-  if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) {
+    // inline V: row-major in LDS + transposing reads (UCE_SATTN_VTI = 0 / 3), or transposed on the way in (= 1)
+    if constexpr (VTI) {
+      if (vti != 1) return launch_cfg_h<48, true, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+    }
+    return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  }
   if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
     return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
@@ -1047,8 +1082,9 @@ size_t sattn_vt_elems(int B, int H, int Lk, int dh) {
 
 // V^T by the pre-pass (k_vt: straight 16-byte tile copies in the key loop) or transposed on the way into LDS (no pre-pass, no
 // scratch): `vti` = UCE_SATTN_VTI (0: by rule - inline up to 1024 keys, where the pre-pass and its launch are a visible share
-// of a short kernel; 1: always inline; 2: always the pre-pass)
-bool sattn_inline_vt(int Lk, int vti, bool use_h) { return vti == 1 || (vti == 0 && (Lk <= 1024 || use_h)); }
+// of a short kernel; 1: always inline, transposed by 2-byte stores; 2: always the pre-pass; 3: always inline - k_sattn_h keeps V
+// row-major and reads it with ds_read_b64_tr_b16 under 0 and 3)
+bool sattn_inline_vt(int Lk, int vti, bool use_h) { return vti == 1 || vti == 3 || (vti == 0 && (Lk <= 1024 || use_h)); }
 
 // qt_variant (UCE_SATTN_QT, read at uce_create): 0 = measured best by shape, 1 = always k_sattn with one query tile per wave,
 // 2 = two query tiles wherever dh <= 48, 3 = the pipelined kernel wherever it exists (dh <= 48, 64 < dh <= 80)
@@ -1057,7 +1093,7 @@ int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o,
                  float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, float lazy) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   if (ld <= 0) ld = (long)H * dh;
-  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy);
+  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy, vti);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
