@@ -229,11 +229,10 @@ int uce_create(uce_handle_t* out, int device) {
   {
     const int cap = lr_rider_cap();
     const int want = env_int("UCE_RIDER_MAX_N", cap);
-    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), env_int("UCE_TRISOLVE_VARIANT", 1), want < cap ? want : cap, env_int("UCE_CONV_DMA", 1),
-                        env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0), env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128),
-                        env_int("UCE_SPLIT_MAX_N", 1 << 30), env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0),
-                        env_int("UCE_CONV_TILE", 0), env_int("UCE_WIDE_EPILOGUE", 1), env_int("UCE_SATTN_LAZY", 8), env_int("UCE_CONV_W1", 1),
-                        env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
+    h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), want < cap ? want : cap, env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
+                        env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30),
+                        env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0),
+                        env_int("UCE_CONV_W1", 1), env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
   }
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }

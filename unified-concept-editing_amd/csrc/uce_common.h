@@ -63,28 +63,23 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_SPLIT_MAX_NE / UCE_SPLIT_MAX_N  uce_edit takes the project + update form up to this many edit concepts / concepts in all (beyond: Delta + dense apply)
 //   UCE_PROJECT_LA      1: N > 128 with <= 128 edit concepts: the persistent Cholesky inside the projection launch | 0: in front of it
 //   UCE_POTRF_RIDER_CUS workgroups (CUs) the persistent Cholesky launch may occupy with its riders included (default 250; 0: no riders)
-//   UCE_TRISOLVE_VARIANT 1: GEMM-shaped solve for systems of >= 3 diagonal blocks | 0: the substitution kernel at every size
 //   UCE_RIDER_MAX_N     largest dual system (64 or 128) factored by rider blocks of the projection launch; 0: never
-//   UCE_CONV_DMA        1: direct-to-LDS convolution where it applies | 0: always the 128 x 128 kernel
 //   UCE_SATTN_QT        0: self-attention kernel by measured rule | 1: k_sattn, one query tile per wave | 2: two query tiles
 //                       wherever dh <= 48 | 3: the software-pipelined k_sattn_p wherever it exists
 //   UCE_SATTN_VTI       0: V^T of the self-attention transposed on the way into LDS up to 1024 keys, by the k_vt pre-pass beyond |
 //                       1: always inline (2-byte transposing stores) | 2: always the pre-pass | 3: always inline (k_sattn_h: row-major V +
 //                       ds_read_b64_tr_b16, also what 0 takes there)
-//   UCE_SATTN_LAZY      self-attention: the running maximum of the online softmax is raised only when a key tile's maximum exceeds
-//                       it by more than this many powers of two (default 8: P <= 256; 0: exact running maximum, rescale whenever it moves)
 //   UCE_CONV_W1         one-wave-per-SIMD convolution (uce_conv_w1.hip: 4 waves, 128 x 160 / 128 x 128 wave tiles, accumulators pinned in
 //                       AGPRs): 1 (default) = where a layer gives every CU a 256-pixel tile | 2 = wherever the shape allows | 0 = off
 //   UCE_CONV_TILE       0: tile of the direct-to-LDS convolution by rule | 1000 * BM + BN: forced
-//   UCE_WIDE_EPILOGUE   1: GEMM / convolution tiles leave through LDS in whole rows | 0: 8 bytes per lane from the accumulators
 //   UCE_GEMM_TILE       0: tile of uce_linear_fwd by rule | 1000 * BM + BN (256320, 256256, 128320, 128256, 256128): forced
 //   UCE_GN_FUSED        1: GroupNorm of small activations in ONE launch (grid-wide wait inside a sample) | 0: always stats + apply
 //   UCE_SK_SPLIT        0: slabs per tile of the few-tile GEMM / convolution forms by rule (uce_splitk.h) | S: forced
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
-  int xattn_variant, trisolve_variant, rider_max_n, conv_dma, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, wide_epilogue, sattn_lazy, conv_w1, sk_split, gn_fused;
+  int xattn_variant, rider_max_n, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
+      gemm_tile, sattn_vti, conv_tile, conv_w1, sk_split, gn_fused;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding

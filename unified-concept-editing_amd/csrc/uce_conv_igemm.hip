@@ -255,13 +255,13 @@ extern "C" int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w
   {
     // outputs that are multiples of 128 / 256 / 320 channels: the direct-to-LDS form (uce_conv_dma.hip), which also carries the
     // stride-2 taps and the residual epilogue
-    int rc;                                                  // UCE_CONV_DMA=0 (read at uce_create): always the 128 x 128 kernel
+    int rc;
     // the one-wave-per-SIMD form first (UCE_CONV_W1; forced tile forms keep the 8-wave kernel)
-    if (h->sw.conv_dma != 0 && h->sw.conv_tile == 0 && h->sw.wide_epilogue &&
+    if (h->sw.conv_tile == 0 &&
         launch_conv_w1(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual, h->sw.conv_w1))
       return rc;
-    if (h->sw.conv_dma != 0 && launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual,
-                                               h->sw.conv_tile, h->sw.wide_epilogue, h))
+    if (launch_conv_dma(x, w, bias, y, M, H, W, Cin, Cout, upsample ? 1 : 0, dtype, st, &rc, stride, residual,
+                                               h->sw.conv_tile, 1, h))
       return rc;
   }
   if (stride != 1 || residual) return UCE_ENOSYS;            // only the direct-to-LDS form has them

@@ -478,7 +478,7 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
     const int rc = launch_linear((const unsigned short*)x + m0 * ldx, ldx, w, bias,
                                  residual ? (const void*)((const unsigned short*)residual + m0 * ldr) : nullptr, ldr,
                                  (unsigned char*)y + m0 * ldy * ybytes, ldy, mb, N, K, geglu, dtype, (hipStream_t)stream, force,
-                                 h->sw.wide_epilogue, outf32,
+                                 1, outf32,
                                  x2 ? (const void*)((const unsigned short*)x2 + m0 * ldx2) : nullptr, ldx2, K1, h);
     if (rc != UCE_OK) return rc;
   }

@@ -333,7 +333,7 @@ int launch_potrf(uce_ctx* h, double* M, int n, hipStream_t st, int n_valid) {
 int launch_trisolve(uce_ctx* h, int n, int m, const double* rhs64, const float* rhs32, int rhs_rows,
                     float* out, int out_rows, hipStream_t st, double* scratch) {
   // UCE_TRISOLVE_VARIANT=0 (read at uce_create) keeps the substitution kernel at every size (A/B measurements)
-  if (h->sw.trisolve_variant && scratch && n >= 192 && m % 64 == 0)
+  if (scratch && n >= 192 && m % 64 == 0)
     return launch_trisolve_inv(h, n, m, rhs64, rhs32, rhs_rows, out, out_rows, scratch, st);
   const bool use_lds = n <= 1024;
   const size_t smem = 64 * 16 * 8 + (use_lds ? (size_t)n * 16 * 8 : 0);
