@@ -25,13 +25,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t fu_rsrc(const float* base, lon
 }
 
 // Update of the workgroup's rows [R0, R0 + MT*16) from the T tile in LDS.  8 waves: wave w takes the 64-column quarter
-// w & 3 of every 256-column group and every second 16-row tile (w >> 2).  Per column group the wave's R fragments
-// (NK k-steps of 4 concepts) are loaded ONCE into registers - L1-bypassing loads, R was published write-through by other
-// CUs of this launch - and reloaded in place for the next group under the last tile's MFMAs; the next tile's W rows are in
-// flight under the current tile's MFMAs (k_lr_update_s's streams, one level up).
-template <int D, int MT, int NK>
+// w & 3 of every 256-column group and every second 16-row tile (w >> 2); a work item = (column group, tile) = 16 rows x 64 columns =
+// 16 accumulator registers, loaded straight from W_old in the accumulator layout.
+// PRE: the first PRE work items' rows of W_old are loaded BEFORE the wait for R (`wait()` below: the rider chain ends ~30 us after
+// launch start, the projection earlier) and stay in registers across it - the second read of W_old, which bounded the update phase
+// of the round-4 form (PRE = 0: every item's rows fetched after the wait, one item ahead), then costs nothing on the critical path:
+// after the wait the phase is R fragments + MFMAs + stores.  The item loops are fully unrolled (static register indices).
+template <int D, int MT, int NK, int PRE, class WaitFn>
 __device__ __forceinline__ void fused_update(const float* __restrict__ W_old, const float* __restrict__ R, float* __restrict__ W_new,
-                                             const float* Ts, int tld, long rows, int Ne, long R0) {
+                                             const float* Ts, int tld, long rows, int Ne, long R0, WaitFn wait) {
   constexpr int d = D;
   constexpr int MG = D / 256;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,34 +59,60 @@ __device__ __forceinline__ void fused_update(const float* __restrict__ W_old, co
     return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(fu_rsrc(Wb + row0 * d + gi * 256, tile_rows * d * 4 - sh),
                                                                                vo_w, 0, 0));
   };
-
+  // item g = gi * NT + it (it < my_tiles): tile th + 2 it of column group gi
+  constexpr int NITEM = MG * NT;
+  constexpr int NPRE = PRE < NITEM ? PRE : NITEM;
+  float4_t pre[NPRE > 0 ? NPRE : 1][4];
+#pragma unroll
+  for (int g = 0; g < NPRE; ++g) {
+    const int gi = g / NT, it = g % NT;
+    if (it < my_tiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre[g][r] = ld_w(th + 2 * it, r, gi);
+    }
+  }
+  wait();                                             // R is complete
   float4_t rr[NK];
-  float4_t res[4];
 #pragma unroll
   for (int t = 0; t < NK; ++t) rr[t] = ld_r(t, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  if (my_tiles > 0) {
+  float4_t res[4];
+  if constexpr (NPRE == 0) {
+    if (my_tiles > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) res[r] = ld_w(th, r, 0);
+      for (int r = 0; r < 4; ++r) res[r] = ld_w(th, r, 0);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
+#pragma unroll
   for (int gi = 0; gi < MG; ++gi) {
-#pragma unroll 1
-    for (int it = 0; it < my_tiles; ++it) {
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      if (it >= my_tiles) continue;                   // (wave-uniform)
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int g = gi * NT + it;
       const int tile = th + 2 * it;
       const bool last_tile = it + 1 == my_tiles;
       float4_t acc[4];                                // acc[q][r]: row tile*16 + 4*lk + r, column 4*li + q of the wave's 64
+      if (g < NPRE) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q][r] = res[r][q];
-      if (!last_tile) {
+          for (int q = 0; q < 4; ++q) acc[q][r] = pre[g < NPRE ? g : 0][r][q];
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) res[r] = ld_w(tile + 2, r, gi);
-      } else if (gi + 1 < MG) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) res[r] = ld_w(th, r, gi + 1);
+          for (int q = 0; q < 4; ++q) acc[q][r] = res[r][q];
+      }
+      // the next item that is NOT preloaded: its rows in flight under this item's MFMAs
+      {
+        const int gn_it = last_tile ? 0 : it + 1, gn_gi = last_tile ? gi + 1 : gi;
+        const int gn = gn_gi * NT + gn_it;
+        if (gn_gi < MG && gn >= NPRE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[r] = ld_w(th + 2 * gn_it, r, gn_gi);
+        }
       }
       const float* trow = Ts + (tile * 16 + li) * tld + lk;
       float a = trow[0];
@@ -129,10 +157,10 @@ __device__ __forceinline__ float4_t fu_mfma(uint4_t a, uint4_t b, float4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fu_bf16x8_t, a), __builtin_bit_cast(fu_bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int D, int MT, int CT>
+template <int D, int MT, int CT, int PRE, class WaitFn>
 __device__ __forceinline__ void fused_update_b3(const float* __restrict__ W_old, const unsigned short* __restrict__ Rp,
                                                 float* __restrict__ W_new, const float* Ts, int tld, unsigned char* Rs, long rows,
-                                                long R0) {
+                                                long R0, WaitFn wait) {
   constexpr int d = D;
   constexpr int NEP = 64 * CT;
   constexpr int KG = NEP / 8;                         // k-groups of 8 concepts
@@ -179,76 +207,88 @@ __device__ __forceinline__ void fused_update_b3(const float* __restrict__ W_old,
   auto item_col = [&](int ch, int it) { return ch * CHW + ((it / my_tiles) * 2 + half) * 64; };
   auto item_tile = [&](int it) { return tslot + 4 * (it % my_tiles); };
 
-  issue_chunk(0);
-  // W rows of the next THREE work items in flight (one wave = 4 KB per item; at one workgroup per CU a single item ahead left
-  // the update latency-bound: 31 us for 153 MB whatever the MFMA type)
-  float4_t res[4], res1[4], res2[4];
-  const int total = items * NCH;
-  auto ld_item = [&](int g, float4_t (&dst)[4]) {
-    if (g < total) {
-      const int c2 = g / items, i2 = g - c2 * items;
+  // PRE: the first PRE work items' rows of W_old are loaded BEFORE the wait for R and stay in registers across it (see fused_update);
+  // the others follow one item ahead.  Fully unrolled (static register indices): MAXT tiles per wave slot x NBLK blocks x NCH chunks.
+  constexpr int MAXT = (MT + 3) / 4;
+  constexpr int MAXI = MAXT * NBLK;                                    // items per chunk, at most
+  constexpr int NPRE = PRE < MAXI * NCH ? PRE : MAXI * NCH;
+  float4_t pre[NPRE > 0 ? NPRE : 1][4];
+  // static item number g = (ch * NBLK + b) * MAXT + t  <->  tile tslot + 4 t (t < my_tiles), block b of chunk ch
+  auto col_of = [&](int ch, int b) { return ch * CHW + (b * 2 + half) * 64; };
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[r] = ld_w(item_tile(i2), r, item_col(c2, i2));
+  for (int g = 0; g < NPRE; ++g) {
+    const int t = g % MAXT, b = (g / MAXT) % NBLK, ch = g / (MAXT * NBLK);
+    if (t < my_tiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre[g][r] = ld_w(tslot + 4 * t, r, col_of(ch, b));
     }
-  };
-  ld_item(0, res);
-  ld_item(1, res1);
-  ld_item(2, res2);
-#pragma unroll 1
+  }
+  wait();                                                              // R (and its planes) are complete
+  issue_chunk(0);
+  float4_t res[4];
+#pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     __syncthreads();                                                   // the previous chunk's fragment reads are done
     park_chunk();
     if (ch + 1 < NCH) issue_chunk(ch + 1);
     __syncthreads();
-#pragma unroll 1
-    for (int it = 0; it < items; ++it) {
-      const int tile = item_tile(it), col0 = item_col(ch, it);
-      const int blk = (it / my_tiles) * 2 + half;
-      float4_t acc[4];                                // acc[q][r]: row tile*16 + 4*lkg + r, column col0 + 4*li + q
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+    for (int b = 0; b < NBLK; ++b) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q][r] = res[r][q];
+      for (int t = 0; t < MAXT; ++t) {
+        if (t >= my_tiles) continue;                                   // (wave-uniform)
+        const int g = (ch * NBLK + b) * MAXT + t;
+        const int tile = tslot + 4 * t, col0 = col_of(ch, b);
+        const int blk = b * 2 + half;
+        float4_t acc[4];                              // acc[q][r]: row tile*16 + 4*lkg + r, column col0 + 4*li + q
+        if (g < NPRE) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        res[r] = res1[r];
-        res1[r] = res2[r];
-      }
-      ld_item(ch * items + it + 3, res2);
-      const float* trow = Ts + (tile * 16 + li) * tld + 8 * lkg;
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float4_t t0 = *(const float4_t*)(trow + 32 * s), t1 = *(const float4_t*)(trow + 32 * s + 4);
-        const float tx[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-        uint4_t ah, am, al;
-        rp_split8(tx, ah, am, al);
+            for (int q = 0; q < 4; ++q) acc[q][r] = pre[g < NPRE ? g : 0][r][q];
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned char* bq = Rs + ((((4 * s + lkg) * 4 + q) * (CHW / 4)) + blk * 16 + li) * 16;
-          const uint4_t bh = *(const uint4_t*)bq;
-          const uint4_t bm = *(const uint4_t*)(bq + (size_t)KG * 4 * (CHW / 4) * 16);
-          const uint4_t bl = *(const uint4_t*)(bq + (size_t)2 * KG * 4 * (CHW / 4) * 16);
-          acc[q] = fu_mfma(al, bh, acc[q]);           // small terms first
-          acc[q] = fu_mfma(ah, bl, acc[q]);
-          acc[q] = fu_mfma(am, bm, acc[q]);
-          acc[q] = fu_mfma(am, bh, acc[q]);
-          acc[q] = fu_mfma(ah, bm, acc[q]);
-          acc[q] = fu_mfma(ah, bh, acc[q]);
+          for (int r = 0; r < 4; ++r) res[r] = ld_w(tile, r, col0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][r] = res[r][q];
         }
-      }
+        const float* trow = Ts + (tile * 16 + li) * tld + 8 * lkg;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float4_t o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        const long row0 = (long)tile * 16 + r;
-        const long sh = (row0 * d + col0) * 4;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), fu_rsrc(Ob + row0 * d + col0, tile_rows * d * 4 - sh), vo_w, 0,
-                                               2 /* nt */);
+        for (int s = 0; s < NS; ++s) {
+          const float4_t t0 = *(const float4_t*)(trow + 32 * s), t1 = *(const float4_t*)(trow + 32 * s + 4);
+          const float tx[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+          uint4_t ah, am, al;
+          rp_split8(tx, ah, am, al);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned char* bq = Rs + ((((4 * s + lkg) * 4 + q) * (CHW / 4)) + blk * 16 + li) * 16;
+            const uint4_t bh = *(const uint4_t*)bq;
+            const uint4_t bm = *(const uint4_t*)(bq + (size_t)KG * 4 * (CHW / 4) * 16);
+            const uint4_t bl = *(const uint4_t*)(bq + (size_t)2 * KG * 4 * (CHW / 4) * 16);
+            acc[q] = fu_mfma(al, bh, acc[q]);           // small terms first
+            acc[q] = fu_mfma(ah, bl, acc[q]);
+            acc[q] = fu_mfma(am, bm, acc[q]);
+            acc[q] = fu_mfma(am, bh, acc[q]);
+            acc[q] = fu_mfma(ah, bm, acc[q]);
+            acc[q] = fu_mfma(ah, bh, acc[q]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4_t o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+          const long row0 = (long)tile * 16 + r;
+          const long sh = (row0 * d + col0) * 4;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), fu_rsrc(Ob + row0 * d + col0, tile_rows * d * 4 - sh), vo_w, 0,
+                                                 2 /* nt */);
+        }
       }
     }
   }
 }
 
-template <int D, int MT, int CT, int NK>
+template <int D, int MT, int CT, int NK, int PRE = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_fused(
     const float* __restrict__ W_old, const float* __restrict__ Dm, const float* __restrict__ Csub, float* __restrict__ W_new,
     long rows, int Ne, int NEP, GramPotrfJob job) {
@@ -266,23 +306,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* Wc = (float*)smem_raw;                       // [2][MT*16][PJ_LD] staging, then the T tile [MT*16][NEP + 4]
   const int tld = NEP + 4;                            // 16-byte aligned rows, 4 banks apart
   project_dispatch<D, MT, CT>(W_old, Dm, Csub, nullptr, rows, Ne, NEP, Wc, has_rider, Wc, tld);
-  wait_stage(job, 4);                                 // R is complete (the barrier inside also closes the T tile's stores)
-  if (threadIdx.x == 0) {
-    // seen: count out; the last projecting block re-arms the stage word and this counter for the next launch
-    const unsigned t = __hip_atomic_fetch_add(job.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == (unsigned)job.n_proj - 1) {
-      __hip_atomic_store(job.ticket + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(job.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   const long R0 = (long)((int)blockIdx.x - has_rider) * (MT * 16);
-  if constexpr (NK == 0)                              // split-bf16 update: the R chunk sits behind the T tile
-    fused_update_b3<D, MT, CT>(W_old, job.Rp, W_new, Wc, tld, smem_raw + (size_t)MT * 16 * (64 * CT + 4) * sizeof(float), rows, R0);
-  else
-    fused_update<D, MT, NK>(W_old, job.R, W_new, Wc, tld, rows, Ne, R0);
+  auto wait = [&]() {
+    wait_stage(job, 4);                               // R is complete (the barrier inside also closes the T tile's stores)
+    if (threadIdx.x == 0) {
+      // seen: count out; the last projecting block re-arms the stage word and this counter for the next launch
+      const unsigned t = __hip_atomic_fetch_add(job.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)job.n_proj - 1) {
+        __hip_atomic_store(job.ticket + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(job.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if constexpr (NK == 0) {                            // split-bf16 update: the R chunk sits behind the T tile
+    fused_update_b3<D, MT, CT, PRE>(W_old, job.Rp, W_new, Wc, tld, smem_raw + (size_t)MT * 16 * (64 * CT + 4) * sizeof(float), rows, R0, wait);
+  } else {
+    fused_update<D, MT, NK, PRE>(W_old, job.R, W_new, Wc, tld, rows, Ne, R0, wait);
+  }
 }
 
-template <int D, int MT, int CT, int NK>
+template <int D, int MT, int CT, int NK, int PRE = 0>
 int launch_fused(const float* W_old, const float* G, const float* Csub, float* W_new, long rows, int N_edit, int NEP64,
                  GramPotrfJob job, hipStream_t st) {
   size_t smem = (size_t)2 * (MT * 16 + 64 * CT) * PJ_LD * sizeof(float);
@@ -293,7 +336,7 @@ int launch_fused(const float* W_old, const float* G, const float* Csub, float* W
   if (smem > 160 * 1024) return UCE_EINVAL;
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_fused<D, MT, CT, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_fused<D, MT, CT, NK, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   const long n_proj = (rows + MT * 16 - 1) / (MT * 16);
@@ -301,7 +344,7 @@ int launch_fused(const float* W_old, const float* G, const float* Csub, float* W
   if (n_proj > 0x3fffffffL) return UCE_EINVAL;
   job.fused = 1;
   job.n_proj = (int)n_proj;
-  hipLaunchKernelGGL((k_lr_fused<D, MT, CT, NK>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, G, Csub, W_new, rows, N_edit, NEP64,
+  hipLaunchKernelGGL((k_lr_fused<D, MT, CT, NK, PRE>), dim3((unsigned)nwg), dim3(512), smem, st, W_old, G, Csub, W_new, rows, N_edit, NEP64,
                      job);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -309,20 +352,20 @@ int launch_fused(const float* W_old, const float* G, const float* Csub, float* W
 
 // NK = k-steps of 4 concepts the update walks (rows of R beyond N_edit read as zeros, the T tile's padding columns are zero):
 // 13 / 16 for one 64-concept tile row, 25 / 32 for two
-template <int D, int MT>
+template <int D, int MT, int PRE = 0>
 int launch_fused_d(const float* W_old, const float* G, const float* Csub, float* W_new, long rows, int N_edit, int NEP64,
                    const GramPotrfJob& job, hipStream_t st) {
   if (job.Rp) {                                        // split-bf16 update (NK = 0 marks it)
-    if (NEP64 <= 64) return launch_fused<D, MT, 1, 0>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
-    return launch_fused<D, MT, 2, 0>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
+    if (NEP64 <= 64) return launch_fused<D, MT, 1, 0, PRE>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
+    return launch_fused<D, MT, 2, 0, PRE>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
   }
   const int nks = (N_edit + 3) / 4;
   if (NEP64 <= 64) {
-    if (nks <= 13) return launch_fused<D, MT, 1, 13>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
-    return launch_fused<D, MT, 1, 16>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
+    if (nks <= 13) return launch_fused<D, MT, 1, 13, PRE>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
+    return launch_fused<D, MT, 1, 16, PRE>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
   }
-  if (nks <= 25) return launch_fused<D, MT, 2, 25>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
-  return launch_fused<D, MT, 2, 32>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
+  if (nks <= 25) return launch_fused<D, MT, 2, 25, PRE>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
+  return launch_fused<D, MT, 2, 32, PRE>(W_old, G, Csub, W_new, rows, N_edit, NEP64, job, st);
 }
 
 }  // namespace
@@ -330,11 +373,13 @@ int launch_fused_d(const float* W_old, const float* G, const float* Csub, float*
 // W_new = W_old + (W_old (G - C_e)^T) R with R = rows of (lamb S^-1 + C C^T)^-1 C, N <= 128 concepts, in ONE launch.
 // h->ticket / slabs / Lmat / Linv / status / R as launch_lr_project's rider form.
 int launch_lr_fused(const float* W_old, const float* G, const float* C, const float* s, float* W_new, long rows, int d, int N,
-                    int N_edit, float lamb, uce_ctx* h, hipStream_t st, unsigned short* Rp) {
+                    int N_edit, float lamb, uce_ctx* h, hipStream_t st, unsigned short* Rp, int pre) {
   const int NEP64 = (N_edit + 63) / 64 * 64;
   const int nb = (N + 63) / 64;
   if (!h || nb < 1 || nb > GP_MAXB || N_edit < 1 || N_edit > 128 || !C || !s || !G) return UCE_EINVAL;
   GramPotrfJob job{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, nb, h->R, N_edit, Rp, NEP64, 1, 0};
+  if (d == 768 && pre >= 12) return launch_fused_d<768, 7, 12>(W_old, G, C, W_new, rows, N_edit, NEP64, job, st);
+  if (d == 768 && pre >= 8) return launch_fused_d<768, 7, 8>(W_old, G, C, W_new, rows, N_edit, NEP64, job, st);
   if (d == 768) return launch_fused_d<768, 7>(W_old, G, C, W_new, rows, N_edit, NEP64, job, st);
   if (d == 1024) return launch_fused_d<1024, 7>(W_old, G, C, W_new, rows, N_edit, NEP64, job, st);
   if (d == 2048) return launch_fused_d<2048, 5>(W_old, G, C, W_new, rows, N_edit, NEP64, job, st);
