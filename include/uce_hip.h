@@ -78,6 +78,13 @@ int uce_solve_delta(uce_handle_t h, double* A, const double* Bt, int d, float* D
  * column).  A is destroyed; pivot failures as uce_solve_delta. */
 int uce_solve_rhs(uce_handle_t h, double* A, const double* B, int d, int m, float* X, uce_stream_t stream);
 
+/* The EDGE path of a5: a symmetric INDEFINITE system (negative scales or lambda <= 0 - the reference's `torch.inverse(mat2)` of
+ * uce_sd_erase.py:82 is an LU inverse and accepts them, a Cholesky does not):  X [n, m] f32 = A^-1 B  by Gaussian elimination with
+ * partial pivoting in f64 on [A | B] (csrc/uce_lu.hip: one pivot launch + one update launch per column, then the back
+ * substitution - latency-bound, ~14 ms at n = 768).  A and B are destroyed.  Synchronises the stream once (the singularity
+ * threshold n eps max|A|); a pivot below it is recorded in the handle like a failed Cholesky pivot (uce_status: column + 1). */
+int uce_solve_general(uce_handle_t h, double* A, double* B, int n, int m, float* X, uce_stream_t stream);
+
 /* a5 - apply (replaces `mat1 @ inverse` of uce_sd_erase.py:82 for ALL modules in one launch):
  *   W_new [rows,d] = W_old + W_old Delta ; rows = sum of the modules' out_features (the host
  *   keeps every attn2.to_k/to_v weight in one [rows,d] slab).  Products carry fp32 accuracy: each row of W_old

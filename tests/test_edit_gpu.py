@@ -483,8 +483,8 @@ def test_primal_edit_other_widths(H, N_e, N_p, d, rows_):
 
 @pytest.mark.parametrize("N_e,N_p,d,neg", [(40, 20, 768, "scales"), (300, 700, 768, "scales"), (30, 30, 1024, "lamb")])
 def test_edit_slab_indefinite_system_matches_the_lu_solve(H, N_e, N_p, d, neg):
-    """Negative scales / lamb <= 0 (the reference's `torch.inverse` takes them): edit_slab's general form (f64 LU solve) against
-    numpy's LU solve in float64."""
+    """Negative scales / lamb <= 0 (the reference's `torch.inverse` takes them): edit_slab's general form (uce_gram ->
+    uce_solve_general, the library's own f64 LU -> uce_apply) against numpy's LU solve in float64."""
     from uce_amd import edit as E
     C, G, s = _synthetic(N_e + N_p, N_e, d, seed=N_e + 3)
     lamb = 0.5
@@ -503,6 +503,41 @@ def test_edit_slab_indefinite_system_matches_the_lu_solve(H, N_e, N_p, d, neg):
     out = E.edit_slab(H, slab, _dev(C), _dev(G), _dev(s), lamb).data.cpu()
     want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
     assert O.rel_fro(out, want) < max(2e-6, 1e-14 * cond), cond
+
+
+@pytest.mark.parametrize("n,m", [(64, 64), (200, 72), (768, 768), (1024, 130)])
+def test_general_solve_is_the_library_s_own_lu_and_matches_numpy(H, n, m):
+    """uce_solve_general (Gaussian elimination with partial pivoting in f64, csrc/uce_lu.hip - no vendor solver on this edge path):
+    a symmetric indefinite matrix with a zero on its diagonal (no pivoting = division by zero), against numpy's LU solve; torch's
+    linalg is made unreachable for the call; a singular matrix raises EDOM."""
+    rng = np.random.Generator(np.random.PCG64(n + m))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.concatenate([np.linspace(-3.0, -0.05, n // 3), np.linspace(0.02, 5.0, n - n // 3)])
+    A = (Q * ev) @ Q.T
+    A = 0.5 * (A + A.T)
+    P = np.eye(n)[rng.permutation(n)]
+    A = P @ A @ P.T
+    A[0, :] -= A[0, 0] * np.eye(n)[0]                                    # a zero leading entry: the first pivot MUST come from below
+    A[:, 0] = A[0, :]
+    B = rng.standard_normal((n, m))
+    want = np.linalg.solve(A, B)
+    orig = torch.linalg.solve
+
+    def no_library(*a, **k):
+        raise AssertionError("torch.linalg.solve reached from the product path")
+    torch.linalg.solve = no_library
+    try:
+        X = H.solve_general(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda())
+    finally:
+        torch.linalg.solve = orig
+    cond = np.linalg.cond(A)
+    assert O.rel_fro(X.cpu(), want) < max(3e-7, 1e-13 * cond), cond     # (the result is rounded to f32 once)
+    S = np.ones((n, n))                                                  # rank one: singular
+    with pytest.raises(L.UceError) as ei:
+        H.solve_general(torch.from_numpy(S).cuda(), torch.from_numpy(B).cuda())
+    assert ei.value.code == L.EDOM
+    X2 = H.solve_general(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda())          # the handle recovers
+    assert torch.equal(X, X2)                                            # bit-repeatable (fixed pivot order, no atomics)
 
 
 @pytest.mark.parametrize("env,value,N_e,N_p", [("UCE_PROJECT_LA", "0", 100, 80), ("UCE_SPLIT_MAX_NE", "256", 200, 60),

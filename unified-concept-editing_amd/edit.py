@@ -108,6 +108,20 @@ class UceHandle:
         _lib.check(self.lib.uce_solve_rhs(self._h, _ptr(A), _ptr(B), d, m, _ptr(X), _stream_ptr(self.device)), "uce_solve_rhs")
         return X
 
+    def solve_general(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """X [n, m] f32 = A^-1 B for ANY non-singular f64 A [n, n] (destroyed) and f64 B [n, m] (destroyed): Gaussian elimination with
+        partial pivoting in f64 (uce_solve_general) - the indefinite systems the Cholesky path cannot take.  Raises UceError(EDOM) for
+        a matrix that is singular to working precision."""
+        n, m = B.shape
+        X = torch.empty(n, m, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.uce_solve_general(self._h, _ptr(A), _ptr(B), n, m, _ptr(X), _stream_ptr(self.device)), "uce_solve_general")
+        info = ctypes.c_int(0)
+        rc = self.lib.uce_status(self._h, ctypes.byref(info), _stream_ptr(self.device))
+        if rc == _lib.EDOM:
+            raise _lib.UceError(rc, f"solve of the indefinite system (singular to working precision at column {info.value - 1})")
+        _lib.check(rc, "uce_status")
+        return X
+
     def apply(self, W_old: torch.Tensor, DeltaT: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         rows, d = W_old.shape
         out = torch.empty_like(W_old) if out is None else out
@@ -653,17 +667,13 @@ def check_spd_inputs(scales, lamb: float) -> bool:
 def edit_slab_general(handle: UceHandle, slab: WeightSlab, C: torch.Tensor, G: torch.Tensor, s: torch.Tensor,
                       lamb: float) -> WeightSlab:
     """The edit for a symmetric INDEFINITE system (negative scales or lamb <= 0; reference: the same
-    `mat1 @ torch.inverse(mat2)` - its LU inverse does not care about definiteness).  An EDGE path outside the SPD hot path:
-    the f64 Gram of the primal form (uce_gram) and the dense apply (uce_apply) are the library's kernels; the d x d solve
-    Delta^T = A^-1 Bt is ONE general LU solve in f64 on the device through torch.linalg.solve (rocSOLVER - a library call,
-    stated here: the hand-written solver is a Cholesky and an indefinite A has no Cholesky factor).  Error ~1e-16 cond(A),
-    below the reference's fp32 LU inverse for every A that one can invert at all; a singular A raises like the reference's
-    torch.inverse does."""
+    `mat1 @ torch.inverse(mat2)` - its LU inverse does not care about definiteness).  An EDGE path outside the SPD hot path, on the
+    library's own kernels end to end: the f64 Gram of the primal form (uce_gram), the d x d solve Delta^T = A^-1 Bt by Gaussian
+    elimination with partial pivoting in f64 (uce_solve_general - no vendor solver), the dense apply (uce_apply).  Error
+    ~1e-16 d cond(A), below the reference's fp32 LU inverse for every A that one can invert at all; a singular A raises like the
+    reference's torch.inverse does."""
     A, Bt = handle.gram(C, G, s, lamb)
-    try:
-        DT = torch.linalg.solve(A, Bt).to(torch.float32).contiguous()
-    except RuntimeError as err:                              # torch._C._LinAlgError is a RuntimeError
-        raise _lib.UceError(_lib.EDOM, f"solve of the indefinite system ({err})") from None
+    DT = handle.solve_general(A, Bt)
     return slab.like(handle.apply(slab.data, DT))
 
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     "uce_gram": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "uce_solve_delta": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uce_solve_rhs": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "uce_solve_general": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "uce_apply": (_i, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
     "uce_dual_factors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "uce_apply_lowrank": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
