@@ -135,6 +135,9 @@ class _VaeAttention(nn.Module):
                 p = hd.softmax_rows(hd.linear_f32(q[i], k[i]), C ** -0.5, h.dtype)
                 hd.linear(p, vt, bv, out=o[i])
             return linear(self.to_out[0], o, residual=xr).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        if _unet.hip16(h):
+            raise RuntimeError(f"VAE attention over {L} tokens of {C} channels ({h.dtype}) has no HIP path (C % 32 == 0, L % 32 == 0, "
+                               "L <= 16384): there is no library attention behind the product path")
         o = F.scaled_dot_product_attention(linear(self.to_q, h)[:, None], linear(self.to_k, h)[:, None],
                                            linear(self.to_v, h)[:, None])[:, 0]
         return linear(self.to_out[0], o, residual=xr).reshape(B, H, W, C).permute(0, 3, 1, 2)
