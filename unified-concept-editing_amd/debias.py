@@ -39,8 +39,8 @@ def get_ratios(pipe, classify: Callable, slab: E.WeightSlab, edit_concepts, debi
                reduce_device=None) -> np.ndarray:
     """uce_sd_debias.py:14-35 (images are sampled UNSEEDED there too).
 
-    Sharded over the ranks of one node: edit concept i is sampled and classified on rank i % world (its
-    `num_images_per_prompt` images are one U-Net batch), every rank fills its own rows of the
+    Sharded over the ranks of one node: edit concept i is sampled and classified on rank i % world (the build's own pipeline
+    takes several concepts' `num_images_per_prompt` images per U-Net batch, any other pipeline one concept per call), every rank fills its own rows of the
     [N_edit, N_debias] float64 `direction_scale` matrix, and ONE all-reduce (sum; the rows are disjoint)
     gives every rank the whole matrix - a few hundred bytes over RCCL/xGMI (gloo on CPU)."""
     state = slab.state_dict()
@@ -49,13 +49,21 @@ def get_ratios(pipe, classify: Callable, slab: E.WeightSlab, edit_concepts, debi
     else:
         pipe.unet.load_state_dict(state, strict=False)
     direction_scale = np.zeros((len(edit_concepts), len(debias_concepts)), dtype=np.float64)
-    for i, concept in enumerate(edit_concepts):
-        if i % world != rank:
-            continue
-        images = pipe(concept, num_inference_steps=num_inference_steps, num_images_per_prompt=num_images_per_prompt,
-                      guidance_scale=guidance_scale).images
-        labels = classify(images, debias_concepts)
-        direction_scale[i] = ratios_from_labels(labels, debias_concepts, desired_ratios, max_diff)
+    mine = [i for i in range(len(edit_concepts)) if i % world == rank]
+    # the build's own pipeline on a GPU samples SEVERAL concepts per pipe() call (their images are independent draws, unseeded in
+    # the reference as well): one concept per call is a CFG batch of 2 x num_images_per_prompt = 20, where the U-Net's layers have too
+    # few output tiles to fill the chip; a foreign pipeline object keeps the reference's one call per concept
+    from .generate import auto_batch_prompts
+    dev = torch.device(getattr(pipe, "device", "cpu"))
+    group = auto_batch_prompts(pipe, dev, num_images_per_prompt, len(mine))
+    for lo in range(0, len(mine), group):
+        idx = mine[lo:lo + group]
+        prompts = [edit_concepts[i] for i in idx]
+        images = pipe(prompts[0] if len(prompts) == 1 else prompts, num_inference_steps=num_inference_steps,
+                      num_images_per_prompt=num_images_per_prompt, guidance_scale=guidance_scale).images
+        for j, i in enumerate(idx):
+            labels = classify(images[j * num_images_per_prompt:(j + 1) * num_images_per_prompt], debias_concepts)
+            direction_scale[i] = ratios_from_labels(labels, debias_concepts, desired_ratios, max_diff)
     if world > 1:
         import torch.distributed as dist
         t = torch.from_numpy(direction_scale).to(reduce_device if reduce_device is not None else "cpu")
