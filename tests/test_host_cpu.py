@@ -496,3 +496,19 @@ def test_one_wave_convolution_index_arithmetic_restated(TNW, stride, up):
     wref = torch.from_numpy(Wt).double().view(BN, 3, 3, Cin).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xin, wref, None, stride=stride, padding=1)[0].permute(1, 2, 0).reshape(256, BN).numpy()
     assert np.abs(Y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_ranks_of_one_node_get_disjoint_core_blocks():
+    """generate.rank_core_block: eight ranks split the cores the job may use into disjoint contiguous blocks (the NUMA-node form
+    needs the GPU box's sysfs; with an unknown node the split is even over everything) and the PNG workers fit the block."""
+    from uce_amd import generate as G
+    allowed = list(range(0, 256))
+    blocks = [G.rank_core_block(r, 8, allowed=allowed, node=-1) for r in range(8)]
+    assert all(len(b) == 32 for b in blocks)
+    assert sorted(c for b in blocks for c in b) == allowed
+    assert all(b == list(range(b[0], b[0] + 32)) for b in blocks)
+    odd = [G.rank_core_block(r, 3, allowed=range(10), node=-1) for r in range(3)]
+    assert all(len(b) == 3 for b in odd) and len({c for b in odd for c in b}) == 9
+    assert G.rank_core_block(0, 1, allowed=range(4), node=-1) == [0, 1, 2, 3]
+    assert G.pin_rank_to_cores(0, 1) == 0                                # a single rank is left alone
+    assert 0 <= G.png_worker_count(8, 8) <= 8 and G.png_worker_count(0, 1) == 0

@@ -40,40 +40,54 @@ def init_distributed(device: torch.device) -> Tuple[int, int]:
     return rank, world
 
 
+def gpu_numa_node(local: int) -> int:
+    """NUMA node of GPU `local` from sysfs (/sys/bus/pci/devices/<domain:bus:device.0>/numa_node), -1 when the platform does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+        return int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+    except Exception:  # noqa: BLE001
+        return -1
+
+
+def rank_core_block(local: int, world: int, allowed=None, node: int = None):
+    """The cores rank `local` of `world` (one process per GPU, one node) keeps to: a contiguous slice of the cores of its GPU's NUMA
+    node - the node's cores divided among the ranks whose GPUs hang off it, assuming the GPUs are spread evenly over the nodes -
+    or, when the node is unknown, an even split of every core the process may run on."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    node = gpu_numa_node(local) if node is None else node
+    block = []
+    if node >= 0:
+        try:
+            cpus = []
+            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus += list(range(int(a), int(b or a) + 1))
+            ok = set(allowed)
+            cpus = [c for c in cpus if c in ok]
+            nodes = max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]))
+            per_node = max(1, -(-world // nodes))                       # ranks sharing this node
+            step = max(1, len(cpus) // per_node)
+            k = local % per_node
+            block = cpus[k * step:(k + 1) * step]
+        except Exception:  # noqa: BLE001
+            block = []
+    if not block:
+        step = max(1, len(allowed) // max(1, world))
+        block = allowed[local * step:(local + 1) * step] or allowed
+    return block
+
+
 def pin_rank_to_cores(local: int, world: int) -> int:
-    """One process per GPU on one node: rank `local` of `world` keeps to its own contiguous block of the cores this process may run
-    on - preferring, when the node exposes it, the cores of the NUMA node its GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node) -
-    so that eight ranks' host work (CPU-seeded latent draws, tokenizer, graph replays, PNG encoding on worker threads) never migrates
-    across sockets or piles onto the same cores.  Returns the number of cores the rank ended up with (0: nothing changed - one rank,
-    or a platform without sched_setaffinity).  The torch intra-op pool is sized to the block."""
+    """One process per GPU on one node: the rank keeps to its own block of cores (`rank_core_block`: its GPU's NUMA node first), so
+    that eight ranks' host work (CPU-seeded latent draws, tokenizer, graph replays, PNG encoding on worker threads) never migrates
+    across sockets or piles onto the same cores.  Call it before any worker thread exists (they inherit the mask).  Returns the
+    number of cores of the block (0: nothing changed - one rank, or a platform without sched_setaffinity); torch's intra-op pool
+    is sized to the block."""
     if world <= 1 or not hasattr(os, "sched_setaffinity"):
         return 0
     try:
-        allowed = sorted(os.sched_getaffinity(0))
-        block = []
-        try:                                                        # cores of the GPU's NUMA node, split among the ranks that share it
-            bdf = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
-            if isinstance(bdf, int) or bdf is None:
-                bdf = None
-            if bdf:
-                node = int(open(f"/sys/bus/pci/devices/{bdf.lower()}/numa_node").read())
-                if node >= 0:
-                    txt = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
-                    cpus = []
-                    for part in txt.split(","):
-                        a, _, b = part.partition("-")
-                        cpus += list(range(int(a), int(b or a) + 1))
-                    cpus = [c for c in cpus if c in set(allowed)]
-                    nodes = max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]))
-                    per_node = max(1, -(-world // nodes))               # ranks sharing this node (GPUs spread evenly over the nodes)
-                    k = local % per_node
-                    step = max(1, len(cpus) // per_node)
-                    block = cpus[k * step:(k + 1) * step]
-        except Exception:  # noqa: BLE001
-            block = []
-        if not block:
-            step = max(1, len(allowed) // world)
-            block = allowed[local * step:(local + 1) * step] or allowed
+        block = rank_core_block(local, world)
         os.sched_setaffinity(0, set(block))
         torch.set_num_threads(max(1, min(len(block), 8)))
         return len(block)
