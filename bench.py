@@ -927,6 +927,10 @@ def main() -> None:
     # on cuda:0 and UCE_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
     if os.environ.get("UCE_BENCH_SAME_DEVICE") == "1":
         local = 0
+        # several processes on ONE device: the one-launch GroupNorm waits grid-wide inside a sample and needs its whole grid resident -
+        # with another process's grids on the same CUs that is not guaranteed (the wait is bounded, but two such kernels can starve
+        # each other until it expires); the dry run takes the two-kernel form
+        os.environ.setdefault("UCE_GN_FUSED", "0")
     backend = os.environ.get("UCE_BENCH_BACKEND", "nccl")
     dev_index = local if local < torch.cuda.device_count() else 0     # a launcher that masks one GPU per rank shows it as cuda:0
     torch.cuda.set_device(dev_index)
