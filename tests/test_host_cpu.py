@@ -248,7 +248,7 @@ def test_even_chunk_respects_cap_and_balances():
 def test_edit_slab_routes_indefinite_systems_to_the_general_form():
     """Negative scales / lamb <= 0 make lamb*I + C^T S C symmetric INDEFINITE: the reference's LU inverse accepts them, the
     Cholesky path cannot.  edit_slab decides on the host from the scalars (no launch) and hands such jobs to the
-    general form (uce_gram, one f64 LU solve, uce_apply); SPD jobs go to uce_edit as before."""
+    general form (uce_gram, the library's own f64 LU solve uce_solve_general, uce_apply); SPD jobs go to uce_edit as before."""
     from uce_amd import edit as E
     assert E.check_spd_inputs([1.0, 0.0, 2.5], 0.5)
     assert not E.check_spd_inputs([1.0, -0.5, 1.0], 0.5)
@@ -267,8 +267,8 @@ def test_edit_slab_routes_indefinite_systems_to_the_general_form():
             d = C.shape[1]
             return torch.eye(d, dtype=torch.float64) * 2.0, torch.zeros(d, d, dtype=torch.float64)
 
-        def solve_delta(self, A, Bt):
-            calls.append(("solve_delta", float(A[0, 0])))          # A A of the fake 2 I
+        def solve_general(self, A, Bt):
+            calls.append(("solve_general", float(A[0, 0])))
             return torch.zeros(A.shape[0], A.shape[0])
 
         def status(self):
@@ -284,11 +284,11 @@ def test_edit_slab_routes_indefinite_systems_to_the_general_form():
     assert [c[0] for c in calls] == ["edit"]
     calls.clear()
     E.edit_slab(FakeHandle(), slab, C, G, torch.tensor([1.0, -0.5, 1.0]), 0.5)
-    assert [c[0] for c in calls] == ["gram", "apply"]          # the LU solve in between is torch.linalg.solve on the fake's A
+    assert [c[0] for c in calls] == ["gram", "solve_general", "apply"]
     assert calls[0][1] == -0.5
     calls.clear()
     E.edit_slab(FakeHandle(), slab, C, G, torch.ones(3), 0.0)
-    assert [c[0] for c in calls] == ["gram", "apply"]
+    assert [c[0] for c in calls] == ["gram", "solve_general", "apply"]
 
 
 def test_two_way_f16_split_model_carries_fp32_products():
