@@ -192,6 +192,8 @@ int uce_ensure_sk(uce_ctx* h, size_t bytes, size_t tiles) {
 
 constexpr size_t LA_FLAGS = 2 * 22 * 22 + 2 * 22 + 8;          // k_potrf_la: systems of up to 22 diagonal blocks
 
+int g_uce_conv_tapin = -1;
+
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
@@ -234,6 +236,7 @@ int uce_create(uce_handle_t* out, int device) {
                         env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0),
                         env_int("UCE_CONV_W1", 1), env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
   }
+  g_uce_conv_tapin = env_int("UCE_CONV_TAPIN", -1);
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->status, 0, sizeof(int));

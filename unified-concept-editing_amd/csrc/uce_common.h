@@ -197,6 +197,20 @@ struct UceProfScope {
   }
 };
 
+// k-tile order of the implicit-GEMM convolutions: CHUNK-major - the nine taps of a 64-channel chunk back to back - instead of the
+// weight's own tap-major order.  A tap's pixel segments are shared with its neighbours; tap-major brings a segment back cch k-tiles
+// later (Cin = 320: 164 KB of A per CU, 5 MB per XCD in between - more than its 4 MB L2), chunk-major one k-tile later (33 KB).
+// Measured on an MI355X at 128 prompts per call (tools/probe_r04.py conv, profiles/r05/conv_tap_order_b128_*.jsonl; us, tap-major |
+// chunk-major, k_conv3x3_w1): 320 -> 320 @ 64^2 838 | 802, 960 -> 320 @ 64^2 2316 | 2092, 640 -> 320 @ 64^2 1507 | 1454, 1920 -> 640 @ 32^2
+// 2123 | 2011, 1280 -> 640 @ 32^2 1414 | 1374; alone a few small-activation layers are level or behind (320 -> 640 @ 32^2 370 | 388, 2560 ->
+// 1280 @ 16^2 1323 | 1343), inside the generation loop chunk-major EVERYWHERE is the fastest: same box, 128 images at 128 prompts per
+// call, 8.73 / 8.73 images/s tap-major, 8.86 / 8.85 chunk-major from 1 M source elements per image, 9.05 always (tools/ab_gen.sh).
+extern int g_uce_conv_tapin;      // UCE_CONV_TAPIN (measurements, read at uce_create): -1 / 1 = chunk-major (default), 0 = tap-major
+inline int conv_tap_inner(int H, int W, int Cin, int up, int sd) {
+  (void)H; (void)W; (void)Cin; (void)up; (void)sd;
+  return g_uce_conv_tapin == 0 ? 0 : 1;
+}
+
 // ---- internal launchers (defined across the .hip files) -------------------------------------
 int uce_ensure(uce_ctx* h, int d, int n);
 // uce_conv_dma.hip: 1 = launched (*rc = status), 0 = shape not taken by the direct-to-LDS form

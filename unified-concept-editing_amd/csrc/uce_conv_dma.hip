@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv3x3_dma(const unsigned short
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                      long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
                                                      int sd, const unsigned short* __restrict__ Rs,
-                                                     float* __restrict__ skws, unsigned* __restrict__ sktick, int S) {
+                                                     float* __restrict__ skws, unsigned* __restrict__ sktick, int S, int tapin) {
   // sd: stride (1, or 2 = diffusers' Downsample2D: output pixel (y, x) reads source pixels (2y + dy, 2x + dx) of a [N, 2H, 2W, Cin]
   // tensor, pad 1); Rs: optional residual [M, Cout] added in the epilogue (the ResnetBlock2D's `x + conv2(.) + b`)
   static_assert(WGM * WGN == NW && (NW == 8 || (NW == 4 && BK == 64 && NSTP == 2)), "waves (the four-wave form: two-stage ring only - its wait counts)");
@@ -166,7 +166,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv3x3_dma(const unsigned short
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)w_bytes, 0x00020000);
 
   auto stage = [&](int st, int kt) {
-    const int tap = kt / cch, c0 = (kt - tap * cch) * CD_BK;
+    // k-tile order: tap-major, or chunk-major for large activations (uce_common.h: conv_tap_inner)
+    const int chunk = tapin ? kt / 9 : 0;
+    const int tap = tapin ? kt - chunk * 9 : kt / cch;
+    const int c0 = tapin ? chunk * CD_BK : (kt - tap * cch) * CD_BK;
+    const unsigned wk = (unsigned)((tapin ? tap * Cin + c0 : kt * CD_BK) * 2);
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
     unsigned char* sbase = smem + st * STAGE;
 #pragma unroll
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv3x3_dma(const unsigned short
     for (int j = 0; j < NBJ; ++j) {
       if (NW * j + w < NB)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + CD_BM * CD_BK * 2 + (NW * j + w) * 1024), 16,
-                                                 b_base[j] == OOB ? OOB : b_base[j] + (unsigned)(kt * CD_BK * 2), 0, 0, 0);
+                                                 b_base[j] == OOB ? OOB : b_base[j] + wk, 0, 0, 0);
     }
   };
   // waits until this wave's DMAs of every k-tile but the last (NST - 2) issued have landed
@@ -313,11 +317,11 @@ int launch_dma(const void* x, const void* w, const void* bias, void* y, long M, 
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, true, WIDE, BK, SK, NSTP, NW>), dim3((unsigned)nwg), dim3(64 * NW), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
-                       (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S);
+                       (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S, conv_tap_inner(H, W, Cin, up, sd));
   else
     hipLaunchKernelGGL((k_conv3x3_dma<WGM, WGN, TM, TN, false, WIDE, BK, SK, NSTP, NW>), dim3((unsigned)nwg), dim3(64 * NW), smem, st, (const unsigned short*)x,
                        (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up,
-                       (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S);
+                       (int)mtiles, ntiles, sd, (const unsigned short*)res, skws, sktick, S, conv_tap_inner(H, W, Cin, up, sd));
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }

@@ -68,7 +68,7 @@ template <int TNW, bool F16, int TAPS>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                        const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y,
                                                        long M, int H, int W, int Cin, int Cout, int up, int mtiles, int ntiles,
-                                                       int sd, const unsigned short* __restrict__ Rs) {
+                                                       int sd, const unsigned short* __restrict__ Rs, int tapin) {
   constexpr int BN = 32 * TNW;
   constexpr int NB = BN / 8 / 4;                     // B DMA instructions per wave and k-tile
   constexpr int PER = W1_NA + NB;
@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
   auto dma = [&](int st, int kt, int i) __attribute__((always_inline)) {
     unsigned char* sbase = smem + st * STAGE;
     if (i < W1_NA) {
-      const int tap = TAPS == 1 ? 0 : kt / cch, c0 = (kt - tap * cch) * W1_BK;
+      // k-tile order: tap-major (the weight's own [tap][Cin] order) or, for large activations, chunk-major - the nine taps of a
+      // 64-channel chunk back to back, so that the pixel segments a tap shares with its neighbours are re-read while they are still
+      // in the XCD's L2 (tap-major: a segment comes back cch k-tiles = 164 KB of A per CU later, 5 MB per XCD; chunk-major: 33 KB)
+      const int chunk = tapin ? kt / 9 : 0;
+      const int tap = TAPS == 1 ? 0 : (tapin ? kt - chunk * 9 : kt / cch);
+      const int c0 = TAPS == 1 ? kt * W1_BK : (tapin ? chunk * W1_BK : (kt - tap * cch) * W1_BK);
       const int dy = TAPS == 1 ? 0 : tap / 3 - 1, dx = TAPS == 1 ? 0 : tap - (tap / 3) * 3 - 1;
       const int yy = (a_yx[i] >> 16) + dy, xx = (a_yx[i] & 0xffff) + dx;
       const bool ok = (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
     } else {
       const int j = i - W1_NA;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sbase + W1_BM * W1_ROWB + (4 * j + w) * 1024), 16,
-                                               b_base[j] == OOB ? OOB : b_base[j] + (unsigned)(kt * W1_BK * 2), 0, 0, 0);
+                                               b_base[j] == OOB ? OOB : b_base[j] + (unsigned)((tapin ? (kt % 9) * Cin + (kt / 9) * W1_BK : kt * W1_BK) * 2), 0, 0, 0);
     }
   };
 
@@ -293,11 +298,11 @@ int launch_w1(const void* x, const void* w, const void* bias, void* y, long M, i
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_conv3x3_w1<TNW, true, TAPS>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x, (const unsigned short*)w,
                        (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up, (int)mtiles, ntiles, sd,
-                       (const unsigned short*)res);
+                       (const unsigned short*)res, TAPS == 9 ? conv_tap_inner(H, W, Cin, up, sd) : 0);
   else
     hipLaunchKernelGGL((k_conv3x3_w1<TNW, false, TAPS>), dim3((unsigned)nwg), dim3(256), smem, st, (const unsigned short*)x, (const unsigned short*)w,
                        (const unsigned short*)bias, (unsigned short*)y, M, H, W, Cin, Cout, up, (int)mtiles, ntiles, sd,
-                       (const unsigned short*)res);
+                       (const unsigned short*)res, TAPS == 9 ? conv_tap_inner(H, W, Cin, up, sd) : 0);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
