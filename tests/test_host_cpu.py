@@ -434,7 +434,7 @@ def test_one_wave_convolution_index_arithmetic_restated(TNW, stride, up):
     epilogue - assembled into an output and compared with torch's convolution."""
     import numpy as np
     rng = np.random.default_rng(TNW + stride + up)
-    BN, Cin, cch = 32 * TNW, 64, 1
+    BN, Cin, cch = 32 * TNW, 128, 2                   # two 64-channel chunks: the k-tiles walk them CHUNK-major (nine taps each)
     Ho, Wo = 16, 16                                    # output image: 256 pixels = one 256-pixel tile
     Hi, Wi = Ho * stride, Wo * stride                  # the image the taps index
     Hs, Ws = Hi >> up, Wi >> up                        # the stored image (before the fused 2x upsample)
@@ -443,7 +443,8 @@ def test_one_wave_convolution_index_arithmetic_restated(TNW, stride, up):
     lanes = np.arange(64)
     acc = np.zeros((4, TNW, 8, 64, 4), np.float64)     # [wave][channel tile a][pixel tile b][lane][register]
     for kt in range(9 * cch):
-        tap, c0 = kt // cch, (kt % cch) * 64
+        chunk, tap = kt // 9, kt % 9                   # conv_tap_inner (csrc/uce_common.h): the taps of a chunk back to back
+        c0 = chunk * 64
         dy, dx = tap // 3 - 1, tap % 3 - 1
         # ---- the LDS image of this k-tile: A rows 0..255 (pixels), B rows 0..BN-1 (channels), 8 slots of 8 elements
         A = np.zeros((256, 8, 8), np.float32)
@@ -462,7 +463,7 @@ def test_one_wave_convolution_index_arithmetic_restated(TNW, stride, up):
                 R = 8 * (4 * j + w) + r
                 c = p ^ ((R >> 1) & 7)
                 for ln in lanes:
-                    Bm[R[ln], p[ln]] = Wt[R[ln], kt * 64 + 8 * c[ln]:kt * 64 + 8 * c[ln] + 8]
+                    Bm[R[ln], p[ln]] = Wt[R[ln], tap * Cin + c0 + 8 * c[ln]:tap * Cin + c0 + 8 * c[ln] + 8]
         # ---- two k-steps of 32: fragments and MFMAs
         l16, lq = lanes & 15, lanes >> 4
         key = (l16 >> 1) & 7
