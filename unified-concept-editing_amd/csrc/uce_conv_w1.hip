@@ -62,6 +62,100 @@ constexpr int W1_NA = W1_BM / 8 / 4;                 // A DMA instructions per w
 template <int TNW>
 constexpr size_t w1_smem() { return (size_t)2 * (W1_BM + 32 * TNW) * W1_ROWB; }
 
+// Whole-row epilogue of k_conv3x3_w1.  Memory operations of a wave complete in order (one vmcnt for loads and stores), so a
+// residual load issued behind a store waits for that store's acknowledgement: the row segments leave in sub-batches of SB pieces,
+// and the residual pieces of sub-batch q + 1 are requested BEFORE the stores of sub-batch q go out (across the two passes as
+// well) - the wait for them is a `vmcnt(stores of q)`.  Loads and stores are buffer operations on a descriptor of the wave's 128
+// pixels clipped to M: no branch, nothing for the compiler to sink into a conditional block and serialise there (before: one
+// residual load + vmcnt(0) + store per piece, 2 x BN / 16 round trips per wave with one wave per SIMD to hide them).
+constexpr int W1_PB = 4;                             // pixel tiles per pass (two passes)
+template <int TNW, bool F16, bool RES>
+__device__ __forceinline__ void w1_epilogue(float4_t (&acc)[10][8], unsigned char* slab, const unsigned short* __restrict__ bias,
+                                            const unsigned short* __restrict__ Rs, unsigned short* __restrict__ Y, long mrow,
+                                            int ncol0, long M, int Cout, int lane) {
+  constexpr int BN = 32 * TNW;
+  constexpr int SROW = BN + 16;                      // bytes per slab row (BN / 2 channels of 2 bytes)
+  constexpr int CPR = BN / 16;                       // 16-byte pieces per slab row
+  constexpr int ITP = (16 * W1_PB * CPR) / 64;       // pieces per lane and pass (= CPR)
+  constexpr int SB = ITP % 5 == 0 ? 5 : (ITP % 4 == 0 ? 4 : ITP);
+  constexpr int NSB = ITP / SB;                      // sub-batches per pass
+  const int l16 = lane & 15, lq = lane >> 4;
+  const long left = M - mrow;
+  const int rows = left <= 0 ? 0 : (left < 128 ? (int)left : 128);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y + mrow * Cout), 0, rows * Cout * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? Rs + mrow * Cout : Y), 0, RES ? rows * Cout * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, bias ? Cout * 2 : 0, 0x00020000);
+  auto piece_off = [&](int q, int j) {               // byte offset (within the wave's rows) of piece j of sub-batch q
+    const int pb = q / NSB, it = (q % NSB) * SB + j;
+    const int idx = it * 64 + lane;
+    const int row = idx / CPR, ch = idx - row * CPR;
+    return (unsigned)(((16 * W1_PB * pb + row) * Cout + ncol0 + ch * 8) * 2);
+  };
+  uint4_t r[2][SB];
+  if constexpr (RES) {
+#pragma unroll
+    for (int j = 0; j < SB; ++j) r[0][j] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, piece_off(0, j), 0, 0));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float bv[10][4];
+  {
+    uint2_t b2[10];
+#pragma unroll
+    for (int a = 0; a < TNW; ++a)
+      b2[a] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(br, (unsigned)(ncol0 + 16 * a + 4 * lq) * 2u, 0, 0));
+#pragma unroll
+    for (int a = 0; a < TNW; ++a) {                  // (no bias: the empty descriptor reads 0)
+      bv[a][0] = w1_tof<F16>((unsigned short)(b2[a][0] & 0xffffu));
+      bv[a][1] = w1_tof<F16>((unsigned short)(b2[a][0] >> 16));
+      bv[a][2] = w1_tof<F16>((unsigned short)(b2[a][1] & 0xffffu));
+      bv[a][3] = w1_tof<F16>((unsigned short)(b2[a][1] >> 16));
+    }
+  }
+#pragma unroll
+  for (int pb = 0; pb < 8 / W1_PB; ++pb) {
+#pragma unroll
+    for (int bb = 0; bb < W1_PB; ++bb) {
+      const int b = pb * W1_PB + bb;
+#pragma unroll
+      for (int a = 0; a < TNW; ++a)
+        *(uint2_t*)(slab + (16 * bb + l16) * SROW + (16 * a + 4 * lq) * 2) =
+            (uint2_t){w1_pack2<F16>(acc[a][b][0] + bv[a][0], acc[a][b][1] + bv[a][1]),
+                      w1_pack2<F16>(acc[a][b][2] + bv[a][2], acc[a][b][3] + bv[a][3])};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) {
+      const int q = pb * NSB + s;
+      if constexpr (RES) {
+        if (q + 1 < (8 / W1_PB) * NSB) {             // (resolved when the loops are unrolled)
+#pragma unroll
+          for (int j = 0; j < SB; ++j)
+            r[(q + 1) & 1][j] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, piece_off(q + 1, j), 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);           // (the scheduler, short of registers here, sinks every load to its use)
+      }
+      uint4_t v[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int idx = (s * SB + j) * 64 + lane;
+        const int row = idx / CPR, ch = idx - row * CPR;
+        v[j] = *(const uint4_t*)(slab + row * SROW + ch * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        uint4_t o = v[j];
+        if constexpr (RES) {
+          const uint4_t r4 = r[q & 1][j];
+          o = (uint4_t){w1_add2<F16>(o[0], r4[0]), w1_add2<F16>(o[1], r4[1]), w1_add2<F16>(o[2], r4[2]), w1_add2<F16>(o[3], r4[3])};
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, yr, piece_off(q, j), 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is read before the next pass overwrites it
+  }
+}
+
 // TAPS: 9 = the 3 x 3 convolution.  (1 = its centre tap alone on a 1 x 1 "image" per row, i.e. a linear layer over contiguous rows:
 // measured behind UCE_GEMM_W1 in round 4, level with or behind k_gemm_dma on every U-Net shape - no longer instantiated, HISTORY.md)
 template <int TNW, bool F16, int TAPS>
@@ -231,53 +325,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_w1(const unsigned short* __r
   // ---- epilogue: 64-pixel slabs (four pixel tiles per pass, two passes) through this wave's LDS region.  acc[a][b] = channels
   // n0 + wn BN/2 + 16 a + 4 lq + {0..3} of pixel m0 + wm 128 + 16 b + l16.  Slab row = one pixel, BN/2 channels (+ 16 bytes: rows
   // two bank groups apart); the rows leave as 16-byte pieces, consecutive lanes on consecutive pieces of a row.
-  constexpr int SROW = BN + 16;                      // bytes per slab row (BN / 2 channels of 2 bytes)
-  constexpr int CPR = BN / 16;                       // 16-byte pieces per slab row
-  constexpr int PB = 4;                              // pixel tiles per pass
-  unsigned char* slab = smem + w * (16 * PB) * SROW;
+  unsigned char* slab = smem + w * (16 * W1_PB) * (BN + 16);
   const int ncol0 = n0 + wn * (BN / 2);
-  float bv[10][4];
-#pragma unroll
-  for (int a = 0; a < TNW; ++a) {
-    bv[a][0] = bv[a][1] = bv[a][2] = bv[a][3] = 0.f;
-    if (bias) {
-      const uint2_t b2 = *(const uint2_t*)(bias + ncol0 + 16 * a + 4 * lq);
-      bv[a][0] = w1_tof<F16>((unsigned short)(b2[0] & 0xffffu));
-      bv[a][1] = w1_tof<F16>((unsigned short)(b2[0] >> 16));
-      bv[a][2] = w1_tof<F16>((unsigned short)(b2[1] & 0xffffu));
-      bv[a][3] = w1_tof<F16>((unsigned short)(b2[1] >> 16));
-    }
-  }
-#pragma unroll
-  for (int pb = 0; pb < 8 / PB; ++pb) {
-#pragma unroll
-    for (int bb = 0; bb < PB; ++bb) {
-      const int b = pb * PB + bb;
-#pragma unroll
-      for (int a = 0; a < TNW; ++a)
-        *(uint2_t*)(slab + (16 * bb + l16) * SROW + (16 * a + 4 * lq) * 2) =
-            (uint2_t){w1_pack2<F16>(acc[a][b][0] + bv[a][0], acc[a][b][1] + bv[a][1]),
-                      w1_pack2<F16>(acc[a][b][2] + bv[a][2], acc[a][b][3] + bv[a][3])};
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const long mrow0 = m0 + wm * 128 + 16 * PB * pb;
-#pragma unroll
-    for (int it = 0; it < (16 * PB * CPR) / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / CPR, ch = idx - row * CPR;
-      const long m = mrow0 + row;
-      if (m < M) {
-        uint4_t v = *(const uint4_t*)(slab + row * SROW + ch * 16);
-        const int n = ncol0 + ch * 8;
-        if (Rs) {
-          const uint4_t r4 = *(const uint4_t*)(Rs + m * Cout + n);
-          v = (uint4_t){w1_add2<F16>(v[0], r4[0]), w1_add2<F16>(v[1], r4[1]), w1_add2<F16>(v[2], r4[2]), w1_add2<F16>(v[3], r4[3])};
-        }
-        *(uint4_t*)(Y + m * Cout + n) = v;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is read before the next pass overwrites it
-  }
+  const long mrow = m0 + wm * 128;                   // the wave's 128 pixels (uniform)
+  if (Rs) w1_epilogue<TNW, F16, true>(acc, slab, bias, Rs, Y, mrow, ncol0, M, Cout, lane);
+  else w1_epilogue<TNW, F16, false>(acc, slab, bias, Rs, Y, mrow, ncol0, M, Cout, lane);
 }
 
 template <int TNW, int TAPS>

@@ -65,70 +65,134 @@ constexpr int row_bytes() { return (GEGLU ? CH * 32 : CH * 64) + 16; }        //
 template <int CH, bool GEGLU>
 constexpr int wave_bytes() { return 32 * row_bytes<CH, GEGLU>(); }
 
-// one chunk: tiles CA .. CA + CW - 1 of row tile b
-template <int TM, int TN, bool F16, bool GEGLU, int CH, int CA>
-__device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], int b, unsigned char* lds, const unsigned short* __restrict__ bias,
-                                            const unsigned short* __restrict__ res, long ldr, unsigned short* __restrict__ Y,
-                                            long ldy, long mrow0, int ncol0, long M, int N, int lane) {
-  constexpr int CW = (TN - CA < CH) ? TN - CA : CH;
-  constexpr int ROWB = row_bytes<CH, GEGLU>();
-  constexpr int CPR = (GEGLU ? CW * 32 : CW * 64) / 16;                   // 16-byte pieces per row of the chunk
-  constexpr int ITER = (32 * CPR) / 64;                                  // 32 rows x CPR pieces over 64 lanes
-  const int li = lane & 31, lh = lane >> 5;
-  const int ocol0 = (GEGLU ? ncol0 / 2 : ncol0) + (GEGLU ? CA * 16 : CA * 32);
-  const int NO = GEGLU ? N / 2 : N;
-  // ---- park the chunk: 8 bytes per lane per (tile, register group)
+// Memory operations of a wave complete IN ORDER on gfx9 (one vmcnt for loads and stores): a load issued after a store cannot
+// be waited for without waiting for that store's acknowledgement too.  The epilogue therefore never issues a load behind a
+// store it does not want to wait for: the bias of the wave's columns is folded into the accumulators up front (loads in
+// batches), and the residual rows of chunk k + 1 are requested BEFORE chunk k's stores go out, so the wait for them is a
+// `vmcnt(stores of chunk k)` that the stores slip past.  Residual loads and output stores are BUFFER operations on a
+// descriptor of the wave's own rows (base = its first row, extent = its rows inside M): rows beyond M fall outside the
+// descriptor, columns beyond N get the out-of-range offset - no branch anywhere, so the compiler cannot sink a load (or the
+// LDS read) into a conditional store block and serialise it there.  (Before: one bias load + `vmcnt(0)` per (tile, register
+// group) and one LDS read + residual load + `vmcnt(0)` + store per 16-byte piece - every one a full round trip, with 8 waves
+// per CU to hide it.)
+template <int TN, int CH>
+constexpr int col_chunks() { return (TN + CH - 1) / CH; }
+template <int TN, bool GEGLU, int CH, int CA>
+struct chunk_geom {
+  static constexpr int CW = (TN - CA < CH) ? TN - CA : CH;               // 32-column tiles of this chunk
+  static constexpr int CPR = (GEGLU ? CW * 32 : CW * 64) / 16;           // 16-byte pieces per row of the chunk
+  static constexpr int ITER = (32 * CPR) / 64;                           // 32 rows x CPR pieces over 64 lanes
+};
+template <int CH, bool GEGLU>
+constexpr int max_iter() { return (32 * ((GEGLU ? CH * 32 : CH * 64) / 16)) / 64; }
+// bit 31 for a column beyond the bound: the offset leaves every descriptor (arithmetic, not a select - the compiler turns a
+// select between a computed offset and a constant into a divergent branch around the load)
+__device__ __forceinline__ unsigned oob_bit(int n, int NO) { return (unsigned)(NO - 1 - n) & 0x80000000u; }
+
+// descriptor of `rows` rows of `ld` elements from `base` (uniform arguments)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const unsigned short* base, long ld, int rows) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)rows * ld * 2), 0x00020000);
+}
+
+// residual rows of chunk K (row tile K / NCA, column chunk K % NCA): lane = (row, 16-byte piece)
+template <int TN, int CH, int K, int IT>
+__device__ __forceinline__ void fetch_residual(uint4_t (&r)[IT], __amdgpu_buffer_rsrc_t rr, long ldr, int ocol0w, int NO, int lane) {
+  constexpr int NCA = col_chunks<TN, CH>();
+  constexpr int b = K / NCA, CA = (K % NCA) * CH;
+  using G = chunk_geom<TN, false, CH, CA>;
 #pragma unroll
-  for (int aa = 0; aa < CW; ++aa) {
+  for (int it = 0; it < G::ITER; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / G::CPR, ch = idx - row * G::CPR;
+    const int n = ocol0w + CA * 32 + ch * 8;
+    const unsigned off = (((unsigned)(b * 32 + row) * (unsigned)ldr + (unsigned)n) * 2u) | oob_bit(n, NO);
+    r[it] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0));
+  }
+}
+
+// chunk K: park (convert / GEGLU) -> request chunk K + 1's residual rows -> whole row segments out -> next chunk
+template <int TM, int TN, bool F16, bool GEGLU, int CH, bool RES, int K, int IT, bool PIPE, bool LEAN>
+__device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], unsigned char* lds, uint4_t (&r)[IT], __amdgpu_buffer_rsrc_t rr,
+                                            long ldr, __amdgpu_buffer_rsrc_t yr, long ldy, int ocol0w, int NO, int lane) {
+  constexpr int NCA = col_chunks<TN, CH>();
+  constexpr int b = K / NCA, CA = (K % NCA) * CH;
+  using G = chunk_geom<TN, GEGLU, CH, CA>;
+  constexpr int ROWB = row_bytes<CH, GEGLU>();
+  const int li = lane & 31, lh = lane >> 5;
+  if constexpr (RES && !PIPE && !LEAN) fetch_residual<TN, CH, K, IT>(r, rr, ldr, ocol0w, NO, lane);   // (under the parking VALU)
+  // ---- park the chunk: 8 bytes per lane per (tile, register group); the bias is in the accumulators already
+#pragma unroll
+  for (int aa = 0; aa < G::CW; ++aa) {
     const int a = CA + aa;
     if constexpr (GEGLU) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const int nh = ncol0 + a * 32 + 8 * g + 4 * lh;                  // hidden columns; their gates sit 16 further
-        float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias && nh < N) {
-          unpack4<F16>(*(const uint2_t*)(bias + nh), bh);
-          unpack4<F16>(*(const uint2_t*)(bias + nh + 16), bg);
-        }
+      for (int g = 0; g < 2; ++g) {                                      // hidden columns 8 g + 4 lh + i; their gates sit 16 further
         float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (acc[a][b][4 * g + i] + bh[i]) * gelu_erf(acc[a][b][4 * (g + 2) + i] + bg[i]);
+        for (int i = 0; i < 4; ++i) o[i] = acc[a][b][4 * g + i] * gelu_erf(acc[a][b][4 * (g + 2) + i]);
         *(uint2_t*)(lds + li * ROWB + (aa * 16 + 8 * g + 4 * lh) * 2) = (uint2_t){pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3])};
       }
     } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ncol0 + a * 32 + 8 * g + 4 * lh;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias && n < N) unpack4<F16>(*(const uint2_t*)(bias + n), bv);
+      for (int g = 0; g < 4; ++g)
         *(uint2_t*)(lds + li * ROWB + (aa * 32 + 8 * g + 4 * lh) * 2) =
-            (uint2_t){pack2<F16>(acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1]),
-                      pack2<F16>(acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3])};
-      }
+            (uint2_t){pack2<F16>(acc[a][b][4 * g], acc[a][b][4 * g + 1]), pack2<F16>(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3])};
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  uint4_t rn[PIPE ? IT : 1];
+  if constexpr (RES && PIPE && K + 1 < TM * NCA) fetch_residual<TN, CH, K + 1, IT>(rn, rr, ldr, ocol0w, NO, lane);
+  if constexpr (RES && !PIPE && LEAN) fetch_residual<TN, CH, K, IT>(r, rr, ldr, ocol0w, NO, lane);    // (no registers to spare earlier)
   // ---- whole row segments out: lane = (row, 16-byte piece), consecutive lanes on consecutive pieces
+  const int ocol0 = ocol0w + (GEGLU ? CA * 16 : CA * 32);
+  uint4_t v[G::ITER];
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
+  for (int it = 0; it < G::ITER; ++it) {
     const int idx = it * 64 + lane;
-    const int row = idx / CPR, ch = idx - row * CPR;
-    uint4_t v = *(const uint4_t*)(lds + row * ROWB + ch * 16);
-    const long m = mrow0 + b * 32 + row;
+    const int row = idx / G::CPR, ch = idx - row * G::CPR;
+    v[it] = *(const uint4_t*)(lds + row * ROWB + ch * 16);
+  }
+#pragma unroll
+  for (int it = 0; it < G::ITER; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / G::CPR, ch = idx - row * G::CPR;
     const int n = ocol0 + ch * 8;
-    if (m < M && n < NO) {
-      if constexpr (!GEGLU) {
-        if (res) {
-          const uint4_t r4 = *(const uint4_t*)(res + m * ldr + n);
-          v = (uint4_t){add2<F16>(v[0], r4[0]), add2<F16>(v[1], r4[1]), add2<F16>(v[2], r4[2]), add2<F16>(v[3], r4[3])};
-        }
-      }
-      *(uint4_t*)(Y + m * ldy + n) = v;
-    }
+    uint4_t o = v[it];
+    if constexpr (RES)
+      o = (uint4_t){add2<F16>(o[0], r[it][0]), add2<F16>(o[1], r[it][1]), add2<F16>(o[2], r[it][2]), add2<F16>(o[3], r[it][3])};
+    const unsigned off = (((unsigned)(b * 32 + row) * (unsigned)ldy + (unsigned)n) * 2u) | oob_bit(n, NO);
+    __builtin_amdgcn_raw_buffer_store_b128(o, yr, off, 0, 0);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the chunk is read before the next one overwrites it
-  if constexpr (CA + CH < TN)
-    store_chunk<TM, TN, F16, GEGLU, CH, CA + CH>(acc, b, lds, bias, res, ldr, Y, ldy, mrow0, ncol0, M, N, lane);
+  if constexpr (K + 1 < TM * NCA) {
+    if constexpr (PIPE) store_chunk<TM, TN, F16, GEGLU, CH, RES, K + 1, IT, PIPE, LEAN>(acc, lds, rn, rr, ldr, yr, ldy, ocol0w, NO, lane);
+    else store_chunk<TM, TN, F16, GEGLU, CH, RES, K + 1, IT, PIPE, LEAN>(acc, lds, r, rr, ldr, yr, ldy, ocol0w, NO, lane);
+  }
+}
+
+// bias into the accumulators, BG column tiles at a time: their loads first, then the adds.  `br` covers the N bias values (no
+// bias: an empty descriptor) - columns beyond it read 0, and a null bias adds 0.f as the per-group epilogue does (- 0 + 0 = + 0).
+template <int TM, int TN, bool F16, int BGMAX, int A0>
+__device__ __forceinline__ void add_bias(float16_t (&acc)[TN][TM], __amdgpu_buffer_rsrc_t br, int ncol0, int lh) {
+  constexpr int BG = (TN - A0 < BGMAX) ? TN - A0 : BGMAX;                // 8 BG transient registers
+  uint2_t bq[BG][4];
+#pragma unroll
+  for (int a = 0; a < BG; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bq[a][g] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(br, (unsigned)(ncol0 + (A0 + a) * 32 + 8 * g + 4 * lh) * 2u, 0, 0));
+#pragma unroll
+  for (int a = 0; a < BG; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float bv[4];
+      unpack4<F16>(bq[a][g], bv);
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[A0 + a][b][4 * g + i] += bv[i];
+    }
+  if constexpr (A0 + BG < TN) add_bias<TM, TN, F16, BGMAX, A0 + BG>(acc, br, ncol0, lh);
 }
 
 // acc[a][b][4 g + i]: column 32 a + 8 g + 4 lh + i of the wave's TN x 32 columns, row 32 b + li of its TM x 32 rows.
@@ -136,13 +200,34 @@ __device__ __forceinline__ void store_chunk(float16_t (&acc)[TN][TM], int b, uns
 //   bias    indexed by the (interleaved, for GEGLU) column; may be null.   res / ldr: residual rows (MODE 0), may be null
 //   mrow0   first row of the wave's slab (global), ncol0 its first column in the index space of `bias` (a multiple of 32)
 //   M, N    bounds in that space (GEGLU: N counts the interleaved columns; the output has N / 2)
-template <int TM, int TN, bool F16, bool GEGLU, int CH = TN>
+//   LEAN    the kernel runs under a 128-register cap
+template <int TM, int TN, bool F16, bool GEGLU, int CH = TN, bool LEAN = false>
 __device__ __forceinline__ void store_rows(float16_t (&acc)[TN][TM], unsigned char* lds, const unsigned short* __restrict__ bias,
                                            const unsigned short* __restrict__ res, long ldr, unsigned short* __restrict__ Y,
                                            long ldy, long mrow0, int ncol0, long M, int N, int lane) {
-#pragma unroll
-  for (int b = 0; b < TM; ++b)
-    store_chunk<TM, TN, F16, GEGLU, CH, 0>(acc, b, lds, bias, res, ldr, Y, ldy, mrow0, ncol0, M, N, lane);
+  const int lh = lane >> 5;
+  const int NO = GEGLU ? N / 2 : N;
+  const int ocol0w = GEGLU ? ncol0 / 2 : ncol0;
+  add_bias<TM, TN, F16, LEAN ? 1 : 3, 0>(acc, __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, bias ? N * 2 : 0, 0x00020000), ncol0, lh);
+  // the wave's rows (uniform: the caller's wave index is a scalar; the two halves go through readfirstlane so that the
+  // descriptors are scalar whatever the compiler can prove)
+  const long mrow = ((long)__builtin_amdgcn_readfirstlane((int)(mrow0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)mrow0);
+  const long left = M - mrow;
+  const int rows = left <= 0 ? 0 : (left < TM * 32 ? (int)left : TM * 32);
+  const __amdgpu_buffer_rsrc_t yr = rows_rsrc(Y + mrow * ldy, ldy, rows);
+  constexpr int IT = max_iter<CH, GEGLU>();
+  // two chunks' residual rows in registers where the budget has them: LEAN = a 128-register kernel (two workgroups of 512 per CU)
+  constexpr bool PIPE = IT <= 4 && (!LEAN || TM * TN <= 4);
+  uint4_t r[IT];
+  if constexpr (!GEGLU) {
+    if (res) {                                                           // (uniform)
+      const __amdgpu_buffer_rsrc_t rr = rows_rsrc(res + mrow * ldr, ldr, rows);
+      if constexpr (PIPE) fetch_residual<TN, CH, 0, IT>(r, rr, ldr, ocol0w, NO, lane);
+      store_chunk<TM, TN, F16, false, CH, true, 0, IT, PIPE, LEAN>(acc, lds, r, rr, ldr, yr, ldy, ocol0w, NO, lane);
+      return;
+    }
+  }
+  store_chunk<TM, TN, F16, GEGLU, CH, false, 0, IT, false, LEAN>(acc, lds, r, yr, ldr, yr, ldy, ocol0w, NO, lane);
 }
 
 }  // namespace uce_epi

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : ((NST == 4 || BK == 64) ? 2 
   if constexpr (WIDE) {
     __builtin_amdgcn_s_barrier();                                      // every wave's tail re-loads have landed: the ring is free
     constexpr int CH = (NST == 4 || TN < 2) ? TN : 2;                  // (shallow ring: the slabs must fit the smaller allocation)
-    uce_epi::store_rows<TM, TN, F16, GEGLU, CH>(acc, smem + w * uce_epi::wave_bytes<CH, GEGLU>(), bias, R, ldr, Y, ldy,
+    constexpr bool LEAN = !(NW == 4 || NST == 4 || BK == 64);          // (the launch bounds above: 4 waves per SIMD)
+    uce_epi::store_rows<TM, TN, F16, GEGLU, CH, LEAN>(acc, smem + w * uce_epi::wave_bytes<CH, GEGLU>(), bias, R, ldr, Y, ldy,
                                                 m0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane);
   } else if constexpr (GEGLU) {
 #pragma unroll
