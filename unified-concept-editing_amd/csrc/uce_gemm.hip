@@ -426,6 +426,9 @@ int launch_linear(const void* x, long ldx, const void* w, const void* bias, cons
   if (K <= 320 && M >= 65536 && M < 196608 && N <= 320) { nst = 2; bm = 128; bn = 320; }
   else if (K <= 320 && K % 64 == 0 && M >= 65536 && N >= 2560 && N % 256 == 0 && !(x2 && K1 % 64)) { nst = 64; bm = 256; bn = 256; }
   else if (K <= 320 && M >= 65536 && N >= 2560 && N % 256 == 0) { nst = 3; bm = 128; bn = 256; }
+  // the GEGLU projections of the 32 x 32 / 16 x 16 / 8 x 8 levels (N = 5120 / 10240): 256 x 256 tiles 3-6 % ahead of 256 x 320
+  // (CFG batch 256, profiles/r05/gemm_forms_b256.jsonl: N = 5120 1923 us against 1994; N = 10240 1639 against 1720, 404 against 412)
+  else if (K % 64 == 0 && N >= 5120 && N % 256 == 0 && M >= 4096 && !(x2 && K1 % 64)) { nst = 64; bm = 256; bn = 256; }
   else if (K % 64 == 0 && bn != 128 && !(x2 && K1 % 64)) nst = 64;         // 128-byte k-tiles, two stages: 5-10 % ahead of the 64-byte ring wherever K allows
   if (force_tile > 0) { nst = force_tile >= 1000000 ? force_tile / 1000000 : 4; bm = (force_tile / 1000) % 1000; bn = force_tile % 1000; }
   if (!wide_ok) nst = 4;
