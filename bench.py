@@ -644,7 +644,8 @@ def generation_leg(device, world, n_images, steps, edited_slab, batch=8, model_i
     # when the last file is on disk.
     from uce_amd import generate as _gen
     png_dir = tempfile.mkdtemp(prefix="uce_bench_png_") if vae else None
-    png_workers = max(1, _gen.png_worker_count(8, world))                # (after the rank was pinned to its block of cores)
+    # (after the rank was pinned to its block of cores; UCE_BENCH_PNG_WORKERS: a fixed count for an A/B)
+    png_workers = max(1, _gen.png_worker_count(int(os.environ.get("UCE_BENCH_PNG_WORKERS", _gen.PNG_WORKERS_AUTO)), world))
     writer = ThreadPoolExecutor(max_workers=png_workers) if vae else None
     pending = []
     png_cpu_s = [0.0]

@@ -513,3 +513,5 @@ def test_ranks_of_one_node_get_disjoint_core_blocks():
     assert G.rank_core_block(0, 1, allowed=range(4), node=-1) == [0, 1, 2, 3]
     assert G.pin_rank_to_cores(0, 1) == 0                                # a single rank is left alone
     assert 0 <= G.png_worker_count(8, 8) <= 8 and G.png_worker_count(0, 1) == 0
+    auto = G.png_worker_count(G.PNG_WORKERS_AUTO, 1)                     # a quarter of the cores of the rank, 1 .. 32
+    assert 1 <= auto <= 32 and auto <= max(1, len(os.sched_getaffinity(0)) - 1)

@@ -95,13 +95,21 @@ def pin_rank_to_cores(local: int, world: int) -> int:
         return 0
 
 
+PNG_WORKERS_AUTO = -1
+
+
 def png_worker_count(requested: int, world: int) -> int:
-    """PNG-encoding threads of one rank: the caller's number, capped so that `world` ranks x (workers + the rank's own thread) never
-    ask for more threads than the cores the process may run on."""
+    """PNG-encoding threads of one rank.  `requested` < 0 (the default): a quarter of the cores the process may run on (after
+    pin_rank_to_cores: the rank's own block), at most 32 - an image costs ~30 ms of one core, so eight threads keep up with the
+    GPU many times over, but the files of the LAST batch are encoded with nothing left to hide behind: 128 images on 8 threads
+    are 0.46 s, on 32 threads 0.12 s.  An explicit number is kept, capped so that the workers + the rank's own thread never ask
+    for more threads than those cores; 0 = encode inline like the reference's loop."""
     try:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
     except Exception:  # noqa: BLE001
         cores = os.cpu_count() or 8
+    if int(requested) < 0:
+        requested = max(1, min(32, cores // 4))
     return max(0, min(int(requested), max(1, cores - 1)))
 
 
@@ -172,7 +180,7 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
                     torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=100,
                     num_images_per_prompt=10, from_case=0, till_case=1000000, model_dir=None, synthetic=False,
                     latents_only=False, skip_existing=False, pipe=None, batch_prompts: int = 0,
-                    png_workers: int = 8) -> Dict[str, float]:
+                    png_workers: int = PNG_WORKERS_AUTO) -> Dict[str, float]:
     """evalscripts/generate-images-sd.py:10-46.  `batch_prompts` CSV rows are denoised as one batch (each row
     still draws its latents from its own CPU generator seeded with `evaluation_seed`, exactly the draw the
     reference makes row by row); file names and contents per image are those of the row-by-row loop.  0 (the default) picks the
