@@ -131,6 +131,38 @@ def test_linear_strided_operands(H):
     assert float(big_y[:, :N].abs().max()) == 0.0 and float(big_y[:, 2 * N:].abs().max()) == 0.0   # neighbours untouched
 
 
+@pytest.mark.parametrize("tile", ["0", "64256320", "64256256", "2128320", "256320", "9128064"])
+@pytest.mark.parametrize("M", [1000, 257, 31])
+def test_whole_row_epilogue_writes_its_rows_and_columns_and_nothing_else(tile, M):
+    """The whole-row epilogue stores through a buffer descriptor of the wave's rows clipped to M and masks columns beyond N by the
+    offset (uce_epilogue.h): the rows after M and the columns either side of the output slice keep their sentinel -
+    with bias + residual (the residual rows of the next chunk are requested ahead: rows beyond M must not fault either) and with
+    the GEGLU epilogue, on the wide, shallow-ring and few-tile forms."""
+    from uce_amd.sd import unet as U
+    Hv = _handle_with("UCE_GEMM_TILE", tile)
+    g = torch.Generator().manual_seed(M + int(tile))
+    K, N = 320, 328                                                      # N: a ragged last column tile of every form (N % 8 == 0)
+    x, w, b = _rand((M, K), g, torch.bfloat16), _rand((N, K), g, torch.bfloat16, K ** -0.5), _rand((N,), g, torch.bfloat16)
+    r = _rand((M, N), g, torch.bfloat16)                                 # exactly M rows: nothing readable behind them is promised
+    big = torch.full((M + 40, N + 64), 7.0, dtype=torch.bfloat16, device="cuda:0")
+    Ng = 640
+    wg, bg = _rand((Ng, K), g, torch.bfloat16, K ** -0.5), _rand((Ng,), g, torch.bfloat16)
+    wi, bi = U.geglu_interleave(wg, bg)
+    bigg = torch.full((M + 40, Ng // 2 + 64), 7.0, dtype=torch.bfloat16, device="cuda:0")
+    try:
+        Hv.linear(x, w, b, r, out=big[:M, 32:32 + N])
+        Hv.linear(x, wi, bi, geglu=True, out=bigg[:M, 32:32 + Ng // 2])
+        torch.cuda.synchronize()
+    finally:
+        Hv.close()
+    want = x.double() @ w.double().T + b.double() + r.double()
+    assert O.rel_fro(big[:M, 32:32 + N].double().cpu(), want.cpu()) < TOL[torch.bfloat16]
+    pg = x.double() @ wg.double().T + bg.double()
+    assert O.rel_fro(bigg[:M, 32:32 + Ng // 2].double().cpu(), (pg[:, :Ng // 2] * F.gelu(pg[:, Ng // 2:])).cpu()) < TOL[torch.bfloat16]
+    for t, n in ((big, N), (bigg, Ng // 2)):
+        assert bool((t[M:] == 7.0).all()) and bool((t[:, :32] == 7.0).all()) and bool((t[:, 32 + n:] == 7.0).all())
+
+
 def test_linear_rejects_bad_arguments(H):
     from uce_amd import lib as L
     x = torch.zeros(8, 40, dtype=torch.bfloat16, device="cuda:0")          # K = 40 is not a multiple of 32
