@@ -402,3 +402,27 @@ def test_bench_generation_leg_two_ranks_gloo(tmp_path, fail_rank):
     else:
         assert res[0]["value"] is None and res[1]["value"] is None
         assert "injected failure" in res[1]["error"] and res[0]["error"] == "another rank failed"
+
+
+def test_decoded_images_become_the_same_bytes_as_diffusers_numpy_to_pil():
+    """sd.pipeline.images_from_decoded does diffusers' post-processing where the tensor lives: `(image / 2 + 0.5).clamp(0, 1)`,
+    NHWC float32, then numpy_to_pil's `(images * 255).round().astype("uint8")` - the uint8 conversion in torch (float32 multiply,
+    round-half-to-even) must give numpy's bytes, exact halves and out-of-range values included."""
+    import numpy as np
+    import torch
+    from uce_amd.sd import pipeline as sdp
+    g = torch.Generator().manual_seed(5)
+    dec = (torch.randn((3, 3, 16, 24), generator=g) * 1.3).to(torch.bfloat16)
+    dec[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, 3.0, -3.0, 1 / 255, 3 / 255, 0.5]).to(torch.bfloat16)
+    halves = torch.tensor([(k + 0.5) / 255 * 2 - 1 for k in range(0, 48)], dtype=torch.float32)   # (x / 2 + 0.5) * 255 = k + 0.5
+    dec32 = dec.float()
+    dec32[1, 1, 2, :] = halves[:24]
+    dec32[1, 1, 3, :] = halves[24:]
+    for d in (dec, dec32):
+        want = (d.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+        want = [(im * 255).round().astype("uint8") for im in want]
+        got = sdp.images_from_decoded(d, "pil")
+        assert len(got) == 3 and all(im.size == (24, 16) for im in got)
+        assert all(np.array_equal(np.asarray(a), b) for a, b in zip(got, want))
+        arr = sdp.images_from_decoded(d, "np")
+        assert all(np.array_equal(a, (d.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()[i]) for i, a in enumerate(arr))
