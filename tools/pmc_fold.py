@@ -2,8 +2,8 @@
 kernel bench.py reports (edit kernels, k_xattn, k_sattn).
 
     python tools/pmc_fold.py edit  <workload> <dir>          # dir holds <workload>_pmc_{fetch,write,sq}_counter_collection.csv
-    python tools/pmc_fold.py xattn <dir> <B,B,...>           # passes of `bench.py --only xattn` (launch-order split)
-    python tools/pmc_fold.py sattn <dir> <B>
+    python tools/pmc_fold.py xattn <dir>                     # passes of `bench.py --only xattn`: the shapes and the launches
+    python tools/pmc_fold.py sattn <dir>                     #   per shape are read from the bench line in <mode>_pmc_<pass>.log
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE
 come from separate passes, rocprofv3 reports them in kilobytes (value * 1024 bytes), and on gfx950 FETCH_SIZE counts
@@ -26,8 +26,8 @@ EDIT_KERNELS = ["k_lr_project", "k_lr_update_s", "k_lr_update", "k_lr_fused", "k
 CHAINS = {"potrf": ["k_potrf_la", "k_potrf_first", "k_potrf_step", "k_potrf_panel", "k_potrf_diag"],
           "k_trisolve": ["k_trinv_fwd", "k_trinv_merge", "k_trinv_bwd"],
           "gram_primal": ["k_gram_primal", "k_reduce_slabs"]}     # uce_edit's primal path: A split over the concepts + its reduction
-XATTN_SHAPES = ((4096, 40), (1024, 80), (256, 160), (64, 160))
-LAUNCHES_PER_SHAPE = 5          # bench.py --only xattn / sattn: one warm launch + 4 timed
+MAIN_KERNELS = {"xattn": ("k_xattn_g", "k_xattn"), "sattn": ("k_sattn_h", "k_sattn_p", "k_sattn")}   # ONE launch of one of these per call
+AUX_KERNELS = {"xattn": (), "sattn": ("k_vt",)}                                                      # helpers a call may launch BEFORE its main kernel
 
 
 def short(name: str, wanted):
@@ -39,13 +39,13 @@ def short(name: str, wanted):
 
 
 def dispatches(path):
-    """[(dispatch id, kernel name, {counter: value})] in dispatch order."""
+    """[(dispatch id, kernel name, {counter: value}, grid size)] in dispatch order."""
     acc = {}
     for r in csv.DictReader(open(path)):
         did = int(r["Dispatch_Id"])
-        ent = acc.setdefault(did, (r["Kernel_Name"], {}))
+        ent = acc.setdefault(did, (r["Kernel_Name"], {}, r.get("Grid_Size", "")))
         ent[1][r["Counter_Name"]] = ent[1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    return [(d, n, c) for d, (n, c) in sorted(acc.items())]
+    return [(d, n, c, g) for d, (n, c, g) in sorted(acc.items())]
 
 
 def mean(v):
@@ -82,31 +82,80 @@ def fold_groups(groups_fetch, groups_write, groups_sq):
 def by_kernel(path, wanted):
     g = defaultdict(list)
     if path and os.path.exists(path):
-        for _, name, c in dispatches(path):
+        for _, name, c, _g in dispatches(path):
             k = short(name, wanted)
             if k:
                 g[k].append(c)
     return g
 
 
-ALIASES = {"k_xattn_g": "k_xattn", "k_sattn_p": "k_sattn", "k_sattn_h": "k_sattn"}       # forms of one kernel that serve the same call
 
 
-def by_order(path, kernel_names, keys):
-    """Launch-order split: the i-th group of LAUNCHES_PER_SHAPE launches of each named kernel belongs to keys[i]."""
+class FoldError(RuntimeError):
+    pass
+
+
+def bench_line(log_path):
+    """The JSON line `bench.py --only xattn|sattn` printed into the pass's log: the shapes IN LAUNCH ORDER, each with the number
+    of calls bench.time_kernel made for it (`launches` = untimed burst + timed; bench.kernel_launches is the one place that
+    number comes from)."""
+    last = None
+    with open(log_path) as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith("{") and '"shapes"' in line:
+                last = line
+    if last is None:
+        raise FoldError(f"{log_path}: no bench.py JSON line with `shapes`")
+    shapes = json.loads(last)["shapes"]
+    if any("launches" not in e for e in shapes):
+        raise FoldError(f"{log_path}: the bench line carries no `launches` per shape (bench.py older than the fold)")
+    return shapes
+
+
+def shape_key(mode, e):
+    return f"B{e['B']}_Lq{e['Lq']}_dh{e['dh']}" if mode == "xattn" else f"B{e['B']}_L{e['L']}_dh{e['dh']}"
+
+
+def by_manifest(path, mode, shapes):
+    """Attribute the dispatches of one pass to the shapes of the bench line.  A call launches exactly ONE main kernel
+    (MAIN_KERNELS[mode], whatever its template form) after its helpers (AUX_KERNELS): walking the pass in dispatch order, the
+    n-th main launch belongs to the shape whose cumulative `launches` range holds n, helpers to the main launch that follows
+    them.  Refuses (FoldError) when the pass does not hold exactly the launches the line announces, or when the main launches
+    attributed to one shape are not ONE kernel instantiation at ONE grid size - a launch-order split that drifted by one
+    call mixes shapes silently (round 5: 5 per shape assumed, 8 issued)."""
     g = defaultdict(list)
     if not (path and os.path.exists(path)):
         return g
-    seen = defaultdict(int)
-    for _, name, c in dispatches(path):
-        k = short(name, list(kernel_names) + list(ALIASES))
-        if not k:
+    main, aux = MAIN_KERNELS[mode], AUX_KERNELS[mode]
+    bounds, tot = [], 0
+    for e in shapes:
+        tot += int(e["launches"])
+        bounds.append(tot)
+    n_main, pending, sig = 0, [], {}
+    for _, name, c, grid in dispatches(path):
+        k = short(name, list(main) + list(aux))
+        if k is None:
             continue
-        k = ALIASES.get(k, k)
-        idx = seen[k] // LAUNCHES_PER_SHAPE
-        seen[k] += 1
-        if idx < len(keys):
-            g[(keys[idx], k)].append(c)
+        if k in aux:
+            pending.append((k, c))
+            continue
+        idx = next((i for i, b in enumerate(bounds) if n_main < b), None)
+        n_main += 1
+        if idx is None:
+            continue                                   # counted; the total check below reports it
+        key = shape_key(mode, shapes[idx])
+        sig.setdefault(key, set()).add((name.split("(")[0], grid))
+        g[(key, main[-1])].append(c)                   # every form of the main kernel under one name
+        for ak, ac in pending:
+            g[(key, ak)].append(ac)
+        pending = []
+    if n_main != tot:
+        raise FoldError(f"{path}: {n_main} launches of {'/'.join(main)} in the pass, the bench line announces {tot} "
+                        f"({[int(e['launches']) for e in shapes]} per shape)")
+    for key, sg in sig.items():
+        if len(sg) != 1:
+            raise FoldError(f"{path}: the launches attributed to {key} are not one kernel at one grid: {sorted(sg)}")
     return g
 
 
@@ -160,15 +209,13 @@ def main():
                   + (f"mfma_util {e['mfma_util']}" if "mfma_util" in e else ""))
     elif mode in ("xattn", "sattn"):
         d = sys.argv[2]
-        batches = [int(b) for b in sys.argv[3].split(",")]
-        if mode == "xattn":
-            keys = [f"B{B}_Lq{L}_dh{dh}" for B in batches for L, dh in XATTN_SHAPES]
-            names = ["k_xattn"]
-        else:
-            keys = [f"B{B}_L{L}_dh{dh}" for B in batches for L, dh in XATTN_SHAPES]
-            names = ["k_sattn", "k_vt"]
         pf, pw, ps = paths(d, mode)
-        ent = fold_groups(by_order(pf, names, keys), by_order(pw, names, keys), by_order(ps, names, keys))
+        names = [MAIN_KERNELS[mode][-1]] + list(AUX_KERNELS[mode])
+        groups = []
+        for p, tag in zip((pf, pw, ps), ("fetch", "write", "sq")):
+            log = os.path.join(d, f"{mode}_pmc_{tag}.log")
+            groups.append(by_manifest(p, mode, bench_line(log)) if os.path.exists(p) else defaultdict(list))
+        ent = fold_groups(*groups)
         merged = {}
         for (key, kern), e in ent.items():
             m = merged.setdefault(key, {"kernels": {}})
