@@ -193,6 +193,8 @@ def edit_path(N: int, n_e: int, d: int, rows: int, algo: int) -> str:
     dual = (algo == 2) or (algo == 0 and round_up(N, 64) < d)
     if not dual:
         return "primal"
+    if 1 <= n_e <= N <= 64 and d == 768 and rows >= 1024 and os.environ.get("UCE_EDIT_RESIDENT", "1") != "0":
+        return "dual_resident"                                            # one launch, W_old register-resident (uce_edit_resident.hip)
     if 1 <= n_e <= 128 and d in (768, 1024, 2048) and rows >= 1024:      # (UCE_SPLIT_MAX_NE: beyond, Delta + the dense apply)
         return "dual_lowrank"
     return "dual_other"
@@ -220,6 +222,15 @@ def kernel_model(name: str, path: str, N: int, n_e: int, d: int, rows: int):
                                                                            f"one pass over W per {'64' if nep <= 64 else '128'} concepts")
     if name in ("k_lr_update_s", "k_lr_update"):
         return "hbm", 8.0 * rows * d + 4.0 * rows * nep + 4.0 * n_e * d, HBM_PEAK_GBS, "GB/s", "W in + W out, T in, R once"
+    if name == "k_lr_resident":
+        # ONE launch = the whole step; W_old is read from HBM once, held in registers, written once.  Both products run on the f16
+        # matrix cores with two-term split operands (3 MFMAs per fp32-equivalent product): 3 * 4 * rows * d * 64 flop = 5.9 us of
+        # the 2.5 PF/s pipe at SD-1.4's size against 19.2 us of HBM time - the launch is priced against HBM
+        byts = 8.0 * rows * d + 4.0 * (N + 2.0 * n_e) * d
+        return "hbm", byts, HBM_PEAK_GBS, "GB/s", ("the whole step in one launch (uce_edit_resident.hip): W in once + W out once + the embeddings; W and T stay in "
+                                                   f"registers between the two products, which run as {3 * 4.0 * rows * d * nep / 1e9:.1f} GF of f16 MFMA (two-term split "
+                                                   "operands, fp32 accumulate); the Gram -> Cholesky -> solve chain rides in rider workgroups and the final "
+                                                   "stores cannot start before it ends")
     if name == "k_lr_fused":
         # ONE launch = the whole step: projection + rider chain + update.  Priced against whichever floor is higher
         byts, fl = 8.0 * rows * d + 4.0 * (N + 2.0 * n_e) * d, 4.0 * rows * d * n_e

@@ -19,7 +19,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")
-EDIT_KERNELS = ["k_lr_project", "k_lr_update_s", "k_lr_update", "k_lr_fused", "k_trisolve", "k_potrf_la", "k_potrf_first", "k_potrf_step",
+EDIT_KERNELS = ["k_lr_resident", "k_lr_project", "k_lr_update_s", "k_lr_update", "k_lr_fused", "k_trisolve", "k_potrf_la", "k_potrf_first", "k_potrf_step",
                 "k_potrf_panel", "k_potrf_diag", "k_trsm", "k_gram_primal", "k_gram_dual", "k_apply_b3", "k_split3", "k_apply_h2", "k_split_h2d", "k_split_h2", "k_apply",
                 "k_delta_factors", "k_apply_lowrank_generic", "k_reduce_slabs", "k_trinv_merge", "k_trinv_fwd", "k_trinv_bwd"]
 # bench.py's launch-chain scopes: per-step bytes = all launches of the members / launches of the FIRST member

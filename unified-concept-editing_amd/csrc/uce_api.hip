@@ -234,14 +234,15 @@ int uce_create(uce_handle_t* out, int device) {
     h->sw = UceSwitches{env_int("UCE_XATTN_VARIANT", 1), want < cap ? want : cap, env_int("UCE_POTRF_VARIANT", 1), env_int("UCE_SATTN_QT", 0),
                         env_int("UCE_POTRF_RIDER_CUS", 250), env_int("UCE_SPLIT_MAX_NE", 128), env_int("UCE_SPLIT_MAX_N", 1 << 30),
                         env_int("UCE_PROJECT_LA", 1), env_int("UCE_GEMM_TILE", 0), env_int("UCE_SATTN_VTI", 0), env_int("UCE_CONV_TILE", 0),
-                        env_int("UCE_CONV_W1", 1), env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1)};
+                        env_int("UCE_CONV_W1", 1), env_int("UCE_SK_SPLIT", 0), env_int("UCE_GN_FUSED", 1), env_int("UCE_EDIT_RESIDENT", 1)};
   }
   g_uce_conv_tapin = env_int("UCE_CONV_TAPIN", -1);
   hipError_t e = hipMalloc((void**)&h->status, sizeof(int));
   if (e != hipSuccess) { delete h; return UCE_ENOMEM; }
   (void)hipMemset(h->status, 0, sizeof(int));
-  if (hipMalloc((void**)&h->ticket, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
-  (void)hipMemset(h->ticket, 0, 4 * sizeof(unsigned));
+  if (hipMalloc((void**)&h->ticket, 8 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(h->status); delete h; return UCE_ENOMEM; }
+  (void)hipMemset(h->ticket, 0, 8 * sizeof(unsigned));
+  if (hipMalloc((void**)&h->res_ws, lr_resident_ws_bytes()) != hipSuccess) h->res_ws = nullptr;      // (without it: the two-launch form)
   if (hipMalloc((void**)&h->la_flags, LA_FLAGS * sizeof(unsigned)) == hipSuccess) (void)hipMemset(h->la_flags, 0, LA_FLAGS * sizeof(unsigned));
   else h->la_flags = nullptr;                                  // (the launch chain is used instead)
   // (k_gn_fused: 1024 workgroups x 64 groups x 2 floats, 2 counters x 1024 samples; without them the two-kernel form runs)
@@ -269,6 +270,7 @@ int uce_destroy(uce_handle_t h) {
   if (h->sk_tick) (void)hipFree(h->sk_tick);
   for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->res_ws) (void)hipFree(h->res_ws);
   if (h->la_flags) (void)hipFree(h->la_flags);
   prof_clear(h);
   delete h;
@@ -504,6 +506,12 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool riders = n_pad <= h->sw.rider_max_n;
+    if (riders && h->sw.edit_resident && h->res_ws && lr_resident_supported(d, N, N_edit, rows)) {
+      // ONE launch: W_old read once and held in registers between the projection and the update, both on the f16 matrix cores
+      // with the two-term split; the chain rides in the first workgroups as below (uce_edit_resident.hip)
+      UceProfScope ps(h, "k_lr_resident", st);
+      return launch_lr_resident(h, W_old, G, C, s, W_new, rows, N, N_edit, lamb, h->res_ws, st);
+    }
     if (riders) {
       // TWO launches: projection || (Gram -> Cholesky -> triangular solves, all in rider blocks of the same launch),
       // then the update
@@ -640,7 +648,7 @@ int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {
     // a bounded in-launch wait gave up (a hand-off of the cooperating workgroups never arrived): NOT a property of the system.
     // A late poster may have set flags after the launch's last block cleared them - re-arm every hand-off word and the status
     // word before the next launch on this handle can pass its waits early.
-    (void)hipMemsetAsync(h->ticket, 0, 4 * sizeof(unsigned), (hipStream_t)stream);
+    (void)hipMemsetAsync(h->ticket, 0, 8 * sizeof(unsigned), (hipStream_t)stream);
     if (h->la_flags) (void)hipMemsetAsync(h->la_flags, 0, LA_FLAGS * sizeof(unsigned), (hipStream_t)stream);
     (void)hipMemsetAsync(h->status, 0, sizeof(int), (hipStream_t)stream);
     (void)hipStreamSynchronize((hipStream_t)stream);

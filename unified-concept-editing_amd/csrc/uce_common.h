@@ -75,11 +75,12 @@ constexpr int UCE_NB = 64;  // block size of the f64 Cholesky / triangular solve
 //   UCE_GEMM_TILE       0: tile of uce_linear_fwd by rule | 1000 * BM + BN (256320, 256256, 128320, 128256, 256128): forced
 //   UCE_GN_FUSED        1: GroupNorm of small activations in ONE launch (grid-wide wait inside a sample) | 0: always stats + apply
 //   UCE_SK_SPLIT        0: slabs per tile of the few-tile GEMM / convolution forms by rule (uce_splitk.h) | S: forced
+//   UCE_EDIT_RESIDENT   1 (default): d = 768, N <= 64: the ONE-launch register-resident edit (uce_edit_resident.hip) | 0: projection + update launches
 //   UCE_POTRF_VARIANT   1: one persistent look-ahead launch for systems of 3..16 diagonal blocks that also forms L^-1 |
 //                       2: the same launch, factor only (L^-1 by the merge launches of uce_trinv.hip) | 0: the launch chain
 struct UceSwitches {
   int xattn_variant, rider_max_n, potrf_variant, sattn_qt, potrf_rider_cus, split_max_ne, split_max_n, project_la,
-      gemm_tile, sattn_vti, conv_tile, conv_w1, sk_split, gn_fused;
+      gemm_tile, sattn_vti, conv_tile, conv_w1, sk_split, gn_fused, edit_resident;
 };
 
 // Workspace owned by a handle.  Everything is sized by (d_cap, n_cap): the largest embedding
@@ -145,7 +146,9 @@ struct uce_ctx {
   int* status;    // device word: 0 or (1-based) index of the first non-positive pivot
   unsigned* la_flags;   // hand-off flags of the persistent Cholesky (uce_solve.hip: k_potrf_la), zero between launches
   unsigned* ticket;  // hand-off words of the rider blocks (uce_lowrank2.hip), all zero between launches: [0] arrival counter
-                     // of the Gram riders, [1] stage word of the factorising block, [2] completion counter of the solve riders
+                     // of the Gram riders, [1] stage word of the factorising block, [2] completion counter of the solve riders,
+                     // [3] main workgroups of a one-launch edit past the wait for R, [4] its D-prep riders done (8 words allocated)
+  unsigned char* res_ws;   // fragment planes + scales of the register-resident edit launch (uce_edit_resident.hip), allocated at uce_create
   float* T;       // [rows_cap, nep_cap] projection W_old D_e^T of the two-kernel low-rank apply; the dense f16 apply keeps the
                   // planes of W_old and the scales here (uce_apply_h2.hip: apply_h2_workspace)
   size_t T_elems;
@@ -265,6 +268,11 @@ int launch_lr_project(const float* W_old, const float* X, const float* Csub, flo
                       const float* s = nullptr, int N = 0, float lamb = 0.f, float* R = nullptr);
 int launch_lr_update(const float* W_old, const float* T, const float* R, float* W_new, long rows, int d,
                      int N_edit, hipStream_t st);
+// uce_edit_resident.hip: the whole step in one launch, W_old held in registers between its two products
+bool lr_resident_supported(int d, int N, int N_edit, long rows);
+size_t lr_resident_ws_bytes();
+int launch_lr_resident(uce_ctx* h, const float* W_old, const float* G, const float* C, const float* s, float* W_new, long rows,
+                       int N, int N_edit, float lamb, unsigned char* ws, hipStream_t st);
 // the projection with the persistent Cholesky of the dual system (la, own workgroups) in the first workgroups of the launch
 int launch_lr_project_la(const float* W_old, const float* X, const float* Csub, float* T, long rows, int d, int N_edit,
                          const PotrfLaJob& la, int own, hipStream_t st);

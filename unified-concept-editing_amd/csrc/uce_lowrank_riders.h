@@ -9,9 +9,14 @@
 // -DUCE_CHAIN_DEBUG: wall-clock stamps (100 MHz) of the rider chain's phases, read back with uce_debug_read
 // (tools/dbg_chain.py); compiled out of the product library.
 #ifdef UCE_CHAIN_DEBUG
+#ifndef UCE_DBG_SYM                            // (a second translation unit that hosts the riders names its own buffer + reader)
+#define UCE_DBG_SYM g_dbg
+#define UCE_DBG_READ uce_debug_read
+#endif
+#define g_dbg UCE_DBG_SYM
 __device__ unsigned long long g_dbg[64][32];   // per block: 16 wall-clock stamps (slots 0-7 Gram / factor / projection role, 8-15 solve role) + 16 shader-clock stamps
 #define DBG(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) { g_dbg[blockIdx.x][slot] = wall_clock64(); g_dbg[blockIdx.x][16 + slot] = clock64(); } } while (0)
-extern "C" int uce_debug_read(unsigned long long* out) {
+extern "C" int UCE_DBG_READ(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
 }
 #else
@@ -239,6 +244,11 @@ struct GramPotrfJob {
                         // posts stage 4 = "R complete", the projecting workgroups wait for it, count themselves out on
                         // ticket[3], and the last of the `n_proj` re-arms [1] and [3]
   int n_proj;
+  // register-resident launch (uce_edit_resident.hip): the solve riders publish R as f16 (hi, lo) MFMA fragments in the order its
+  // phase B reads them - [column tile][k-block of 32 concepts][plane][lane] x 16 bytes, lane (i = lane & 15, kg = lane >> 4) holding
+  // concepts 32 b + 16 (j >> 2) + 4 kg + (j & 3), j = 0..7, of column 16 t + i - under one power-of-two scale per column (Rsc: its inverse)
+  void* Rh;             // null: not wanted
+  float* Rsc;           // [d]
 };
 
 constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of the system (split over the feature axis)
@@ -364,6 +374,25 @@ __device__ __forceinline__ void rp_split8(const float (&x)[8], uint4_t& h, uint4
   }
 }
 
+// The two-term f16 split of uce_apply_h2.hip on register values: biased exponent E of a row / column maximum -> the scale
+// 2^(14 - (E - 127)) that takes the maximum into [2^14, 2^15), its inverse, and eight scaled values -> (hi, lo) f16 x 8
+__device__ __forceinline__ int rs_clamp_exp(unsigned abs_bits) {
+  const int E = (int)(abs_bits >> 23);
+  return E < 30 ? 30 : (E > 240 ? 240 : E);           // (an all-zero / denormal line, or inf / nan in it)
+}
+__device__ __forceinline__ float rs_scale(int E) { return __uint_as_float((unsigned)(268 - E) << 23); }
+__device__ __forceinline__ float rs_inv_scale(int E) { return __uint_as_float((unsigned)(E - 14) << 23); }
+__device__ __forceinline__ void rs_split8(const float (&y)[8], uint4_t& hi, uint4_t& lo) {
+  typedef _Float16 f16x2_t_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 h0 = (_Float16)y[2 * i], h1 = (_Float16)y[2 * i + 1];       // round to nearest even
+    const float r0 = y[2 * i] - (float)h0, r1 = y[2 * i + 1] - (float)h1;      // exact
+    hi[i] = __builtin_bit_cast(unsigned, f16x2_t_{h0, h1});
+    lo[i] = __builtin_bit_cast(unsigned, f16x2_t_{(_Float16)r0, (_Float16)r1});
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char* smem_raw, int colblk) {
   double* M0 = (double*)smem_raw;                         // L_00^-1
@@ -406,7 +435,7 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
   auto store_r = [&](const double* Vt, int kblk) {        // rows of X -> R (fp32), rows < N_edit only
     const int r = tid >> 3, c4 = (tid & 7) << 2;
     const int row = kblk * 64 + r;
-    if (row < j.N_edit) {
+    if (row < j.N_edit && !j.Rh) {
       const float4_t v = {(float)Vt[r * SV_VLD + c4], (float)Vt[r * SV_VLD + c4 + 1], (float)Vt[r * SV_VLD + c4 + 2],
                           (float)Vt[r * SV_VLD + c4 + 3]};
       if (j.fused)                                          // read by other CUs of THIS launch: write-through, past the L2
@@ -437,13 +466,49 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
       __builtin_amdgcn_raw_buffer_store_b128(pl[p], rs, (unsigned)(((((p * KGT + kblk * 8 + g) * 4 + (col & 3)) * (D / 4)) + (col >> 2)) * 16),
                                              0, 16 /* sc1 */);
   };
+  // R as (hi, lo) f16 fragments + column scales for the register-resident launch (one-block systems: rows of X = the 64 concepts).
+  // `scratch`: 32 dead LDS words.
+  auto store_rf = [&](const double* Vt, unsigned* cm) {
+    if (!j.Rh) return;
+    if (tid < 32) cm[tid] = 0u;
+    __syncthreads();
+    {
+      const int c = tid & 31, rg = tid >> 5;               // 32 columns x 16 groups of 4 rows
+      float m = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * rg + r < j.N_edit) m = fmaxf(m, fabsf((float)Vt[(4 * rg + r) * SV_VLD + c]));
+      atomicMax(&cm[c], __float_as_uint(m));
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int u = tid >> 7, b = (tid >> 6) & 1, lane = tid & 63, i = lane & 15, kg = lane >> 4;
+      const int c = 16 * u + i;
+      const float sc = rs_scale(rs_clamp_exp(cm[c]));
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = 32 * b + 16 * (e >> 2) + 4 * kg + (e & 3);
+        y[e] = row < j.N_edit ? (float)Vt[row * SV_VLD + c] * sc : 0.f;
+      }
+      uint4_t hi, lo;
+      rs_split8(y, hi, lo);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(j.Rh, 0, (D / 16) * 4 * 1024, 0x00020000);
+      const unsigned off = (unsigned)(((((2 * colblk + u) * 2 + b) * 2) * 64 + lane) * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off, 0, 16 /* sc1 */);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off + 1024, 0, 16);
+    }
+    if (tid < 32)
+      __hip_atomic_store(j.Rsc + colblk * SV_COLS + tid, rs_inv_scale(rs_clamp_exp(cm[tid])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto finish = [&]() {
     // every rider counts itself out; the last one re-arms the stage word and the counter for the next launch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       const unsigned t = __hip_atomic_fetch_add(j.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)(D / SV_COLS) - 1) {
+      // (register-resident launch: the main workgroups poll this counter themselves and re-arm every word when they are through)
+      if (t == (unsigned)(D / SV_COLS) - 1 && !j.Rh) {
         __hip_atomic_store(j.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // every rider's stores were drained before it drew its ticket: R is complete (fused: the updaters wait for this)
         __hip_atomic_store(j.ticket + 1, j.fused ? 4u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -469,6 +534,7 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
     DBG(12);
     store_r(V0, 0);
     store_rp(V0, 0);
+    store_rf(V0, (unsigned*)V1);                          // (Y is dead)
     DBG(13);
     finish();
     return;
