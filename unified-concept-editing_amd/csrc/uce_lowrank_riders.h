@@ -597,11 +597,24 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   const int tile = blockIdx.x / GP_NB, blk = blockIdx.x % GP_NB;  // tile of the system, feature slice
   const int ti = tile == 0 ? 0 : 1, tk = tile == 2 ? 1 : 0;       // lower tiles in order (0,0) (1,0) (1,1)
   const int nriders = gp_riders(j.nb);
-  double4_t acc[2][2];
+  // 16 x 16 sub-tiles of this wave: a DIAGONAL tile of the system is only read in its lower triangle (fetch_tile below), so its
+  // ten lower sub-tiles are shared 3 + 3 + 2 + 2 over the four waves of a half instead of 4 each - the f64 matrix pipe runs at 64
+  // cycles per 16 x 16 x 4 step and SIMD, the Gram is bound by it (5.6 of the chain's first 8 us), a quarter of it was spent on
+  // sub-tiles nobody reads.  An off-diagonal tile (two-block systems) keeps the 2 x 2 quadrant per wave.
+  const bool gdiag = ti == tk;
+  const int wqs = __builtin_amdgcn_readfirstlane(wq);              // (wave-uniform: the sub-tile maps below are scalar branches)
+  int ga[4], gb[4], gn;
+  if (!gdiag) {
+    gn = 4;
+    ga[0] = ga[1] = 2 * (wq >> 1); ga[2] = ga[3] = 2 * (wq >> 1) + 1;
+    gb[0] = gb[2] = 2 * (wq & 1); gb[1] = gb[3] = 2 * (wq & 1) + 1;
+  } else if (wq == 0) { gn = 3; ga[0] = 0; gb[0] = 0; ga[1] = 1; gb[1] = 0; ga[2] = 1; gb[2] = 1; ga[3] = 0; gb[3] = 0; }
+  else if (wq == 1) { gn = 3; ga[0] = 2; gb[0] = 0; ga[1] = 2; gb[1] = 1; ga[2] = 2; gb[2] = 2; ga[3] = 0; gb[3] = 0; }
+  else if (wq == 2) { gn = 2; ga[0] = 3; gb[0] = 0; ga[1] = 3; gb[1] = 1; ga[2] = ga[3] = 0; gb[2] = gb[3] = 0; }
+  else { gn = 2; ga[0] = 3; gb[0] = 2; ga[1] = 3; gb[1] = 3; ga[2] = ga[3] = 0; gb[2] = gb[3] = 0; }
+  double4_t acc[4];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < 4; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
   float* Ah = As + half * 64 * GP_LD;
   float* Bh = Bs + half * 64 * GP_LD;
   const int lrow = ht >> 3, lc4 = (ht & 7) * 4;
@@ -618,8 +631,15 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
       pre[ch][p] = *(const float4_t*)(j.C + (size_t)(ra < j.N ? ra : j.N - 1) * D + kbeg + ch * 32 + lc4);
       preb[ch][p] = *(const float4_t*)(j.C + (size_t)(rb < j.N ? rb : j.N - 1) * D + kbeg + ch * 32 + lc4);
     }
+#ifdef UCE_CHAIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DBG(6);
+#endif
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
+#ifdef UCE_CHAIN_DEBUG
+    if (ch == 1) DBG(7);
+#endif
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int r = p * 32 + lrow;
@@ -630,16 +650,55 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int kofs = u * 16 + 4 * (lane >> 4);
-      const float4_t fa0 = *(const float4_t*)&Ah[(wr + (lane & 15)) * GP_LD + kofs];
-      const float4_t fa1 = *(const float4_t*)&Ah[(wr + 16 + (lane & 15)) * GP_LD + kofs];
-      const float4_t fb0 = *(const float4_t*)&Bh[(wc + (lane & 15)) * GP_LD + kofs];
-      const float4_t fb1 = *(const float4_t*)&Bh[(wc + 16 + (lane & 15)) * GP_LD + kofs];
+      auto frag = [&](const float* P, int blk16) { return *(const float4_t*)&P[(16 * blk16 + (lane & 15)) * GP_LD + kofs]; };
+      if (!gdiag) {
+        const float4_t fa0 = frag(Ah, ga[0]), fa1 = frag(Ah, ga[2]), fb0 = frag(Bh, gb[0]), fb1 = frag(Bh, gb[1]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0][0] = mfma_f64((double)fa0[t], (double)fb0[t], acc[0][0]);
-        acc[0][1] = mfma_f64((double)fa0[t], (double)fb1[t], acc[0][1]);
-        acc[1][0] = mfma_f64((double)fa1[t], (double)fb0[t], acc[1][0]);
-        acc[1][1] = mfma_f64((double)fa1[t], (double)fb1[t], acc[1][1]);
+        for (int t = 0; t < 4; ++t) {
+          const double a0 = (double)fa0[t], a1 = (double)fa1[t], b0 = (double)fb0[t], b1 = (double)fb1[t];
+          acc[0] = mfma_f64(a0, b0, acc[0]);
+          acc[1] = mfma_f64(a0, b1, acc[1]);
+          acc[2] = mfma_f64(a1, b0, acc[2]);
+          acc[3] = mfma_f64(a1, b1, acc[3]);
+        }
+      } else {
+        // diagonal tile: both operands are rows of the SAME block (Ah == Bh row for row), so a wave converts each 16-row fragment
+        // once (v_cvt_f64_f32 shares the double-precision pipe with the MFMA) - 2 or 3 fragments for its 2 or 3 sub-tiles
+        if (wqs == 0) {
+          const float4_t x0 = frag(Ah, 0), x1 = frag(Ah, 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const double d0 = (double)x0[t], d1 = (double)x1[t];
+            acc[0] = mfma_f64(d0, d0, acc[0]);
+            acc[1] = mfma_f64(d1, d0, acc[1]);
+            acc[2] = mfma_f64(d1, d1, acc[2]);
+          }
+        } else if (wqs == 1) {
+          const float4_t x0 = frag(Ah, 0), x1 = frag(Ah, 1), x2 = frag(Ah, 2);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const double d0 = (double)x0[t], d1 = (double)x1[t], d2 = (double)x2[t];
+            acc[0] = mfma_f64(d2, d0, acc[0]);
+            acc[1] = mfma_f64(d2, d1, acc[1]);
+            acc[2] = mfma_f64(d2, d2, acc[2]);
+          }
+        } else if (wqs == 2) {
+          const float4_t x0 = frag(Ah, 0), x1 = frag(Ah, 1), x3 = frag(Ah, 3);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const double d0 = (double)x0[t], d1 = (double)x1[t], d3 = (double)x3[t];
+            acc[0] = mfma_f64(d3, d0, acc[0]);
+            acc[1] = mfma_f64(d3, d1, acc[1]);
+          }
+        } else {
+          const float4_t x2 = frag(Ah, 2), x3 = frag(Ah, 3);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const double d2 = (double)x2[t], d3 = (double)x3[t];
+            acc[0] = mfma_f64(d3, d2, acc[0]);
+            acc[1] = mfma_f64(d3, d3, acc[1]);
+          }
+        }
       }
     }
     __syncthreads();
@@ -649,24 +708,24 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   const int c = lane & 15, rq = lane >> 4;
   if (half == 1) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int i = 0; i < 4; ++i)
+      if (i < gn) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P1[(wr + m * 16 + rq + 4 * r) * GP_TLD + wc + n * 16 + c] = acc[m][n][r];
+        for (int r = 0; r < 4; ++r) P1[(16 * ga[i] + rq + 4 * r) * GP_TLD + 16 * gb[i] + c] = acc[i][r];
+      }
   }
   __syncthreads();
   double* myslab = j.slabs + (size_t)blockIdx.x * 64 * 64;
   if (half == 0) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
+    for (int i = 0; i < 4; ++i)
+      if (i < gn) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = wr + m * 16 + rq + 4 * r, col = wc + n * 16 + c;
-          st_sc1(&myslab[row * 64 + col], acc[m][n][r] + P1[row * GP_TLD + col]);
+          const int row = 16 * ga[i] + rq + 4 * r, col = 16 * gb[i] + c;
+          st_sc1(&myslab[row * 64 + col], acc[i][r] + P1[row * GP_TLD + col]);
         }
+      }
   }
   // ---- publish the slab, draw a ticket (CDNA guide, Guideline 16 / split-K reduction recipe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
