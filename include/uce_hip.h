@@ -13,7 +13,9 @@
  *   - All work is enqueued on the caller's stream (pass torch.cuda.current_stream().cuda_stream
  *     as a void*); no call synchronises the device except uce_create, uce_reserve, uce_reserve_rows, uce_destroy
  *     (allocation) and uce_status (reads one int back).
- *   - One handle per GPU per thread; calls on one handle must not overlap in time.
+ *   - One handle per GPU per thread; calls on one handle must not overlap in time - neither from two threads nor on two
+ *     streams that run concurrently: the handle's hand-off words, split-contraction slabs and GroupNorm partials exist ONCE
+ *     (launches that share them are ordered by being on one stream; a second stream needs an event edge or its own handle).
  *   - Matrices are row-major and dense unless stated.  d (the text-embedding width) must be
  *     a multiple of 64 (768 SD-1.x, 1024 SD-2.x, 2048 SDXL).
  *
@@ -134,7 +136,10 @@ int uce_edit(uce_handle_t h, const float* C, const float* G, const float* s, int
              float lamb, const float* W_old, float* W_new, long rows, int algo, uce_stream_t stream);
 
 /* Synchronises `stream` and returns the status word of the last solve on this handle:
- * *info = 0 OK, k > 0: leading minor k not positive definite (function then returns UCE_EDOM). */
+ * *info = 0 OK, k > 0: leading minor k not positive definite (function then returns UCE_EDOM); k < 0: a bounded wait between
+ * cooperating workgroups of ONE launch expired (the edit's rider chain, the persistent Cholesky, the one-launch GroupNorm of
+ * uce_groupnorm_nhwc_fwd - e.g. on a device that could not keep the launch's grid resident): UCE_ETIMEDOUT, every hand-off word
+ * of the handle is re-armed, the outputs of that launch are not valid. */
 int uce_status(uce_handle_t h, int* info, uce_stream_t stream);
 
 /* Measurement aid for bench.py (per-kernel time measured live with HIP events on the launch

@@ -426,3 +426,49 @@ def test_decoded_images_become_the_same_bytes_as_diffusers_numpy_to_pil():
         assert all(np.array_equal(np.asarray(a), b) for a, b in zip(got, want))
         arr = sdp.images_from_decoded(d, "np")
         assert all(np.array_equal(a, (d.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()[i]) for i, a in enumerate(arr))
+
+
+def test_automatic_batch_sits_on_a_fixed_ladder(monkeypatch):
+    # the batch an image is denoised in decides tile forms / contraction splits, i.e. its bf16 bits: the automatic size must not follow
+    # the free HBM byte for byte
+    pipe = object.__new__(sdp.StableDiffusionPipeline)
+    pipe.unet = type("U", (), {"cfg": type("C", (), {"sample_size": 64})()})()
+    dev = torch.device("cuda", 0)
+    per = generate.AUTO_BATCH_BYTES_PER_IMAGE
+    for free_images, want in ((300, 128), (127.9, 64), (64, 64), (47, 32), (3, 2), (0.2, 1)):
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d, f=free_images: (int(2 * f * per), int(4 * 300 * per)))
+        assert generate.auto_batch_prompts(pipe, dev, 1, 10 ** 6) == want
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d: (int(2 * 300 * per), int(4 * 300 * per)))
+    assert generate.auto_batch_prompts(pipe, dev, 10, 10 ** 6) == 8            # 128 images / 10 per row = 12 rows -> 8
+    assert generate.auto_batch_prompts(pipe, dev, 1, 5) == 5                   # never more than the rows there are
+    assert generate.auto_batch_prompts(pipe, torch.device("cpu"), 1, 99) == 1  # CPU / foreign pipelines: the reference's loop
+
+
+def test_automatic_batch_halves_on_out_of_memory_and_an_explicit_one_raises(tmp_path, monkeypatch):
+    prompts = _tiny_prompts(tmp_path, 7)
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
+    calls = []
+    real = type(pipe).__call__
+
+    def flaky(self, prompt, **kw):
+        n = 1 if isinstance(prompt, str) else len(prompt)
+        calls.append(n)
+        if n > 2:
+            raise torch.cuda.OutOfMemoryError("injected")
+        return real(self, prompt, **kw)
+
+    monkeypatch.setattr(type(pipe), "__call__", flaky)
+    kw = dict(model_id="tiny-sd-test", uce_model_path=None, prompts_path=prompts, save_path=str(tmp_path), device="cpu",
+              torch_dtype=torch.float32, num_inference_steps=2, num_images_per_prompt=1, pipe=pipe, latents_only=True)
+    monkeypatch.setattr(generate, "auto_batch_prompts", lambda *a: 8)
+    st = generate.generate_images(exp_name="auto", batch_prompts=0, **kw)
+    assert calls == [7, 4, 2, 2, 2, 1] and st["images"] == 7.0 and st["batch_prompts"] == 2.0
+    calls.clear()
+    monkeypatch.setattr(type(pipe), "__call__", real)
+    generate.generate_images(exp_name="rows", batch_prompts=1, **kw)
+    for i in range(7):                                   # the retried rows were re-seeded: same latents as the row-by-row loop
+        a, b = torch.load(tmp_path / "auto" / f"{i}.pt"), torch.load(tmp_path / "rows" / f"{i}.pt")
+        assert torch.allclose(a, b, atol=1e-5), i
+    monkeypatch.setattr(type(pipe), "__call__", flaky)
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        generate.generate_images(exp_name="explicit", batch_prompts=4, **kw)

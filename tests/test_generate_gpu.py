@@ -106,3 +106,30 @@ def test_real_coco30k_rows_at_sd14_size(tmp_path):
                      generator=torch.Generator().manual_seed(call["seed"]), output_type="latent").latents.float().cpu()
         assert got.shape == alone.shape == (2, 4, 64, 64)
         assert float((got - alone).norm() / alone.norm()) < 3e-2, case   # batched vs alone: different GEMM shapes, same draw
+
+
+def test_default_automatic_batch_on_130_rows_matches_rows_generated_alone(tmp_path):
+    """The CLI default (--batch_prompts 0): 130 rows at SD-1.4 size are denoised 128 + 2 per pipe() call (free HBM of a whole
+    MI355X -> the top of the ladder); every file of the row-by-row loop is there, and the latents of three rows - the first of the
+    full batch, one in its middle, the one that lands in the ragged tail batch - are those of the row generated ALONE within the
+    stated distance (same CPU-seeded draw, other tile forms)."""
+    from uce_amd import generate, synth
+    from uce_amd.sd import pipeline as sdp
+    csv_path = synth.write_prompts_csv(str(tmp_path / "coco_synth.csv"), 130, seed=1)
+    df = pd.read_csv(csv_path)
+    pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.bfloat16, "cuda:0", synthetic=True, vae=False)
+    kw = dict(model_id="CompVis/stable-diffusion-v1-4", uce_model_path=None, prompts_path=csv_path, save_path=str(tmp_path),
+              device="cuda:0", torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=6, num_images_per_prompt=1,
+              synthetic=True, pipe=pipe, latents_only=True)
+    stats = generate.generate_images(exp_name="auto", batch_prompts=0, **kw)
+    assert stats["images"] == 130 and stats["batch_prompts"] == 128.0
+    cases = [int(c) for c in df.case_number]
+    assert sorted(os.listdir(tmp_path / "auto")) == sorted(f"{c}.pt" for c in cases)
+    for idx in (0, 77, 129):
+        row = df.iloc[idx]
+        got = torch.load(tmp_path / "auto" / f"{int(row.case_number)}.pt").float()
+        alone = pipe(str(row.prompt), num_inference_steps=6, guidance_scale=7.5, num_images_per_prompt=1,
+                     generator=torch.Generator().manual_seed(int(row.evaluation_seed)), output_type="latent").latents.float().cpu()
+        assert got.shape == alone.shape == (1, 4, 64, 64)
+        assert torch.isfinite(got).all()
+        assert float((got - alone).norm() / alone.norm()) < 3e-2, idx

@@ -650,6 +650,7 @@ int uce_status(uce_handle_t h, int* info, uce_stream_t stream) {
     // word before the next launch on this handle can pass its waits early.
     (void)hipMemsetAsync(h->ticket, 0, 8 * sizeof(unsigned), (hipStream_t)stream);
     if (h->la_flags) (void)hipMemsetAsync(h->la_flags, 0, LA_FLAGS * sizeof(unsigned), (hipStream_t)stream);
+    if (h->gn_counters) (void)hipMemsetAsync(h->gn_counters, 0, 2 * 1024 * sizeof(unsigned), (hipStream_t)stream);   // (k_gn_fused's arrive / depart words)
     (void)hipMemsetAsync(h->status, 0, sizeof(int), (hipStream_t)stream);
     (void)hipStreamSynchronize((hipStream_t)stream);
     return UCE_ETIMEDOUT;

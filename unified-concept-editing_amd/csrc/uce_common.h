@@ -172,6 +172,7 @@ struct uce_ctx {
   // arrive / depart counters of up to 1024 samples (zero between launches); allocated at uce_create
   float* gn_partial;
   unsigned* gn_counters;
+  int gn_fused_cap;      // workgroups of k_gn_fused resident at once on this device (0: not asked yet; uce_norm.hip: gn_fused_capacity)
   float* sk_ws;
   size_t sk_bytes;
   unsigned* sk_tick;

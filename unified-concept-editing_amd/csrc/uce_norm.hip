@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 4) void k_gn_fused(const unsigned short* __res
                                                   const unsigned short* __restrict__ addend, const unsigned short* __restrict__ gamma,
                                                   const unsigned short* __restrict__ beta, float* __restrict__ partial,
                                                   unsigned* __restrict__ counters, unsigned short* __restrict__ y, int HW, int C,
-                                                  int G, int chunks, float eps, int silu, long ald) {
+                                                  int G, int chunks, float eps, int silu, long ald, int* __restrict__ status) {
   constexpr int KR = 8 / NOT;                                           // pixel rows a thread keeps
   extern __shared__ __attribute__((aligned(16))) float red[];          // [RPI][C][2]
   __shared__ float mean_s[64], rstd_s[64];
@@ -398,6 +398,10 @@ __global__ __launch_bounds__(256, 4) void k_gn_fused(const unsigned short* __res
       while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)chunks && ++polls < GNF_SPIN_MAX)
         __builtin_amdgcn_s_sleep(1);
     flag_s = polls < GNF_SPIN_MAX ? 1u : 0u;
+    // an expired wait (the sample's other workgroups were not all resident: a partitioned / shared / CU-masked device beyond what
+    // gn_fused_capacity() saw) is REPORTED: uce_status turns the negative word into UCE_ETIMEDOUT and re-arms the counters; the
+    // NaN below marks the output so that nothing downstream looks valid either
+    if (polls >= GNF_SPIN_MAX) atomicCAS(status, 0, -2);
     if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)chunks - 1) {
       __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // everybody is past the poll: re-arm
       __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,6 +497,26 @@ extern "C" int uce_groupnorm_chunks(int HW) {
 }
 
 // ws: N * uce_groupnorm_chunks(HW) * G * 2 floats, owned by the caller
+// Workgroups of k_gn_fused the device keeps resident AT ONCE (its grid-wide wait inside a sample needs the whole grid on the chip):
+// occupancy of the largest-footprint instantiation (32 KB of dynamic LDS) x compute units of THIS device as the runtime reports
+// them - a CPX-partitioned or smaller part gets its own figure instead of 256 x 4 - capped by the handle's partial-sum buffer.
+// Asked once per handle (the handle is bound to one device).
+static int gn_fused_capacity(uce_handle_t h) {
+  if (h->gn_fused_cap > 0) return h->gn_fused_cap;
+  int cap = GNF_MAX_WG;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) {
+    int per_cu = 4;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_gn_fused<false, 2>, 256, 32 * 1024) == hipSuccess && nb > 0) per_cu = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_gn_fused<false, 1>, 256, 32 * 1024) == hipSuccess && nb > 0 && nb < per_cu) per_cu = nb;
+    const long c = (long)per_cu * prop.multiProcessorCount;
+    cap = c < GNF_MAX_WG ? (int)c : GNF_MAX_WG;
+  }
+  h->gn_fused_cap = cap;
+  return cap;
+}
+
 static int groupnorm_launch(uce_handle_t h, const void* x, const void* x2, int C1, const void* addend, const void* gamma,
                             const void* beta, void* y, float* ws, int N, int HW, int C, int G, float eps, int silu, int dtype,
                             long addend_ld, uce_stream_t stream) {
@@ -513,12 +537,12 @@ static int groupnorm_launch(uce_handle_t h, const void* x, const void* x2, int C
   if (h->gn_partial && h->sw.gn_fused && smem <= 32 * 1024 && N <= GNF_MAX_N) {
     const int P = mp.RPI * (8 / mp.NO);
     const long fch = ((long)HW + P - 1) / P;
-    if (fch * N <= GNF_MAX_WG) {
+    if (fch * N <= gn_fused_capacity(h)) {
       const dim3 fgrid((unsigned)fch, N);
 #define UCE_GNF(F16V, NOV)                                                                                                          \
   hipLaunchKernelGGL((k_gn_fused<F16V, NOV>), fgrid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,       \
                      (const unsigned short*)addend, (const unsigned short*)gamma, (const unsigned short*)beta, h->gn_partial,       \
-                     h->gn_counters, (unsigned short*)y, HW, C, G, (int)fch, eps, silu, ald)
+                     h->gn_counters, (unsigned short*)y, HW, C, G, (int)fch, eps, silu, ald, h->status)
       if (dtype == UCE_DTYPE_F16) { if (mp.NO == 1) UCE_GNF(true, 1); else UCE_GNF(true, 2); }
       else { if (mp.NO == 1) UCE_GNF(false, 1); else UCE_GNF(false, 2); }
 #undef UCE_GNF

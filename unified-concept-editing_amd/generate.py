@@ -160,6 +160,10 @@ def select_rows(df, from_case: int, till_case: int, rank: int, world: int):
 # the free HBM untouched
 AUTO_BATCH_BYTES_PER_IMAGE = 3 << 29          # 1.5 GB
 AUTO_BATCH_MAX_IMAGES = 128
+# the automatic batch is rounded DOWN to this ladder: the tile form and the split of a layer's contraction depend on the rows of its
+# GEMM, so the bf16 bits of an image depend on the batch it was denoised in - a batch that followed the free HBM byte for byte would
+# make a fixed seed's file depend on the GPU's other tenants; on the ladder a given machine state maps to few, stable sizes
+AUTO_BATCH_LADDER = (1, 2, 4, 8, 16, 32, 64, 128)
 
 
 def auto_batch_prompts(pipe, dev: torch.device, num_images_per_prompt: int, n_rows: int) -> int:
@@ -173,7 +177,9 @@ def auto_batch_prompts(pipe, dev: torch.device, num_images_per_prompt: int, n_ro
     free, _ = torch.cuda.mem_get_info(dev)
     side = getattr(getattr(pipe.unet, "cfg", None), "sample_size", 64) / 64.0          # (SDXL: 128 x 128 latents, 4x the pixels)
     images = max(1, min(AUTO_BATCH_MAX_IMAGES, int(free // 2 // int(AUTO_BATCH_BYTES_PER_IMAGE * side * side))))
-    return max(1, min(n_rows, images // max(1, int(num_images_per_prompt))))
+    rows = max(1, images // max(1, int(num_images_per_prompt)))
+    rows = max(b for b in AUTO_BATCH_LADDER if b <= rows)
+    return max(1, min(n_rows, rows))
 
 
 def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name="test", device="cuda:0",
@@ -183,8 +189,10 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
                     png_workers: int = PNG_WORKERS_AUTO) -> Dict[str, float]:
     """evalscripts/generate-images-sd.py:10-46.  `batch_prompts` CSV rows are denoised as one batch (each row
     still draws its latents from its own CPU generator seeded with `evaluation_seed`, exactly the draw the
-    reference makes row by row); file names and contents per image are those of the row-by-row loop.  0 (the default) picks the
-    batch from the free HBM (`auto_batch_prompts`); 1 is the reference's loop."""
+    reference makes row by row); file names are those of the row-by-row loop, the contents of an image equal the row-alone result
+    up to the bf16 summation order of the layers (tile forms depend on the batch: tests/test_generate_gpu.py states the distance).
+    0 (the default) picks the batch from the free HBM on a fixed ladder (`auto_batch_prompts`) and halves it when a call runs out
+    of memory; 1 is the reference's loop."""
     import pandas as pd
     rank, world, local = dist_env()
     dev = torch.device(device)
@@ -217,22 +225,34 @@ def generate_images(model_id, uce_model_path, prompts_path, save_path, exp_name=
     n_img = 0
     todo = [row for _, row in mine
             if not (skip_existing and os.path.exists(f"{folder_path}/{row.case_number}_0.png"))]
-    batch_prompts = int(batch_prompts)
+    batch_prompts = batch_prompts_arg = int(batch_prompts)
     if batch_prompts <= 0:
         batch_prompts = auto_batch_prompts(pipe, dev, num_images_per_prompt, len(todo))
     # PNG encoding (host, ~30 ms per 512x512 image) runs on worker threads behind the next batch's denoising (eight by default, fewer
     # when the rank's block of cores is smaller: the tail after the LAST batch is batch x 30 ms / workers)
     writer = ThreadPoolExecutor(max_workers=png_workers) if (png_workers > 0 and not latents_only) else None
     pending = []
-    for lo in range(0, len(todo), batch_prompts):
+    auto_sized = batch_prompts_arg <= 0
+    lo = 0
+    while lo < len(todo):
         rows = todo[lo:lo + batch_prompts]
         prompts = [str(r.prompt) for r in rows]
-        gens = [torch.Generator().manual_seed(int(r.evaluation_seed)) for r in rows]   # generate-images-sd.py:36
         single = len(rows) == 1
-        out = pipe(prompt=prompts[0] if single else prompts, num_inference_steps=num_inference_steps,
-                   guidance_scale=guidance_scale, num_images_per_prompt=num_images_per_prompt,
-                   generator=gens[0] if single else gens,
-                   **({"output_type": "latent"} if latents_only else {}))
+        try:
+            gens = [torch.Generator().manual_seed(int(r.evaluation_seed)) for r in rows]   # generate-images-sd.py:36
+            out = pipe(prompt=prompts[0] if single else prompts, num_inference_steps=num_inference_steps,
+                       guidance_scale=guidance_scale, num_images_per_prompt=num_images_per_prompt,
+                       generator=gens[0] if single else gens,
+                       **({"output_type": "latent"} if latents_only else {}))
+        except torch.cuda.OutOfMemoryError:
+            # the 1.5 GB per image of the automatic size is an estimate (another tenant, a foreign resolution): halve and retry
+            # the same rows - their generators are re-seeded above, nothing of the failed call is kept
+            if not auto_sized or batch_prompts <= 1:
+                raise
+            batch_prompts = max(1, batch_prompts // 2)
+            torch.cuda.empty_cache()
+            continue
+        lo += len(rows)
         for i, r in enumerate(rows):
             sl = slice(i * num_images_per_prompt, (i + 1) * num_images_per_prompt)
             if latents_only:

@@ -211,6 +211,26 @@ class VaeDecoder(nn.Module):
 
 # ------------------------------------------------------------------------------------ pipeline
 
+def _check_latent_size(pipe, hh: int, ww: int) -> None:
+    """On a GPU in a 16-bit dtype every layer runs on the library's own kernels and a layer they cannot take raises - up front
+    and by name here, not in the middle of a denoising loop: the U-Net halves the map three times (stride-2 convolutions, 2x
+    upsamples back), so the latent height / width must be multiples of 8 (pixel sizes multiples of 64)."""
+    if torch.device(pipe.device).type == "cuda" and getattr(pipe, "dtype", torch.float32) in (torch.bfloat16, torch.float16):
+        if hh <= 0 or ww <= 0 or hh % 8 or ww % 8:
+            raise ValueError(f"height x width = {hh * 8} x {ww * 8}: the 16-bit GPU path needs multiples of 64 pixels "
+                             "(the U-Net halves the latent map three times); use a multiple of 64 or run the pipeline in fp32")
+
+
+def _raise_on_expired_wait(device) -> None:
+    """A kernel of the step that waits on other workgroups of its own launch (the one-launch GroupNorm) reports an expired wait
+    through the handle's status word instead of hanging; its output is NaN then.  One 4-byte read per pipe() call - the call
+    synchronises anyway to hand images / latents to the host - turns that into an exception instead of black PNGs."""
+    if torch.device(device).type != "cuda":
+        return
+    from ..edit import UceHandle
+    UceHandle.get(device).status()
+
+
 def images_from_decoded(decoded: torch.Tensor, output_type: str) -> list:
     """diffusers' post-processing of the VAE output (`(image / 2 + 0.5).clamp(0, 1)`, NHWC float32; `numpy_to_pil`:
     `(images * 255).round().astype("uint8")`) - the arithmetic of the "pil" branch runs where the tensor is: the same float32
@@ -240,7 +260,8 @@ class _GraphedStep:
 
     def __init__(self, pipe, n: int, hh: int, ww: int, cfg: bool, guidance_scale: float, ctx: torch.Tensor,
                  raw: bool = False):
-        from .unet import Attention
+        from .unet import Attention, linear
+        self._linear = linear
         unet, dev = pipe.unet, pipe.device
         self.unet = unet
         self.raw = raw
@@ -248,7 +269,8 @@ class _GraphedStep:
         self.t = torch.zeros((1,), device=dev, dtype=torch.long)
         self.ctx = ctx.clone()
         self.cross = [m for m in unet.modules() if isinstance(m, Attention) and m.is_cross]
-        self.kv = [(m.to_k(self.ctx), m.to_v(self.ctx)) for m in self.cross]
+        # (the hoisted K / V through the SAME entry point as the eager path's cache_context - uce_linear_fwd, no library GEMM)
+        self.kv = [(linear(m.to_k, self.ctx), linear(m.to_v, self.ctx)) for m in self.cross]
         self._bind()
 
         def body():
@@ -279,8 +301,8 @@ class _GraphedStep:
     def set_context(self, ctx: torch.Tensor) -> None:
         self.ctx.copy_(ctx)
         for m, (k, v) in zip(self.cross, self.kv):
-            k.copy_(m.to_k(self.ctx))                      # the same GEMM call as the eager path: bitwise equal
-            v.copy_(m.to_v(self.ctx))
+            k.copy_(self._linear(m.to_k, self.ctx))        # the same call as UNet.cache_context: graphed and eager runs give the same bits
+            v.copy_(self._linear(m.to_v, self.ctx))
         self._bind()
 
     def __call__(self, latents: torch.Tensor, t: int) -> torch.Tensor:
@@ -379,6 +401,7 @@ class StableDiffusionPipeline:
         ctx = torch.cat([ne, pe]) if cfg else pe
         s = self.unet.cfg.sample_size
         hh, ww = (height // 8 if height else s), (width // 8 if width else s)
+        _check_latent_size(self, hh, ww)
         if latents is None:
             latents = self._draw_latents(n_prompts, n, hh, ww, generator)
         else:                                              # diffusers' `latents=`: pre-drawn initial noise
@@ -431,6 +454,7 @@ class StableDiffusionPipeline:
         images: list = []
         if output_type != "latent" and self.vae is not None:
             images = images_from_decoded(self.vae.decode(latents), output_type)
+        _raise_on_expired_wait(self.device)
         return PipeOutput(images=images, latents=latents)
 
 
@@ -496,6 +520,7 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         s = self.unet.cfg.sample_size
         height, width = height or s * 8, width or s * 8
         hh, ww = height // 8, width // 8
+        _check_latent_size(self, hh, ww)
         if latents is None:
             latents = self._draw_latents(n_prompts, n, hh, ww, generator)
         else:
@@ -525,6 +550,7 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         images: list = []
         if output_type != "latent" and self.vae is not None:
             images = images_from_decoded(self.vae.decode(latents), output_type)
+        _raise_on_expired_wait(self.device)
         return PipeOutput(images=images, latents=latents)
 
 
