@@ -288,6 +288,9 @@ int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o,
                  float scale, int dtype, hipStream_t st, int qt_variant = 0, long ld = 0, int vti = 0, float lazy = 8.f);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
                  int dh, float scale, int dtype, hipStream_t st, int variant = 1);
+// all keys resident (Lk <= 128), row stride ld of q / k / v: the short self-attention layers
+int launch_xattn_short_self(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh, float scale,
+                            int dtype, hipStream_t st, long ld);
 
 static __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);

@@ -1092,11 +1092,14 @@ bool sattn_inline_vt(int Lk, int vti, bool use_h) { return vti == 1 || vti == 3 
 // the running maximum of the online softmax is raised only when a key tile's maximum exceeds it by more than 2^8 (P <= 256 keeps the
 // relative precision of bf16 / f16; sums are f32): measured 4, 8, 16 -> 4 882 / 4 843 / 4 860 us at L = 4096, B = 128 (round 4)
 constexpr float SATTN_LAZY = 8.f;
+constexpr int SATTN_SHORT_KEYS = 128;
 
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
                  float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, float lazy) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   if (ld <= 0) ld = (long)H * dh;
+  // at most 128 keys: every key resident, plain softmax - k_xattn's form (uce_xattn.hip); UCE_SATTN_QT != 0 keeps the streaming kernels
+  if (qt_variant == 0 && Lk <= SATTN_SHORT_KEYS) return launch_xattn_short_self(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
   if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy, vti);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
                                                const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ V,
                                                unsigned short* __restrict__ O, int H, int Lq, int Lk,
-                                               int dh, float scale_log2e, int iters) {
+                                               int dh, float scale_log2e, int iters, long ld) {
+  // ld: row stride (elements) of Q, K and V - H * dh for separate tensors, 3 * H * dh for the packed q | k | v projection of a
+  // SHORT self-attention (uce_sattn_*_fwd with at most 128 keys: all keys resident, plain softmax - this kernel); O rows: H * dh
   constexpr int NDV = (DHP + 31) / 32;      // output column tiles
   constexpr int DVP = NDV * 32;
   constexpr int LKP = KT * 32;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
   auto load_q = [&](long t, uint4_t (&f)[NS]) {
     long row = t * 128 + w * 32 + lq;
     if (row > Lq - 1) row = Lq - 1;
-    const unsigned short* qrow = Q + ((size_t)b * Lq + row) * C + (size_t)h * dh;
+    const unsigned short* qrow = Q + ((size_t)b * Lq + row) * ld + (size_t)h * dh;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int dim = 16 * s + 8 * lh;
@@ -89,20 +91,20 @@ __global__ __launch_bounds__(256) void k_xattn(const unsigned short* __restrict_
 
   // ---- stage K_h (zero padded) and V_h^T
   {
-    const unsigned short* kbase = K + (size_t)b * Lk * C + (size_t)h * dh;
-    const unsigned short* vbase = V + (size_t)b * Lk * C + (size_t)h * dh;
+    const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
+    const unsigned short* vbase = V + (size_t)b * Lk * ld + (size_t)h * dh;
     constexpr int KCH = DHP / 8;  // 16-byte chunks per key row
     for (int e = tid; e < LKP * KCH; e += 256) {
       const int key = e / KCH, dim = (e - key * KCH) * 8;
       uint4_t val = {0u, 0u, 0u, 0u};
-      if (key < Lk && dim < dh) val = *(const uint4_t*)(kbase + (size_t)key * C + dim);
+      if (key < Lk && dim < dh) val = *(const uint4_t*)(kbase + (size_t)key * ld + dim);
       *(uint4_t*)(Ks + key * KLD + dim) = val;
     }
     constexpr int VCH = DVP / 8;
     for (int e = tid; e < LKP * VCH; e += 256) {
       const int key = e / VCH, dv = (e - key * VCH) * 8;
       uint4_t val = {0u, 0u, 0u, 0u};
-      if (key < Lk && dv < dh) val = *(const uint4_t*)(vbase + (size_t)key * C + dv);
+      if (key < Lk && dv < dh) val = *(const uint4_t*)(vbase + (size_t)key * ld + dv);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         Vt[(dv + 2 * t) * VLD + key] = (unsigned short)(val[t] & 0xffffu);
@@ -542,7 +544,7 @@ int launch_group(const void* q, const void* k, const void* v, void* o, int B, in
 
 template <int DHP, int KT>
 int launch_cfg(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
-               float scale, int dtype, hipStream_t st) {
+               float scale, int dtype, hipStream_t st, long ld) {
   // query tiles per workgroup: amortise the K/V staging once there are more than ~4 workgroups per CU
   const long tiles_q = (Lq + 127) / 128;
   const long total = tiles_q * H * B;
@@ -554,24 +556,24 @@ int launch_cfg(const void* q, const void* k, const void* v, void* o, int B, int 
   if (dtype == UCE_DTYPE_F16)
     hipLaunchKernelGGL((k_xattn<DHP, KT, true>), grid, dim3(256), 0, st, (const unsigned short*)q,
                        (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, H, Lq, Lk, dh, sl2,
-                       iters);
+                       iters, ld);
   else
     hipLaunchKernelGGL((k_xattn<DHP, KT, false>), grid, dim3(256), 0, st, (const unsigned short*)q,
                        (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, H, Lq, Lk, dh, sl2,
-                       iters);
+                       iters, ld);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
 
 template <int KT>
 int launch_dh(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh,
-              float scale, int dtype, hipStream_t st) {
-  if (dh <= 48) return launch_cfg<48, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
-  if (dh <= 64) return launch_cfg<64, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
-  if (dh <= 80) return launch_cfg<80, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
-  if (dh <= 96) return launch_cfg<96, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
-  if (dh <= 128) return launch_cfg<128, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
-  return launch_cfg<160, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
+              float scale, int dtype, hipStream_t st, long ld) {
+  if (dh <= 48) return launch_cfg<48, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  if (dh <= 64) return launch_cfg<64, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  if (dh <= 80) return launch_cfg<80, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  if (dh <= 96) return launch_cfg<96, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  if (dh <= 128) return launch_cfg<128, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  return launch_cfg<160, KT>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
 }
 
 }  // namespace
@@ -594,8 +596,19 @@ int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, in
     if (big && dh == 80) return launch_group<80, 8>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);
     if (big && dh == 160) return launch_group<160, 4>(q, k, v, o, B, H, Lq, Lk, scale, dtype, st);
   }
-  if (Lk <= 96) return launch_dh<3>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
-  return launch_dh<4>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st);
+  const long ld = (long)H * dh;
+  if (Lk <= 96) return launch_dh<3>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  return launch_dh<4>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+}
+
+// A SHORT self-attention (at most 128 keys: SD-1.4's 8 x 8 level, L = 64) is k_xattn's case - every key resident in LDS, a plain
+// softmax, no running maximum - not the streaming kernel's (uce_sattn.hip: one 64-key tile, half of its 128-row workgroup idle:
+// 45.7 us at B = 128 against 32.5 for torch's SDPA; through here the driver line of round 6 says).  ld: row stride of q, k, v.
+int launch_xattn_short_self(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int dh, float scale,
+                            int dtype, hipStream_t st, long ld) {
+  if (Lk <= 64) return launch_dh<2>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  if (Lk <= 96) return launch_dh<3>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
+  return launch_dh<4>(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
 }
 
 extern "C" int uce_xattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, void* o, int B,
