@@ -193,7 +193,7 @@ def edit_path(N: int, n_e: int, d: int, rows: int, algo: int) -> str:
     dual = (algo == 2) or (algo == 0 and round_up(N, 64) < d)
     if not dual:
         return "primal"
-    if 1 <= n_e <= N <= 64 and d == 768 and rows >= 1024 and os.environ.get("UCE_EDIT_RESIDENT", "1") != "0":
+    if 1 <= n_e <= N <= 128 and d == 768 and rows >= 1024 and os.environ.get("UCE_EDIT_RESIDENT", "1") != "0":
         return "dual_resident"                                            # one launch, W_old register-resident (uce_edit_resident.hip)
     if 1 <= n_e <= 128 and d in (768, 1024, 2048) and rows >= 1024:      # (UCE_SPLIT_MAX_NE: beyond, Delta + the dense apply)
         return "dual_lowrank"

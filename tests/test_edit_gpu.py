@@ -541,7 +541,8 @@ def test_general_solve_is_the_library_s_own_lu_and_matches_numpy(H, n, m):
 
 
 @pytest.mark.parametrize("env,value,N_e,N_p", [("UCE_PROJECT_LA", "0", 100, 80), ("UCE_SPLIT_MAX_NE", "256", 200, 60),
-                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600)])
+                                               ("UCE_POTRF_RIDER_CUS", "0", 300, 600), ("UCE_EDIT_RESIDENT", "0", 50, 0),
+                                               ("UCE_EDIT_RESIDENT", "0", 70, 30)])
 def test_edit_forms_behind_the_switches(env, value, N_e, N_p):
     """The forms uce_edit no longer takes by default stay correct behind their switches: the dual system's Cholesky in a
     launch of its own in front of the projection, the two-pass project + update form for 129 ... 256 edit concepts, the
@@ -559,6 +560,32 @@ def test_edit_forms_behind_the_switches(env, value, N_e, N_p):
         Hv.close()
     want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
     assert O.rel_fro(out, want) < EPS_BUILD
+
+
+def test_resident_edit_on_changing_inputs_matches_fp64_and_the_two_launch_form():
+    """The one-launch register-resident edit (d = 768, N <= 128) publishes its D / R operands as MFMA fragments in handle-owned
+    buffers that every launch rewrites and other workgroups of the SAME launch read back: consecutive edits with DIFFERENT concepts,
+    targets, weights, row counts and system sizes on one handle (a stale fragment, scale or hand-off word of the previous launch
+    would surface here, not in a loop over one input), each against fp64 and against the projection + update launch pair."""
+    d = 768
+    H1 = _handle_with("UCE_EDIT_RESIDENT", "1")
+    H0 = _handle_with("UCE_EDIT_RESIDENT", "0")
+    try:
+        for i, (N_e, N_p, rows_) in enumerate([(50, 0, 24960), (2, 3, 1056), (64, 0, 3000), (100, 0, 24960), (7, 40, 1025),
+                                               (50, 0, 24960), (90, 38, 5000), (1, 0, 1024)]):
+            C, G, s = _synthetic(N_e + N_p, N_e, d, seed=100 + i)
+            W = O.linear_default_weight(rows_, d, np.random.Generator(np.random.PCG64(200 + i)))
+            _, _, DTe = _exact(C, G, s, 0.5)
+            want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
+            a = H1.edit(_dev(C), _dev(G), _dev(s), 0.5, _dev(W), check=True)
+            a2 = H1.edit(_dev(C), _dev(G), _dev(s), 0.5, _dev(W), check=True)
+            b = H0.edit(_dev(C), _dev(G), _dev(s), 0.5, _dev(W), check=True)
+            assert torch.equal(a, a2), (i, "not bit-repeatable")
+            assert O.rel_fro(a.cpu(), want) < EPS_BUILD, i
+            assert O.rel_fro(a.cpu(), b.cpu().double()) < 2e-6, i
+    finally:
+        H1.close()
+        H0.close()
 
 
 @pytest.mark.parametrize("N_e,N_p,d,rows_", [(400, 300, 768, 3000), (300, 20, 768, 700), (500, 100, 1024, 1500)])

@@ -37,12 +37,11 @@ typedef __attribute__((address_space(3))) void rs_lds_void;
 constexpr int RS_D = 768;
 constexpr int RS_NT = RS_D / 16;          // 48 column tiles of a wave's W tile
 constexpr int RS_NKB = RS_D / 32;         // 24 k-blocks of phase A
-constexpr int RS_NCT = 4;                 // concept tiles (64 concepts)
+// NCT = concept tiles of 16 (template parameter of everything below): 4 -> N <= 64 (one 64-block system), 8 -> N <= 128 (two blocks)
 constexpr int RS_CW = 7;                  // compute waves of a main workgroup (16 rows each); wave 7 is the LDS-DMA producer
 constexpr int RS_ROWS = 16 * RS_CW;       // rows per main workgroup
-constexpr int RS_ND = RS_NCT;             // D-prep riders: one per concept tile
-constexpr int RS_STAGE = 16 * 1024;       // LDS ring stage: 2 k-blocks of D fragments / 4 column tiles of R fragments
-constexpr int RS_NSTAGE = 12;
+constexpr int RS_STAGE = 16 * 1024;       // LDS ring stage: 8 / NCT k-blocks of D fragments, 16 / NCT column tiles of R fragments
+__host__ __device__ constexpr int rs_nstage(int nct) { return 3 * nct; }       // stages per operand (12 / 24)
 // Cache policy of the fragment loads.  The producers publish write-through (sc1) and post their flag after the stores drained; a
 // consumer's FIRST read of a line in this launch happens after that flag, and neither its L1 nor its XCD's L2 can hold the line
 // from before (both are invalidated at the launch boundary, nothing in this launch reads the buffers earlier) - so a plain load is
@@ -75,9 +74,9 @@ struct ResidentJob {
   const float* G;          // [N_edit, d] targets
   const float* Ce;         // [N_edit, d] = the first rows of C
   int Ne;
-  uint4_t* Dh;             // D fragments  [k-block 24][concept tile 4][plane 2][lane 64] x 16 B
-  float* Dsc;              // [64]  2^-e of the concept rows of D_e
-  uint4_t* Rh;             // R fragments  [column tile 48][k-block 2][plane 2][lane 64] x 16 B   (written by the solve riders)
+  uint4_t* Dh;             // D fragments  [k-block 24][concept tile NCT][plane 2][lane 64] x 16 B
+  float* Dsc;              // [16 NCT]  2^-e of the concept rows of D_e
+  uint4_t* Rh;             // R fragments  [column tile 48][k-block NCT / 2][plane 2][lane 64] x 16 B   (written by the solve riders)
   float* Rsc;              // [768] 2^-e of the columns of R
   int n_main;
 };
@@ -85,6 +84,7 @@ struct ResidentJob {
 // ---------------------------------------------------------------------------------------------------------------------------
 // D-prep rider ct: concepts 16 ct .. 16 ct + 15 of D_e = G - C_e -> scale per concept, (hi, lo) fragments in phase A's order
 // ---------------------------------------------------------------------------------------------------------------------------
+template <int NCT>
 __device__ __forceinline__ void rs_dprep(const ResidentJob& rj, unsigned* ticket, unsigned char* smem_raw, int ct) {
   unsigned* mx = (unsigned*)smem_raw;                       // [16] row maxima (fp32 bit patterns of |x|)
   const int tid = threadIdx.x;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void rs_dprep(const ResidentJob& rj, unsigned* ticket
   __syncthreads();
   const int E = rs_clamp_exp(mx[i]);
   const float s = rs_scale(E);
-  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)rj.Dh, 0, RS_NKB * RS_NCT * 2 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)rj.Dh, 0, RS_NKB * NCT * 2 * 1024, 0x00020000);
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
     const int item = tid + 512 * p, b = item >> 6, lane = item & 63;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void rs_dprep(const ResidentJob& rj, unsigned* ticket
     for (int e = 0; e < 8; ++e) y[e] = x[p][e] * s;
     uint4_t hi, lo;
     rs_split8(y, hi, lo);
-    const unsigned off = (unsigned)((((b * RS_NCT + ct) * 2) * 64 + lane) * 16);
+    const unsigned off = (unsigned)((((b * NCT + ct) * 2) * 64 + lane) * 16);
     __builtin_amdgcn_raw_buffer_store_b128(hi, dr, off, 0, 16 /* sc1: write-through */);
     __builtin_amdgcn_raw_buffer_store_b128(lo, dr, off + 1024, 0, 16);
   }
@@ -160,8 +160,12 @@ __device__ __forceinline__ void rs_wait_word(const unsigned* word, unsigned want
 // ---------------------------------------------------------------------------------------------------------------------------
 // main workgroup
 // ---------------------------------------------------------------------------------------------------------------------------
+template <int NCT>
 __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* __restrict__ W_new, long rows, const ResidentJob& rj,
                                         const GramPotrfJob& job, unsigned char* smem, int wg) {
+  constexpr int NSTG = rs_nstage(NCT);      // ring stages per operand
+  constexpr int KPS = 8 / NCT;              // k-blocks of D per stage (a k-block = NCT x 2 fragments of 1 KB) = column-tile groups of R
+  constexpr int NKC = NCT / 2;              // k-blocks of 32 concepts in phase B
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, kg = lane >> 4;
   // ---- LDS ring: stage s of `src` = 16 contiguous 1 KB fragments -> ring buffer s % 3 by LDS-DMA.  Wave 7 is the producer: it
@@ -169,7 +173,7 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
   // waits on them; the 7 computing waves meet it at one barrier per stage.  Two stages are in flight while one is read.
   if (w == RS_CW) {
     auto dma_stage = [&](const uint4_t* src, int s) {
-      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, RS_NSTAGE * RS_STAGE, 0x00020000);
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, NSTG * RS_STAGE, 0x00020000);
 #pragma unroll
       for (int c = 0; c < 16; ++c)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (rs_lds_void*)(smem + (s % RS_RING) * RS_STAGE + c * 1024), 16,
@@ -182,8 +186,8 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // stage 0 landed (the 16 pieces of stage 1 may be outstanding)
       __syncthreads();
 #pragma unroll
-      for (int s = 0; s + last_wait < RS_NSTAGE; ++s) {
-        if (s + 2 < RS_NSTAGE) {
+      for (int s = 0; s + last_wait < NSTG; ++s) {
+        if (s + 2 < NSTG) {
           dma_stage(src, s + 2);
           asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage s + 1 landed
         } else {
@@ -206,6 +210,8 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
 
   DBG(0);
   // ---- W tile: 48 loads of 16 B per lane, all in flight - tiles 0..35 into registers, 36..47 straight into this wave's LDS slots
+  // (the tile displacement rides in the SCALAR offset, which the hardware range check ignores: `vo` alone says whether the lane's
+  //  row exists - and the compiler cannot turn 48 displaced offsets into 48 live registers)
   float4_t wv[RS_NREG];
 #pragma unroll
   for (int t = 0; t < RS_NREG; ++t)
@@ -233,33 +239,26 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
   DBG(1);
   const int EW = rs_clamp_exp(__float_as_uint(mxf));
   const float sW = rs_scale(EW), iW = rs_inv_scale(EW);
-
   float* Rsc = (float*)(smem + RS_LDS_RSC);
   float* Dsc = (float*)(smem + RS_LDS_DSC);
 
   // ---- phase A: T^T = D_e W^T
-  rs_wait_word(job.ticket + 4, RS_ND, job.status);
+  rs_wait_word(job.ticket + 4, (unsigned)NCT, job.status);
   DBG(2);
-  if (tid < 16) {
-    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)rj.Dsc, 0, 64 * 4, 0x00020000);
+  if (tid < 4 * NCT) {
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)rj.Dsc, 0, 16 * NCT * 4, 0x00020000);
     *(uint4_t*)(Dsc + 4 * tid) = __builtin_amdgcn_raw_buffer_load_b128(sr, (unsigned)(16 * tid), 0, 16);
   }
   __syncthreads();                                            // stage 0 of the D fragments has landed
-  float4_t tacc[RS_NCT];
+  float4_t tacc[NCT];
 #pragma unroll
-  for (int c = 0; c < RS_NCT; ++c) tacc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NCT; ++c) tacc[c] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < RS_NSTAGE; ++s) {
+  for (int s = 0; s < NSTG; ++s) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int b = 2 * s + q;
-      const unsigned char* fb = smem + (s % RS_RING) * RS_STAGE + q * 8192 + lane * 16;
-      uint4_t dh[RS_NCT], dl[RS_NCT];
-#pragma unroll
-      for (int c = 0; c < RS_NCT; ++c) {
-        dh[c] = *(const uint4_t*)(fb + (2 * c) * 1024);
-        dl[c] = *(const uint4_t*)(fb + (2 * c + 1) * 1024);
-      }
+    for (int q = 0; q < KPS; ++q) {
+      const int b = KPS * s + q;
+      const unsigned char* fb = smem + (s % RS_RING) * RS_STAGE + q * (NCT * 2048) + lane * 16;
       const float4_t w0 = 2 * b < RS_NREG ? wv[2 * b < RS_NREG ? 2 * b : 0] : wt(2 * b);
       const float4_t w1 = 2 * b + 1 < RS_NREG ? wv[2 * b + 1 < RS_NREG ? 2 * b + 1 : 0] : wt(2 * b + 1);
       float y[8];
@@ -271,40 +270,48 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
       uint4_t wh, wl;
       rs_split8(y, wh, wl);
 #pragma unroll
-      for (int c = 0; c < RS_NCT; ++c) tacc[c] = rs_mfma(dl[c], wh, tacc[c]);
+      for (int c0 = 0; c0 < NCT; c0 += 4) {                 // four concept tiles at a time: four independent accumulator chains
+        uint4_t dh[4], dl[4];
 #pragma unroll
-      for (int c = 0; c < RS_NCT; ++c) tacc[c] = rs_mfma(dh[c], wl, tacc[c]);
+        for (int c = 0; c < 4; ++c) {
+          dh[c] = *(const uint4_t*)(fb + (2 * (c0 + c)) * 1024);
+          dl[c] = *(const uint4_t*)(fb + (2 * (c0 + c) + 1) * 1024);
+        }
 #pragma unroll
-      for (int c = 0; c < RS_NCT; ++c) tacc[c] = rs_mfma(dh[c], wh, tacc[c]);
+        for (int c = 0; c < 4; ++c) tacc[c0 + c] = rs_mfma(dl[c], wh, tacc[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tacc[c0 + c] = rs_mfma(dh[c], wl, tacc[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tacc[c0 + c] = rs_mfma(dh[c], wh, tacc[c0 + c]);
+      }
     }
     __syncthreads();                                          // stage s + 1 landed (producer wave), stage s's buffer is free
   }
 
   DBG(3);
   // ---- T (lane: row n, concepts 16 ct + 4 kg + r): undo the operand scales, row maximum, scale, split -> B fragments of phase B
-  float tv[RS_NCT][4];
   float tmx = 0.f;
 #pragma unroll
-  for (int c = 0; c < RS_NCT; ++c) {
+  for (int c = 0; c < NCT; ++c) {
     const float4_t ds = *(const float4_t*)(Dsc + 16 * c + 4 * kg);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      tv[c][r] = tacc[c][r] * iW * ds[r];
-      tmx = fmaxf(tmx, fabsf(tv[c][r]));
+      tacc[c][r] = tacc[c][r] * iW * ds[r];
+      tmx = fmaxf(tmx, fabsf(tacc[c][r]));
     }
   }
   tmx = fmaxf(tmx, __shfl_xor(tmx, 16));
   tmx = fmaxf(tmx, __shfl_xor(tmx, 32));
   const int ET = rs_clamp_exp(__float_as_uint(tmx));
   const float sT = rs_scale(ET), iT = rs_inv_scale(ET);
-  uint4_t th[2], tl[2];
+  uint4_t th[NKC], tl[NKC];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < NKC; ++b) {
     float y[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      y[e] = tv[2 * b][e] * sT;
-      y[4 + e] = tv[2 * b + 1][e] * sT;
+      y[e] = tacc[2 * b][e] * sT;
+      y[4 + e] = tacc[2 * b + 1][e] * sT;
     }
     rs_split8(y, th[b], tl[b]);
   }
@@ -319,55 +326,61 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
   }
   __syncthreads();                                            // stage 0 of the R fragments (and the scales) are in LDS
 
-  // ---- phase B: W_new^T tile t = W^T tile t + R^T T^T, two column tiles in flight
+  // ---- phase B: W_new^T tile t = W^T tile t + R^T T^T.  A group = 8 / NCT column tiles = four independent accumulator chains (tile x
+  // k-block of 32 concepts) of three MFMAs each (a dependent MFMA two issues behind its producer stalls on the accumulator)
 #pragma unroll
-  for (int s = 0; s < RS_NSTAGE; ++s) {
+  for (int s = 0; s < NSTG; ++s) {
+#ifdef UCE_CHAIN_DEBUG
     if (s < 8) DBG(8 + s);
+#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const unsigned char* fb = smem + (s % RS_RING) * RS_STAGE + q * 8192 + lane * 16;
-      uint4_t rh[2][2], rl[2][2];                       // [tile of the pair][k-block]
+      uint4_t rh[KPS][NKC], rl[KPS][NKC];                     // [tile of the group][k-block]
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < KPS; ++u)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          rh[u][b] = *(const uint4_t*)(fb + ((u * 2 + b) * 2) * 1024);
-          rl[u][b] = *(const uint4_t*)(fb + ((u * 2 + b) * 2 + 1) * 1024);
+        for (int b = 0; b < NKC; ++b) {
+          rh[u][b] = *(const uint4_t*)(fb + ((u * NKC + b) * 2) * 1024);
+          rl[u][b] = *(const uint4_t*)(fb + ((u * NKC + b) * 2 + 1) * 1024);
         }
-      // four independent accumulator chains (tile u x k-block b) of three MFMAs each: a dependent MFMA two issues behind its
-      // producer stalls on the accumulator (1 520 cycles per stage measured against 816 of MFMA time with two chains)
-      float4_t ac2[2][2];
+      float4_t ac2[KPS][NKC];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < KPS; ++u)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) ac2[u][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NKC; ++b) ac2[u][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #if RS_ABL != 2
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NKC; ++b)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ac2[u][b] = rs_mfma(rl[u][b], th[b], ac2[u][b]);
+        for (int u = 0; u < KPS; ++u) ac2[u][b] = rs_mfma(rl[u][b], th[b], ac2[u][b]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NKC; ++b)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ac2[u][b] = rs_mfma(rh[u][b], tl[b], ac2[u][b]);
+        for (int u = 0; u < KPS; ++u) ac2[u][b] = rs_mfma(rh[u][b], tl[b], ac2[u][b]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NKC; ++b)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ac2[u][b] = rs_mfma(rh[u][b], th[b], ac2[u][b]);
+        for (int u = 0; u < KPS; ++u) ac2[u][b] = rs_mfma(rh[u][b], th[b], ac2[u][b]);
 #endif
-      float4_t acc[2];
+      // (the sums of the chains are formed for the whole group BEFORE the first store of the group is built: the same statements in
+      //  one loop per tile - `acc = ac2[u][0]; acc += ac2[u][1]; ... store` - compiled to wrong results with hipcc 7.2.0 at -O3)
+      float4_t accs[KPS];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) acc[u] = ac2[u][0] + ac2[u][1];
+      for (int u = 0; u < KPS; ++u) {
+        accs[u] = ac2[u][0];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = 4 * s + 2 * q + u;
+        for (int b = 1; b < NKC; ++b) accs[u] = accs[u] + ac2[u][b];
+      }
+#pragma unroll
+      for (int u = 0; u < KPS; ++u) {
+        const float4_t acc = accs[u];
+        const int t = 2 * KPS * s + KPS * q + u;
         const float4_t rs = *(const float4_t*)(Rsc + 16 * t + 4 * kg);
         const float4_t w0 = t < RS_NREG ? wv[t < RS_NREG ? t : 0] : wt(t);
         float4_t o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(acc[u][r], iT * rs[r], w0[r]);
-        // (the tile displacement rides in the SCALAR offset, which the hardware range check ignores: `vo` alone says whether the
-        //  lane's row exists - and the compiler cannot turn 48 displaced offsets into 48 live registers)
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(acc[r], iT * rs[r], w0[r]);
 #if RS_ABL == 1
         if (o[0] == 12345.678f)
 #endif
@@ -375,7 +388,7 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
       }
     }
     // (the stores stay in flight: nothing in this loop waits on the vector-memory counter)
-    if (s + 1 < RS_NSTAGE) __syncthreads();
+    if (s + 1 < NSTG) __syncthreads();
   }
   DBG(6);
   // seen the chain's result -> count out; the last main workgroup re-arms the hand-off words for the next launch (every rider has
@@ -392,58 +405,69 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
   DBG(7);
 }
 
+template <int NCT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_resident(
     const float* __restrict__ W_old, float* __restrict__ W_new, long rows, GramPotrfJob job, ResidentJob rj) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-  const int n_gram = gp_riders(1);
-  const int n_chain = lr_rider_blocks(1, RS_D);
+  constexpr int NB = NCT / 4;                                 // 64-blocks of the dual system
+  const int n_gram = gp_riders(NB);
+  const int n_chain = lr_rider_blocks(NB, RS_D);
   const int bx = (int)blockIdx.x;
   if (bx < n_gram) {
     gram_potrf_rider<RS_D>(job, smem_raw);
     return;
   }
   if (bx < n_chain) {
-    solve_rider<RS_D>(job, smem_raw, bx - 1);             // column blocks 0 .. n_gram - 2 belong to the Gram riders
+    solve_rider<RS_D>(job, smem_raw, bx - 1);                 // column blocks 0 .. n_gram - 2 belong to the Gram riders
     return;
   }
-  if (bx < n_chain + RS_ND) {
-    rs_dprep(rj, job.ticket, smem_raw, bx - n_chain);
+  if (bx < n_chain + NCT) {                                   // D-prep riders: one per concept tile
+    rs_dprep<NCT>(rj, job.ticket, smem_raw, bx - n_chain);
     return;
   }
-  rs_main(W_old, W_new, rows, rj, job, smem_raw, bx - n_chain - RS_ND);
+  rs_main<NCT>(W_old, W_new, rows, rj, job, smem_raw, bx - n_chain - NCT);
+}
+
+template <int NCT>
+int rs_launch(uce_ctx* h, const float* W_old, const float* G, const float* C, const float* s, float* W_new, long rows, int N, int N_edit,
+              float lamb, unsigned char* ws, hipStream_t st) {
+  constexpr int NB = NCT / 4;
+  constexpr int NSTG = rs_nstage(NCT);
+  uint4_t* Dh = (uint4_t*)ws;
+  uint4_t* Rh = (uint4_t*)(ws + NSTG * RS_STAGE);
+  float* Dsc = (float*)(ws + 2 * NSTG * RS_STAGE);
+  float* Rsc = Dsc + 16 * NCT;
+  const int n_main = (int)((rows + RS_ROWS - 1) / RS_ROWS);
+  GramPotrfJob job{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, NB, h->R, N_edit, nullptr, 16 * NCT, 1, n_main};
+  job.Rh = Rh;
+  job.Rsc = Rsc;
+  ResidentJob rj{G, C, N_edit, Dh, Dsc, Rh, Rsc, n_main};
+  size_t smem = gp_smem(NB) > RS_MAIN_SMEM ? gp_smem(NB) : RS_MAIN_SMEM;
+  static PerDeviceOnce attr_once;
+  if (const int tok = attr_once.first()) {
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_resident<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_once.commit(tok);
+  }
+  const int nwg = lr_rider_blocks(NB, RS_D) + NCT + n_main;
+  hipLaunchKernelGGL(k_lr_resident<NCT>, dim3((unsigned)nwg), dim3(512), smem, st, W_old, W_new, rows, job, rj);
+  UCE_LAUNCH_CHECK();
+  return UCE_OK;
 }
 
 }  // namespace
 
 bool lr_resident_supported(int d, int N, int N_edit, long rows) {
-  return d == RS_D && N >= 1 && N <= 64 && N_edit >= 1 && N_edit <= N && rows >= 1;
+  return d == RS_D && N >= 1 && N <= 128 && N_edit >= 1 && N_edit <= N && rows >= 1;
 }
 
 size_t lr_resident_ws_bytes() {
-  return (size_t)2 * RS_NSTAGE * RS_STAGE + (64 + RS_D) * sizeof(float);
+  return (size_t)2 * rs_nstage(8) * RS_STAGE + (128 + RS_D) * sizeof(float);
 }
 
 // ws: lr_resident_ws_bytes() of handle workspace (D fragments | R fragments | D scales | R scales)
 int launch_lr_resident(uce_ctx* h, const float* W_old, const float* G, const float* C, const float* s, float* W_new, long rows,
                        int N, int N_edit, float lamb, unsigned char* ws, hipStream_t st) {
   if (!lr_resident_supported(RS_D, N, N_edit, rows) || !h || !ws) return UCE_EINVAL;
-  uint4_t* Dh = (uint4_t*)ws;
-  uint4_t* Rh = (uint4_t*)(ws + RS_NSTAGE * RS_STAGE);
-  float* Dsc = (float*)(ws + 2 * RS_NSTAGE * RS_STAGE);
-  float* Rsc = Dsc + 64;
-  const int n_main = (int)((rows + RS_ROWS - 1) / RS_ROWS);
-  GramPotrfJob job{C, s, N, lamb, h->slabs, h->ticket, h->Lmat, h->Linv, h->status, 1, h->R, N_edit, nullptr, 64, 1, n_main};
-  job.Rh = Rh;
-  job.Rsc = Rsc;
-  ResidentJob rj{G, C, N_edit, Dh, Dsc, Rh, Rsc, n_main};
-  size_t smem = gp_smem(1) > RS_MAIN_SMEM ? gp_smem(1) : RS_MAIN_SMEM;
-  static PerDeviceOnce attr_once;
-  if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_lr_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_once.commit(tok);
-  }
-  const int nwg = lr_rider_blocks(1, RS_D) + RS_ND + n_main;
-  hipLaunchKernelGGL(k_lr_resident, dim3((unsigned)nwg), dim3(512), smem, st, W_old, W_new, rows, job, rj);
-  UCE_LAUNCH_CHECK();
-  return UCE_OK;
+  if (N <= 64) return rs_launch<4>(h, W_old, G, C, s, W_new, rows, N, N_edit, lamb, ws, st);
+  return rs_launch<8>(h, W_old, G, C, s, W_new, rows, N, N_edit, lamb, ws, st);
 }

@@ -466,35 +466,40 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
       __builtin_amdgcn_raw_buffer_store_b128(pl[p], rs, (unsigned)(((((p * KGT + kblk * 8 + g) * 4 + (col & 3)) * (D / 4)) + (col >> 2)) * 16),
                                              0, 16 /* sc1 */);
   };
-  // R as (hi, lo) f16 fragments + column scales for the register-resident launch (one-block systems: rows of X = the 64 concepts).
-  // `scratch`: 32 dead LDS words.
-  auto store_rf = [&](const double* Vt, unsigned* cm) {
+  // R as (hi, lo) f16 fragments + column scales for the register-resident launch: rows 0..63 of X in X0, rows 64..127 in X1 (two-
+  // block systems; null otherwise).  `cm`: 32 dead LDS words.
+  auto store_rf = [&](const double* X0, const double* X1, unsigned* cm) {
     if (!j.Rh) return;
+    const int NKC = j.NEP >> 5;                              // k-blocks of 32 concepts (2 or 4)
     if (tid < 32) cm[tid] = 0u;
     __syncthreads();
     {
-      const int c = tid & 31, rg = tid >> 5;               // 32 columns x 16 groups of 4 rows
+      const int c = tid & 31, rg = tid >> 5;               // 32 columns x 16 groups of 4 (+ 4) rows
       float m = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * rg + r < j.N_edit) m = fmaxf(m, fabsf((float)Vt[(4 * rg + r) * SV_VLD + c]));
+      for (int r = 0; r < 4; ++r) {
+        if (4 * rg + r < j.N_edit) m = fmaxf(m, fabsf((float)X0[(4 * rg + r) * SV_VLD + c]));
+        if (X1 && 64 + 4 * rg + r < j.N_edit) m = fmaxf(m, fabsf((float)X1[(4 * rg + r) * SV_VLD + c]));
+      }
       atomicMax(&cm[c], __float_as_uint(m));
     }
     __syncthreads();
-    if (tid < 256) {
-      const int u = tid >> 7, b = (tid >> 6) & 1, lane = tid & 63, i = lane & 15, kg = lane >> 4;
+    if (tid < 128 * NKC) {
+      const int lane = tid & 63, i = lane & 15, kg = lane >> 4;
+      const int ub = tid >> 6, u = ub / NKC, b = ub - u * NKC;
       const int c = 16 * u + i;
       const float sc = rs_scale(rs_clamp_exp(cm[c]));
       float y[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int row = 32 * b + 16 * (e >> 2) + 4 * kg + (e & 3);
-        y[e] = row < j.N_edit ? (float)Vt[row * SV_VLD + c] * sc : 0.f;
+        const double x = row < 64 ? X0[row * SV_VLD + c] : X1[(row - 64) * SV_VLD + c];
+        y[e] = row < j.N_edit ? (float)x * sc : 0.f;
       }
       uint4_t hi, lo;
       rs_split8(y, hi, lo);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(j.Rh, 0, (D / 16) * 4 * 1024, 0x00020000);
-      const unsigned off = (unsigned)(((((2 * colblk + u) * 2 + b) * 2) * 64 + lane) * 16);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(j.Rh, 0, (D / 16) * NKC * 2 * 1024, 0x00020000);
+      const unsigned off = (unsigned)(((((2 * colblk + u) * NKC + b) * 2) * 64 + lane) * 16);
       __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off, 0, 16 /* sc1 */);
       __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off + 1024, 0, 16);
     }
@@ -534,7 +539,7 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
     DBG(12);
     store_r(V0, 0);
     store_rp(V0, 0);
-    store_rf(V0, (unsigned*)V1);                          // (Y is dead)
+    store_rf(V0, nullptr, (unsigned*)V1);                 // (Y is dead)
     DBG(13);
     finish();
     return;
@@ -569,6 +574,7 @@ __device__ __forceinline__ void solve_rider(const GramPotrfJob& j, unsigned char
   DBG(12);
   store_r(V0, 0);
   store_rp(V0, 0);
+  store_rf(V0, V1, (unsigned*)V2);                        // (X1 is still in V1; V2 is dead)
   DBG(13);
   finish();
 }
