@@ -515,3 +515,36 @@ def test_ranks_of_one_node_get_disjoint_core_blocks():
     assert 0 <= G.png_worker_count(8, 8) <= 8 and G.png_worker_count(0, 1) == 0
     auto = G.png_worker_count(G.PNG_WORKERS_AUTO, 1)                     # a quarter of the cores of the rank, 1 .. 32
     assert 1 <= auto <= 32 and auto <= max(1, len(os.sched_getaffinity(0)) - 1)
+
+
+def test_prefix_encoding_gives_the_states_of_the_full_causal_forward():
+    """edit.last_token_embeddings (batched, own pipeline) runs CLIP's text encoder on token positions 0 .. max(idx) only: the encoder
+    is causal, so those states are the full 77-position forward's - checked on transformers' CLIPTextModel at SD-1.4's REAL widths
+    (12 layers x 768, seeded-random weights, fp32 on the CPU) and through last_token_embeddings on the tiny pipeline incl. the
+    cases that cannot be cut ('' -> BOS at index 0 is fine; a > 75-token string needs all positions)."""
+    from uce_amd.sd import pipeline as sdp
+    torch.manual_seed(0)
+    te = sdp.build_text_encoder(sdp.TextConfig()).eval()
+    ids = torch.randint(256, 49000, (3, sdp.MAX_LEN))
+    ids[:, 0] = sdp.BOS
+    with torch.no_grad():
+        full = te(input_ids=ids)[0]
+        for n_pos in (1, 4, 9, 30):
+            part = te(input_ids=ids[:, :n_pos])[0]
+            assert part.shape == (3, n_pos, 768)
+            assert float((part - full[:, :n_pos]).norm() / full[:, :n_pos].norm()) < 2e-6, n_pos
+    pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
+    seen = []
+    real = pipe.encode_prompt_prefix
+    pipe.encode_prompt_prefix = lambda prompts, device, n_pos: (seen.append(n_pos), real(prompts, device, n_pos))[1]
+    prompts = ["Van Gogh", "", "art", "a painting by Picasso"]
+    one = E.last_token_embeddings(pipe, prompts, "cpu")                       # per string: the reference's full-length calls
+    bat = E.last_token_embeddings(pipe, prompts, "cpu", batch_size=4)
+    assert seen == [5]                                                         # BOS + 4 words -> index 4
+    for k in one:
+        assert torch.allclose(one[k], bat[k], atol=1e-5, rtol=1e-5), k
+    seen.clear()
+    long_prompt = " ".join(f"w{i}" for i in range(90))
+    bat = E.last_token_embeddings(pipe, ["art", long_prompt], "cpu", batch_size=2)
+    assert seen == [76]                                                        # truncated to 77 tokens: index 75 -> 76 positions
+    assert torch.allclose(bat[long_prompt], E.last_token_embeddings(pipe, [long_prompt], "cpu")[long_prompt], atol=1e-5, rtol=1e-5)

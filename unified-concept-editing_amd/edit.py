@@ -579,6 +579,7 @@ def save_uce_state(slab: WeightSlab, save_dir: str, exp_name: str) -> str:
 # --------------------------------------------------------------------------------------------
 
 AUTO_EMBED_BATCH = 64
+AUTO_EMBED_MAX = 1024        # strings per forward at most (automatic mode: see last_token_embeddings)
 
 
 def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[Dict[str, torch.Tensor]] = None,
@@ -593,20 +594,37 @@ def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[
     edit spends its wall-clock on.  batch_size None / < 0: automatic (64 for the build's own pipeline on a GPU, else per string)."""
     out = {} if cache is None else cache
     todo = list(dict.fromkeys(e for e in prompts if e not in out))     # unique, first-seen order
-    if batch_size is None or batch_size < 0:
-        # automatic: the build's own pipeline on a GPU batches (64 strings per forward - the rows of a batch are independent and the
-        # gather is bit-exact, tests/test_host_cpu.py, test_edit_gpu.py); a foreign pipe object keeps the reference's call pattern
+    auto = batch_size is None or batch_size < 0
+    if auto:
+        # automatic: the build's own pipeline on a GPU batches (the rows of a batch are independent and the gather is bit-exact,
+        # tests/test_host_cpu.py, test_edit_gpu.py); a foreign pipe object keeps the reference's call pattern
         from .sd import pipeline as _sdp
         own = isinstance(pipe, _sdp.StableDiffusionPipeline) and torch.device(device).type == "cuda"
         batch_size = AUTO_EMBED_BATCH if own else 0
     if batch_size and batch_size > 1 and len(todo) > 1:
-        for i in range(0, len(todo), batch_size):
-            chunk = todo[i:i + batch_size]
-            t_emb = pipe.encode_prompt(prompt=chunk, device=device, num_images_per_prompt=1,
-                                       do_classifier_free_guidance=False)[0]            # [B, 77, d]
-            mask = pipe.tokenizer(chunk, padding="max_length", max_length=pipe.tokenizer.model_max_length,
-                                  truncation=True, return_tensors="pt")["attention_mask"]
-            idx = mask.sum(dim=1) - 2
+        prefix_ok = hasattr(pipe, "encode_prompt_prefix")
+        T = pipe.tokenizer.model_max_length
+        mask_all = pipe.tokenizer(todo, padding="max_length", max_length=T, truncation=True, return_tensors="pt")["attention_mask"]
+        idx_all = mask_all.sum(dim=1) - 2
+        i = 0
+        while i < len(todo):
+            B = batch_size
+            if auto and prefix_ok:
+                # the automatic batch is a budget of TOKEN POSITIONS (64 strings x 77 positions), not of strings: with the encoder cut
+                # to the positions a batch needs (below), short concept names go through in batches of up to 1024 - the 200
+                # launches of a forward cost the same for 64 x 5 positions as for 1024 x 5
+                B = min(AUTO_EMBED_MAX, len(todo) - i)
+                while B > batch_size and B * (max(int(idx_all[i:i + B].max()), 0) + 1) > batch_size * T:
+                    B = max(batch_size, B // 2)
+            chunk, idx = todo[i:i + B], idx_all[i:i + B]
+            i += len(chunk)
+            if prefix_ok and int(idx.min()) >= 0:
+                # the build's own pipeline: the causal encoder on positions 0 .. max(idx) only (a concept name ends at position
+                # 2-8 of 77; the states of a prefix do not depend on what follows it)
+                t_emb = pipe.encode_prompt_prefix(chunk, device, int(idx.max()) + 1)    # [B, max(idx) + 1, d]
+            else:
+                t_emb = pipe.encode_prompt(prompt=chunk, device=device, num_images_per_prompt=1,
+                                           do_classifier_free_guidance=False)[0]        # [B, 77, d]
             idx = torch.where(idx < 0, idx + t_emb.shape[1], idx)      # python indexing of the reference: -1 wraps
             if t_emb.is_cuda and t_emb.shape[-1] % 8 == 0:
                 rows = UceHandle.get(t_emb.device).gather_last_token(t_emb, idx)     # fused gather + fp32 widening (HIP)

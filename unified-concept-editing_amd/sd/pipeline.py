@@ -367,6 +367,17 @@ class StableDiffusionPipeline:
             ne = enc(neg)
         return pe, ne
 
+    def encode_prompt_prefix(self, prompts, device, n_pos: int) -> torch.Tensor:
+        """Hidden states of the FIRST `n_pos` token positions only -> [B, n_pos, d] (pipeline dtype).  CLIP's text encoder is
+        causal: position p attends to positions <= p, every other layer is row-wise, so the states of a prefix are those of the
+        full 77-position forward (up to the summation order of a GEMM of another height) - and the closed-form edit reads ONE
+        position per string, `attention_mask.sum() - 2` (uce_sd_erase.py:25-42), which for a concept name sits at position 2-8:
+        edit.last_token_embeddings runs the encoder on the positions up to the batch's largest index instead of all 77."""
+        device = torch.device(device) if device is not None else self.device
+        tok = self.tokenizer(list(prompts), padding="max_length", max_length=self.tokenizer.model_max_length,
+                             truncation=True, return_tensors="pt")
+        return self.text_encoder(input_ids=tok["input_ids"][:, :n_pos].to(device))[0].to(self.dtype)
+
     def _draw_latents(self, n_prompts: int, n: int, hh: int, ww: int, generator) -> torch.Tensor:
         """diffusers' randn_tensor: a CPU generator draws on the CPU in the target dtype, then moves.
         One generator -> one draw of the whole batch (what generate-images-sd.py:37-42 gets for its single
@@ -508,6 +519,16 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
                     [negative_prompt] * len(prompts) if isinstance(negative_prompt, str) else list(negative_prompt))
                 ne, npool = enc(neg)
         return pe, ne, pp, npool
+
+    def encode_prompt_prefix(self, prompts, device, n_pos: int) -> torch.Tensor:
+        """The first `n_pos` positions of `prompt_embeds` (both encoders' penultimate states, causal: see StableDiffusionPipeline)."""
+        device = torch.device(device) if device is not None else self.device
+        parts = []
+        for tok, te in ((self.tokenizer, self.text_encoder), (self.tokenizer_2, self.text_encoder_2)):
+            ids = tok(list(prompts), padding="max_length", max_length=tok.model_max_length, truncation=True,
+                      return_tensors="pt")["input_ids"][:, :n_pos].to(device)
+            parts.append(te(input_ids=ids, output_hidden_states=True).hidden_states[-2])
+        return torch.cat(parts, dim=-1).to(self.dtype)
 
     @torch.no_grad()
     def __call__(self, prompt, num_inference_steps: int = 50, guidance_scale: float = 5.0,
