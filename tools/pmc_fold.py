@@ -26,7 +26,9 @@ EDIT_KERNELS = ["k_lr_resident", "k_lr_project", "k_lr_update_s", "k_lr_update",
 CHAINS = {"potrf": ["k_potrf_la", "k_potrf_first", "k_potrf_step", "k_potrf_panel", "k_potrf_diag"],
           "k_trisolve": ["k_trinv_fwd", "k_trinv_merge", "k_trinv_bwd"],
           "gram_primal": ["k_gram_primal", "k_reduce_slabs"]}     # uce_edit's primal path: A split over the concepts + its reduction
-MAIN_KERNELS = {"xattn": ("k_xattn_g", "k_xattn"), "sattn": ("k_sattn_h", "k_sattn_p", "k_sattn")}   # ONE launch of one of these per call
+# ONE launch of one of these per call (a self-attention of at most 128 keys runs k_xattn: uce_sattn.hip's short-key rule)
+MAIN_KERNELS = {"xattn": ("k_xattn_g", "k_xattn"), "sattn": ("k_sattn_h", "k_sattn_p", "k_sattn", "k_xattn")}
+CANONICAL = {"xattn": "k_xattn", "sattn": "k_sattn"}                                                  # the name the folded entry carries
 AUX_KERNELS = {"xattn": (), "sattn": ("k_vt",)}                                                      # helpers a call may launch BEFORE its main kernel
 
 
@@ -146,7 +148,7 @@ def by_manifest(path, mode, shapes):
             continue                                   # counted; the total check below reports it
         key = shape_key(mode, shapes[idx])
         sig.setdefault(key, set()).add((name.split("(")[0], grid))
-        g[(key, main[-1])].append(c)                   # every form of the main kernel under one name
+        g[(key, CANONICAL[mode])].append(c)            # every form of the main kernel under one name
         for ak, ac in pending:
             g[(key, ak)].append(ac)
         pending = []
@@ -210,7 +212,7 @@ def main():
     elif mode in ("xattn", "sattn"):
         d = sys.argv[2]
         pf, pw, ps = paths(d, mode)
-        names = [MAIN_KERNELS[mode][-1]] + list(AUX_KERNELS[mode])
+        names = [CANONICAL[mode]] + list(AUX_KERNELS[mode])
         groups = []
         for p, tag in zip((pf, pw, ps), ("fetch", "write", "sq")):
             log = os.path.join(d, f"{mode}_pmc_{tag}.log")
