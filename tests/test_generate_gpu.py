@@ -109,10 +109,11 @@ def test_real_coco30k_rows_at_sd14_size(tmp_path):
 
 
 def test_default_automatic_batch_on_130_rows_matches_rows_generated_alone(tmp_path):
-    """The CLI default (--batch_prompts 0): 130 rows at SD-1.4 size are denoised 128 + 2 per pipe() call (free HBM of a whole
-    MI355X -> the top of the ladder); every file of the row-by-row loop is there, and the latents of three rows - the first of the
-    full batch, one in its middle, the one that lands in the ragged tail batch - are those of the row generated ALONE within the
-    stated distance (same CPU-seeded draw, other tile forms)."""
+    """The CLI default (--batch_prompts 0): 130 rows at SD-1.4 size are denoised 64 + 64 + 2 per pipe() call on a whole 288 GB MI355X
+    (half of the free HBM at 1.5 GB per image = 96, rounded down on the ladder; 128 + 2 where more is free); every file of the
+    row-by-row loop is there, and the latents of three rows - the first of a full batch, one in the middle of a later one, the one
+    that lands in the ragged tail batch - are those of the row generated ALONE within the stated distance (same CPU-seeded draw,
+    other tile forms)."""
     from uce_amd import generate, synth
     from uce_amd.sd import pipeline as sdp
     csv_path = synth.write_prompts_csv(str(tmp_path / "coco_synth.csv"), 130, seed=1)
@@ -122,7 +123,7 @@ def test_default_automatic_batch_on_130_rows_matches_rows_generated_alone(tmp_pa
               device="cuda:0", torch_dtype=torch.bfloat16, guidance_scale=7.5, num_inference_steps=6, num_images_per_prompt=1,
               synthetic=True, pipe=pipe, latents_only=True)
     stats = generate.generate_images(exp_name="auto", batch_prompts=0, **kw)
-    assert stats["images"] == 130 and stats["batch_prompts"] == 128.0
+    assert stats["images"] == 130 and stats["batch_prompts"] in (64.0, 128.0)
     cases = [int(c) for c in df.case_number]
     assert sorted(os.listdir(tmp_path / "auto")) == sorted(f"{c}.pt" for c in cases)
     for idx in (0, 77, 129):
