@@ -554,7 +554,7 @@ def generation_roofline(pipe, device, steps: int, seconds_per_image: float, batc
     """The images/s half of the metric against the chip: counted MFMA FLOPs per image (count_generation_flops) over the measured
     seconds per image of ONE rank -> achieved PFLOP/s and its fraction of the dense bf16 peak; per kernel family, the counted FLOPs
     over the family's share of the image time (shares from the committed steady-state rocprofv3 profile of the same loop at the
-    same prompts per call, profiles/r05/generate_families_b<batch>.json, when there is one)."""
+    same prompts per call, profiles/r06/generate_families_b<batch>.json - else the round-5 one - when there is one)."""
     fl = count_generation_flops(pipe, device, steps)
     per_image = fl["per_image"]
     ach = per_image / seconds_per_image / 1e15
@@ -566,8 +566,8 @@ def generation_roofline(pipe, device, steps: int, seconds_per_image: float, batc
            "floor_seconds_per_image": round(per_image / (BF16_MFMA_PEAK_TF * 1e12), 5),
            "note": "FLOPs counted from the build's own U-Net / VAE (2 M N K per linear layer and convolution tap, 4 B L Lk C per attention); "
                    "norms, activations, text encoder, host work are in the seconds but not in the FLOPs"}
-    for cand in (batch, 128, 64):
-        path = os.path.join(ROOT, "profiles", "r05", f"generate_families_b{cand}.json")
+    for rnd, cand in [(r, c) for c in (batch, 128, 64) for r in ("r06", "r05")]:
+        path = os.path.join(ROOT, "profiles", rnd, f"generate_families_b{cand}.json")
         if os.path.exists(path):
             try:
                 fam = json.load(open(path))
