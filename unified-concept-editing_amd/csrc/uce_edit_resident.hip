@@ -42,19 +42,17 @@ constexpr int RS_CW = 7;                  // compute waves of a main workgroup (
 constexpr int RS_ROWS = 16 * RS_CW;       // rows per main workgroup
 constexpr int RS_STAGE = 16 * 1024;       // LDS ring stage: 8 / NCT k-blocks of D fragments, 16 / NCT column tiles of R fragments
 __host__ __device__ constexpr int rs_nstage(int nct) { return 3 * nct; }       // stages per operand (12 / 24)
-// Cache policy of the fragment loads.  The producers publish write-through (sc1) and post their flag after the stores drained; a
-// consumer's FIRST read of a line in this launch happens after that flag, and neither its L1 nor its XCD's L2 can hold the line
-// from before (both are invalidated at the launch boundary, nothing in this launch reads the buffers earlier) - so a plain load is
-// coherent here, and 23 of the 24 main workgroups of an XCD hit the L2 instead of going to memory for every 16 KB stage (sc1 loads:
-// ~1 us of exposed latency per stage, 24 stages).
 #ifndef RS_ABL
 #define RS_ABL 0          // measurement builds only: 1 = phase B without its stores, 2 = without its MFMAs
 #endif
 #ifndef RS_ST_AUX
-#define RS_ST_AUX 0       // plain stores: phase B 14.5 us against 16-19 with the nt hint (profiles/r06/resident_ablation.txt)
+#define RS_ST_AUX 0       // plain stores: phase B 14.5 us against 16-19 with the nt hint (profiles/r06/resident/ablation_stores_mfma_nt.log)
 #endif
+// Cache policy of the fragment loads: sc1 (past the L1 and this XCD's L2), like every other consumer of a payload another workgroup of
+// the SAME launch published write-through (uce_lowrank_riders.h: st_sc1).  A plain load measured the same (the producer wave hides
+// the latency either way) and is only coherent if no stale line of the previous launch's fragments survives in this XCD's L2.
 #ifndef RS_DMA_AUX
-#define RS_DMA_AUX 0
+#define RS_DMA_AUX 16
 #endif
 constexpr int RS_NREG = 36;               // column tiles of the W tile held in registers (144 VGPRs) ...
 constexpr int RS_NLDS = RS_NT - RS_NREG;  // ... and in LDS (12 KB per wave): 192 + the working set of either phase does not fit 256 registers
