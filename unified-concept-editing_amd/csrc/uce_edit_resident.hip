@@ -362,7 +362,8 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
         for (int u = 0; u < KPS; ++u) ac2[u][b] = rs_mfma(rh[u][b], th[b], ac2[u][b]);
 #endif
       // (the sums of the chains are formed for the whole group BEFORE the first store of the group is built: the same statements in
-      //  one loop per tile - `acc = ac2[u][0]; acc += ac2[u][1]; ... store` - compiled to wrong results with hipcc 7.2.0 at -O3)
+      //  one loop per tile - `acc = ac2[u][0]; acc += ac2[u][1]; ... store` - compiled to wrong results with hipcc 7.2.0 at -O3, with or
+      //  without wait states behind the MFMAs: not a read-after-MFMA hazard; tests/test_edit_gpu.py's changing-input test is the guard)
       float4_t accs[KPS];
 #pragma unroll
       for (int u = 0; u < KPS; ++u) {
