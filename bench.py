@@ -774,38 +774,45 @@ def uce_wall_leg(pipe_bf16, device, tmpdir: str):
     import contextlib
     import io
 
-    def legs(pipe, which):
+    def legs(pipe, which, reps=1, per_string=True):
         out = []
         for name, n_e, n_p in which:
             edit = [f"artist number {i}" for i in range(n_e)]
             pres = [f"kept artist {i}" for i in range(n_p)]
             guide = ["art"] * n_e
             ent = {"workload": name, "concepts": n_e + n_p}
-            for label, eb in (("default", None), ("per_string", 0)):        # default = automatic (64 strings per forward on this pipeline)
-                tm = {}
-                with contextlib.redirect_stdout(io.StringIO()):
-                    E.UCE(pipe, edit, guide, pres, 1.0, 1.0, 0.5, tmpdir, f"wall_{name}_{label}", device=str(device), embed_batch=eb,
-                          timings=tm)
-                ent[label] = {k: round(v, 4) for k, v in tm.items()}
+            modes = (("default", None, reps),) + ((("per_string", 0, 1),) if per_string else ())   # default = automatic batching
+            for label, eb, n in modes:
+                runs = []
+                for _ in range(n):
+                    tm = {}
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        E.UCE(pipe, edit, guide, pres, 1.0, 1.0, 0.5, tmpdir, f"wall_{name}_{label}", device=str(device), embed_batch=eb,
+                              timings=tm)
+                    runs.append({k: round(v, 4) for k, v in tm.items()})
+                runs.sort(key=lambda t: t["total"])
+                ent[label] = runs[len(runs) // 2]                               # the median call
+                if n > 1:
+                    ent[label + "_totals"] = [t["total"] for t in runs]
             out.append(ent)
         return out
 
     all_cfg = (("sd14_erase2p3", 2, 3), ("sd14_erase50", 50, 0), ("sd14_erase1000p500", 1000, 500))
     res = {"metric": "UCE() wall seconds, end to end (the reference's own printed figure)", "unit": "s",
            "stages": "slab | embed | edit | save | total"}
-    extra = legs(pipe_bf16, all_cfg[1:]) if pipe_bf16 is not None else None
+    extra = legs(pipe_bf16, all_cfg[1:], per_string=False) if pipe_bf16 is not None else None
     del pipe_bf16
     torch.cuda.empty_cache()
     pipe = sdp.load_pipeline("CompVis/stable-diffusion-v1-4", torch.float32, device, synthetic=True, vae=False)
-    legs(pipe, all_cfg[:1])                                                  # untimed: first-call set-up of the fp32 encoder
+    legs(pipe, all_cfg[:1], per_string=False)                                # untimed: first-call set-up of the fp32 encoder
     res["text_encoder"] = ("CLIP-L architecture, seeded-random weights, fp32 (the CLI's / reference's load: torch_dtype float32, no VAE), "
                            "on the GPU; batched mode runs it on token positions 0 .. max(last-token index) only (causal encoder: "
                            "edit.last_token_embeddings)")
-    first = legs(pipe, all_cfg)            # the first UCE() of each size in this process: includes the GEMM library's one-time set-up per new shape
-    res["configs"] = legs(pipe, all_cfg)   # ... and the same calls again: what the work itself costs
+    first = legs(pipe, all_cfg, per_string=False)   # the first UCE() of each size in this process: includes the GEMM library's one-time set-up per new shape
+    res["configs"] = legs(pipe, all_cfg, reps=3)    # ... and the same calls again (median of three: a shared host adds 10-150 ms at will)
     res["first_call_configs"] = first
-    res["note"] = ("`configs` = the second UCE() of each size in the process, `first_call_configs` = the first (torch's GEMM library picks a "
-                   "kernel per new shape on first use: ~50 ms at 1 500 concepts)")
+    res["note"] = ("`configs` = the median of three further UCE() calls of each size in the process (all totals listed), `first_call_configs` = "
+                   "the first (torch's GEMM library picks a kernel per new shape on first use: ~50 ms at 1 500 concepts)")
     if extra is not None:
         res["bf16_pipeline"] = {"text_encoder": "the generation leg's bf16 pipeline (NOT what the CLI loads): labelled extra",
                                 "configs": extra}
