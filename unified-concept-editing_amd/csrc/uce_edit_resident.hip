@@ -1,30 +1,30 @@
-// The register-resident form of the low-rank edit  W_new = W_old + (W_old D_e^T) R_e  for d = 768, N <= 64 (reference: the per-module
+// The register-resident form of the low-rank edit  W_new = W_old + (W_old D_e^T) R_e  for d = 768, N <= 128 (reference: the per-module
 // `mat1 @ torch.inverse(mat2)` of trainscripts/uce_sd_erase.py:56-82, collapsed as DESIGN.md section 2 derives) - ONE launch, W_old read
-// from HBM ONCE and never again:
+// from HBM ONCE and never again (DESIGN.md section 4.39):
 //
 //   * a main workgroup (7 computing waves + one LDS-DMA producer wave) owns 112 rows; a wave owns 16 of them and keeps its 16 x 768 fp32
 //     tile of W_old in 144 registers + 12 KB of LDS from the first load to the final store (SD-1.4's 24 960 x 768 slab = 223
-//     workgroups = 223 CUs beside the 29 rider workgroups: the final stores are issue-bound PER CU at ~13 B/cycle, so the CU count
-//     is what sets the length of phase B), laid out as the accumulator tiles of the TRANSPOSED update: tile t (16 columns), lane
-//     (n = lane & 15, kg = lane >> 4) holds W[row n][16 t + 4 kg + 0..3];
+//     workgroups beside the 29 / 33 rider workgroups: one per CU), laid out as the accumulator tiles of the TRANSPOSED update: tile t
+//     (16 columns), lane (n = lane & 15, kg = lane >> 4) holds W[row n][16 t + 4 kg + 0..3];
 //   * both products run on the f16 matrix cores with fp32-equivalent operands - the two-term split of uce_apply_h2.hip (x s = x_h +
-//     x_l under a power-of-two scale per row / column, three MFMAs l*h + h*l + h*h per product, fp32 accumulation): the exact-f32
-//     MFMA form of the two-launch path issues 2 * 2 * rows * d * 64 flop at 157 TF/s (31 us at 50 concepts), this one 3 x that at
-//     2.5 PF/s (6 us), so the step's floor is its HBM traffic (W in once, W out once);
+//     x_l under a power-of-two scale per row / column / concept, three MFMAs l*h + h*l + h*h per product, fp32 accumulation): the
+//     exact-f32 MFMA form of the two-launch path issues 2 * 2 * rows * d * 64 flop at 157 TF/s (31 us at 50 concepts), this one 3 x that
+//     at 2.5 PF/s (6 us), so the step's floor is its HBM traffic (W in once, W out once);
 //   * phase A  T^T = D_e W^T : the contraction index (W's column) may be permuted as long as both operands agree, and the
 //     accumulator layout above IS a valid B-operand layout of v_mfma_f32_16x16x32_f16 for the k-block of 32 columns made of tiles
 //     2b and 2b + 1 (slot j of lane kg <-> column 32 b + 16 (j >> 2) + 4 kg + (j & 3)); the A operand - D_e = G - C_e as f16 (hi,
-//     lo) fragments in exactly that order - is prepared ONCE by four "D-prep" rider workgroups of the same launch while the main
-//     workgroups wait for their W tiles, and streamed through a two-stage LDS ring shared by the 8 waves;
+//     lo) fragments in exactly that order - is prepared ONCE by "D-prep" rider workgroups of the same launch (one per 16 concepts)
+//     while the main workgroups wait for their W tiles, and streamed through a three-stage LDS ring by the producer wave;
 //   * T stays in registers too: the output tile of phase A (lane: row n, concepts 16 ct + 4 kg + 0..3) is, after its own split, the
 //     B operand of phase B  W_new^T += R^T T^T  under the same permutation trick on the concept index;
 //   * the small-system chain (Gram -> Cholesky -> solves, uce_lowrank_riders.h) rides in the first workgroups of the launch as in the
-//     two-launch form; its solve riders publish R as f16 (hi, lo) fragments + per-column scales (write-through), the last one posts
-//     stage 4, the main workgroups - T ready, W in registers - wait for it, stream the fragments through the same LDS ring and store.
+//     two-launch form; its solve riders publish R as f16 (hi, lo) fragments + per-column scales (write-through) and count out; the
+//     main workgroups - T ready, W in registers - wait for that counter, stream the fragments through the same ring and store
+//     (phase B sits on the write floor of HBM: tools/ubench/store_pattern.hip).
 //
 // Hand-off words (h->ticket, zero between launches): [0] [1] the riders' own, [2] solve riders done (the main workgroups wait for all
-// of them - no "last rider posts a stage" hop), [3] main workgroups done (the last one re-arms [1] .. [4]), [4] D-prep riders done.  Riders come FIRST in the grid: whatever the CU count, they are resident before any
-// main workgroup waits for them.
+// of them - no "last rider posts a stage" hop), [3] main workgroups done (the last one re-arms [1] .. [4]), [4] D-prep riders done.
+// Riders come FIRST in the grid: whatever the CU count, they are resident before any main workgroup waits for them.
 #define UCE_DBG_SYM g_dbg_res    // -DUCE_CHAIN_DEBUG: this launch's own stamp buffer (tools/dbg_chain.py --resident)
 #define UCE_DBG_READ uce_debug_read_res
 #include "uce_lowrank_riders.h"
@@ -56,7 +56,7 @@ __host__ __device__ constexpr int rs_nstage(int nct) { return 3 * nct; }       /
 #endif
 constexpr int RS_NREG = 36;               // column tiles of the W tile held in registers (144 VGPRs) ...
 constexpr int RS_NLDS = RS_NT - RS_NREG;  // ... and in LDS (12 KB per wave): 192 + the working set of either phase does not fit 256 registers
-// main workgroup LDS: ring [3][16 KB] | R column scales [768] | D concept scales [64] | W tail tiles [8 waves][12][1 KB]
+// main workgroup LDS: ring [3][16 KB] | R column scales [768] | D concept scales [128] | W tail tiles [7 waves][12][1 KB]
 constexpr int RS_RING = 3;                // ring stages: two DMA stages in flight while one is computed on
 constexpr int RS_LDS_RSC = RS_RING * RS_STAGE;
 constexpr int RS_LDS_DSC = RS_LDS_RSC + RS_D * 4;

@@ -3,6 +3,7 @@
 // Cholesky -> triangular solves -> R) and their hand-off words.  See uce_lowrank2.hip for the design notes.
 #pragma once
 #include "uce_common.h"
+#include <type_traits>
 #include "uce_potrf64.h"
 #include "uce_potrf_la.h"
 
@@ -251,12 +252,15 @@ struct GramPotrfJob {
   float* Rsc;           // [d]
 };
 
-constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of the system (split over the feature axis)
+constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of a TWO-block system (split over the feature axis)
+constexpr int GP_NB1 = 8;       // ... of a one-block system: the Gram is bound by the f64 matrix pipe (64 cycles per 16 x 16 x 4 step and SIMD:
+                                // 5.6 us on four CUs); eight CUs halve that for 0.8 us more of slab summation (every slab load is in flight at once)
+__host__ __device__ constexpr int gp_nb(int nb) { return nb <= 1 ? GP_NB1 : GP_NB; }
 constexpr int GP_MAXB = 2;      // largest system the riders take: 128 x 128 (3 lower tiles)
 constexpr int GP_LD = 40;       // floats, k-contiguous NT tile stride (conflict-free b128)
 constexpr int GP_TLD = 66;      // doubles
 
-__host__ __device__ constexpr int gp_riders(int nb) { return GP_NB * nb * (nb + 1) / 2; }
+__host__ __device__ constexpr int gp_riders(int nb) { return gp_nb(nb) * nb * (nb + 1) / 2; }
 
 // Write-through (sc1) stores / L1-bypassing (sc1) loads of hand-off payloads: a relaxed agent-scope atomic of 8 bytes
 // lowers to global_store/load_dwordx2 sc1.  Payload published this way needs NO release fence (buffer_wbl2 writes back
@@ -600,7 +604,8 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   const int half = w >> 2, wq = w & 3;
   const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
   const int ht = tid & 255;                                       // thread index within its half
-  const int tile = blockIdx.x / GP_NB, blk = blockIdx.x % GP_NB;  // tile of the system, feature slice
+  const int nbk = gp_nb(j.nb);
+  const int tile = blockIdx.x / nbk, blk = blockIdx.x % nbk;      // tile of the system, feature slice
   const int ti = tile == 0 ? 0 : 1, tk = tile == 2 ? 1 : 0;       // lower tiles in order (0,0) (1,0) (1,1)
   const int nriders = gp_riders(j.nb);
   // 16 x 16 sub-tiles of this wave: a DIAGONAL tile of the system is only read in its lower triangle (fetch_tile below), so its
@@ -623,19 +628,23 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   for (int i = 0; i < 4; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
   float* Ah = As + half * 64 * GP_LD;
   float* Bh = Bs + half * 64 * GP_LD;
-  const int lrow = ht >> 3, lc4 = (ht & 7) * 4;
-  constexpr int KS = D / (2 * GP_NB);                             // features per (block, half) slice
-  constexpr int NCH = KS / 32;                                    // 32-feature chunks (3 / 4 / 8)
+  auto gram_mm = [&](auto nbk_c) __attribute__((always_inline)) {
+  constexpr int NBK = decltype(nbk_c)::value;
+  constexpr int KS = D / (2 * NBK);                               // features per (block, half) slice
+  constexpr int CHK = (KS % 32 == 0) ? 32 : 16;                   // features per staged chunk (d = 768 on eight riders: 48 = 3 x 16)
+  constexpr int NCH = KS / CHK;
+  constexpr int TPRW = CHK / 4, RPP = 256 / TPRW, NPP = 64 / RPP; // threads per row, rows per pass, passes of a half's 256 threads
+  const int lrow = ht / TPRW, lc4 = (ht % TPRW) * 4;
   const int kbeg = (blk * 2 + half) * KS;
   // the whole slice is fetched up front (one memory round trip instead of one per chunk)
-  float4_t pre[NCH][2], preb[NCH][2];
+  float4_t pre[NCH][NPP], preb[NCH][NPP];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int ra = ti * 64 + p * 32 + lrow, rb = tk * 64 + p * 32 + lrow;
-      pre[ch][p] = *(const float4_t*)(j.C + (size_t)(ra < j.N ? ra : j.N - 1) * D + kbeg + ch * 32 + lc4);
-      preb[ch][p] = *(const float4_t*)(j.C + (size_t)(rb < j.N ? rb : j.N - 1) * D + kbeg + ch * 32 + lc4);
+    for (int p = 0; p < NPP; ++p) {
+      const int ra = ti * 64 + p * RPP + lrow, rb = tk * 64 + p * RPP + lrow;
+      pre[ch][p] = *(const float4_t*)(j.C + (size_t)(ra < j.N ? ra : j.N - 1) * D + kbeg + ch * CHK + lc4);
+      preb[ch][p] = *(const float4_t*)(j.C + (size_t)(rb < j.N ? rb : j.N - 1) * D + kbeg + ch * CHK + lc4);
     }
 #ifdef UCE_CHAIN_DEBUG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -647,14 +656,14 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     if (ch == 1) DBG(7);
 #endif
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int r = p * 32 + lrow;
+    for (int p = 0; p < NPP; ++p) {
+      const int r = p * RPP + lrow;
       *(float4_t*)&Ah[r * GP_LD + lc4] = (ti * 64 + r < j.N) ? pre[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
       *(float4_t*)&Bh[r * GP_LD + lc4] = (tk * 64 + r < j.N) ? preb[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < CHK / 16; ++u) {
       const int kofs = u * 16 + 4 * (lane >> 4);
       auto frag = [&](const float* P, int blk16) { return *(const float4_t*)&P[(16 * blk16 + (lane & 15)) * GP_LD + kofs]; };
       if (!gdiag) {
@@ -709,6 +718,9 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     }
     __syncthreads();
   }
+  };
+  if (j.nb <= 1) gram_mm(std::integral_constant<int, GP_NB1>{});
+  else gram_mm(std::integral_constant<int, GP_NB>{});
   DBG(1);
   // D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15
   const int c = lane & 15, rq = lane >> 4;
@@ -765,23 +777,25 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   const __amdgpu_buffer_rsrc_t slab_r = sc1_rsrc(j.slabs, (unsigned)(nriders * 4096 * sizeof(double)));
   const __amdgpu_buffer_rsrc_t linv_r = sc1_rsrc(j.Linv, (unsigned)(j.nb * 4096 * sizeof(double)));
   // thread -> element pairs e, e + 1 with e = 2 (tid + 512 p): row e >> 6, columns e & 63 (even) and the next
-  auto fetch_tile = [&](int t, int nrow4, bool lower, double2_t (&v)[GP_NB][4]) {
+  auto fetch_tile = [&](int t, int nrow4, bool lower, auto& v) {
+    constexpr int NBK = sizeof(v) / sizeof(v[0]);                 // slabs per tile: the first extent of v[NBK][4]
 #pragma unroll
-    for (int b = 0; b < GP_NB; ++b)
+    for (int b = 0; b < NBK; ++b)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int e = 2 * (tid + 512 * p), row = e >> 6, col = e & 63;
         const bool live = row < nrow4 && (!lower || col <= (row | 3));       // (col even, row | 3 odd: both elements alike)
-        v[b][p] = ld_sc1_x2(slab_r, live ? (unsigned)(((t * GP_NB + b) * 4096 + e) * sizeof(double)) : SC1_OOB);
+        v[b][p] = ld_sc1_x2(slab_r, live ? (unsigned)(((t * NBK + b) * 4096 + e) * sizeof(double)) : SC1_OOB);
       }
   };
-  auto reduce_tile = [&](const double2_t (&v)[GP_NB][4], int nrow4, int row_base, bool diag, double2_t (&out)[4]) {
+  auto reduce_tile = [&](const auto& v, int nrow4, int row_base, bool diag, double2_t (&out)[4]) {
+    constexpr int NBK = sizeof(v) / sizeof(v[0]);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int e = 2 * (tid + 512 * p), row = e >> 6, col = e & 63;
       double2_t a = v[0][p];
 #pragma unroll
-      for (int b = 1; b < GP_NB; ++b) a += v[b][p];                          // fixed slab order: bit-repeatable
+      for (int b = 1; b < NBK; ++b) a += v[b][p];                            // fixed slab order: bit-repeatable
       if (diag && row == col) a[0] = (row < nrow4 ? a[0] : 0.0) + diag_term(row_base + row);
       if (diag && row == col + 1) a[1] = (row < nrow4 ? a[1] : 0.0) + diag_term(row_base + row);
       out[p] = a;
@@ -803,7 +817,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   if (j.nb == 1) {
     {
       const int n4 = (j.N + 3) & ~3;
-      double2_t v[GP_NB][4], o[4];
+      double2_t v[GP_NB1][4], o[4];
       fetch_tile(0, n4, true, v);
       reduce_tile(v, n4, 0, true, o);
       park_tile(Ksum, o);
