@@ -253,14 +253,17 @@ struct GramPotrfJob {
 };
 
 constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of a TWO-block system (split over the feature axis)
-constexpr int GP_NB1 = 8;       // ... of a one-block system: the Gram is bound by the f64 matrix pipe (64 cycles per 16 x 16 x 4 step and SIMD:
-                                // 5.6 us on four CUs); eight CUs halve that for 0.8 us more of slab summation (every slab load is in flight at once)
-__host__ __device__ constexpr int gp_nb(int nb) { return nb <= 1 ? GP_NB1 : GP_NB; }
+// A ONE-block system is split by OUTPUT instead: one rider per lower 16 x 16 sub-tile of the 64 x 64 Gram (ten of them), its eight
+// waves each contract an eighth of the features straight from global fragments (no LDS staging) and meet in LDS - the workgroup
+// writes FINISHED elements, so there is one "slab" and no summation by the block that factors (the f64 matrix pipe runs at 64 cycles
+// per 16 x 16 x 4 step and SIMD: a K-split over four riders spent 5.6 us in MFMAs, 1.8 publishing and 3.5 summing four slabs).
+constexpr int GP_SUB1 = 10;
+__host__ __device__ constexpr int gp_nb(int nb) { return nb <= 1 ? 1 : GP_NB; }               // slabs per tile of the system
 constexpr int GP_MAXB = 2;      // largest system the riders take: 128 x 128 (3 lower tiles)
 constexpr int GP_LD = 40;       // floats, k-contiguous NT tile stride (conflict-free b128)
 constexpr int GP_TLD = 66;      // doubles
 
-__host__ __device__ constexpr int gp_riders(int nb) { return gp_nb(nb) * nb * (nb + 1) / 2; }
+__host__ __device__ constexpr int gp_riders(int nb) { return nb <= 1 ? GP_SUB1 : GP_NB * nb * (nb + 1) / 2; }
 
 // Write-through (sc1) stores / L1-bypassing (sc1) loads of hand-off payloads: a relaxed agent-scope atomic of 8 bytes
 // lowers to global_store/load_dwordx2 sc1.  Payload published this way needs NO release fence (buffer_wbl2 writes back
@@ -605,7 +608,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
   const int ht = tid & 255;                                       // thread index within its half
   const int nbk = gp_nb(j.nb);
-  const int tile = blockIdx.x / nbk, blk = blockIdx.x % nbk;      // tile of the system, feature slice
+  const int tile = j.nb <= 1 ? 0 : blockIdx.x / nbk, blk = j.nb <= 1 ? 0 : blockIdx.x % nbk;      // tile of the system, feature slice
   const int ti = tile == 0 ? 0 : 1, tk = tile == 2 ? 1 : 0;       // lower tiles in order (0,0) (1,0) (1,1)
   const int nriders = gp_riders(j.nb);
   // 16 x 16 sub-tiles of this wave: a DIAGONAL tile of the system is only read in its lower triangle (fetch_tile below), so its
@@ -719,8 +722,46 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     __syncthreads();
   }
   };
-  if (j.nb <= 1) gram_mm(std::integral_constant<int, GP_NB1>{});
-  else gram_mm(std::integral_constant<int, GP_NB>{});
+  if (j.nb <= 1) {
+    // ---- one-block system: this rider = lower sub-tile (sa, sb), sb <= sa, in the order (0,0) (1,0) (1,1) (2,0) ...
+    const int bx = (int)blockIdx.x;
+    const int sa = bx >= 6 ? 3 : (bx >= 3 ? 2 : (bx >= 1 ? 1 : 0));
+    const int sb = bx - sa * (sa + 1) / 2;
+    constexpr int FW = D / 8, NS = FW / 16;                          // features per wave, 16-feature steps
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int rowa = 16 * sa + i16, rowb = 16 * sb + i16;
+    const float* pa = j.C + (size_t)(rowa < j.N ? rowa : 0) * D + w * FW + 4 * kq;
+    const float* pb = j.C + (size_t)(rowb < j.N ? rowb : 0) * D + w * FW + 4 * kq;
+    float4_t fa[NS], fb[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      fa[s2] = *(const float4_t*)(pa + 16 * s2);
+      fb[s2] = *(const float4_t*)(pb + 16 * s2);
+    }
+#ifdef UCE_CHAIN_DEBUG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DBG(6);
+#endif
+    const double ma = rowa < j.N ? 1.0 : 0.0, mb = rowb < j.N ? 1.0 : 0.0;   // padding rows contribute zeros
+    double4_t a4 = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a4 = mfma_f64(ma * (double)fa[s2][t], mb * (double)fb[s2][t], a4);
+    DBG(1);
+    // D layout: row = (lane >> 4) + 4 r, col = lane & 15.  The eight partial sub-tiles meet in LDS, summed in wave order
+    double* Pw = (double*)smem_raw;                                   // [8][256]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Pw[w * 256 + (kq + 4 * r) * 16 + i16] = a4[r];
+    __syncthreads();
+    if (tid < 256) {
+      double v = Pw[tid];
+#pragma unroll
+      for (int ww = 1; ww < 8; ++ww) v += Pw[ww * 256 + tid];
+      st_sc1(&j.slabs[(16 * sa + (tid >> 4)) * 64 + 16 * sb + (tid & 15)], v);
+    }
+  } else {
+  gram_mm(std::integral_constant<int, GP_NB>{});
   DBG(1);
   // D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15
   const int c = lane & 15, rq = lane >> 4;
@@ -744,6 +785,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
           st_sc1(&myslab[row * 64 + col], acc[i][r] + P1[row * GP_TLD + col]);
         }
       }
+  }
   }
   // ---- publish the slab, draw a ticket (CDNA guide, Guideline 16 / split-K reduction recipe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -817,7 +859,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   if (j.nb == 1) {
     {
       const int n4 = (j.N + 3) & ~3;
-      double2_t v[GP_NB1][4], o[4];
+      double2_t v[1][4], o[4];
       fetch_tile(0, n4, true, v);
       reduce_tile(v, n4, 0, true, o);
       park_tile(Ksum, o);
