@@ -10,4 +10,4 @@ done
 timeout 300 python bench.py --only edit --workload sdxl_debias36x2 --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
 import json,sys
 p=json.loads(sys.stdin.read()); print('SDXL', p['ms_per_step'], p['ms_per_step_events'])"
-UCE_CHAIN_DEBUG=1 python tools/dbg_resident.py 2>&1 | sed -n 2,12p
+UCE_CHAIN_DEBUG=1 python tools/dbg_resident.py 2>&1 | grep -v None.*None.*None.*None.*None | sed -n 2,9p

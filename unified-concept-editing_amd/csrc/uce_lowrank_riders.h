@@ -787,6 +787,20 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
       }
   }
   }
+  auto diag_term = [&](int row) -> double {
+    const float sv = (row < j.N) ? j.s[row] : 1.f;
+    return (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
+  };
+  // one-block systems: the diagonal terms lambda / s_i this thread will add if it turns out to be the factoring block - a load
+  // and an f64 division, taken off the path between the ticket and the elimination (they overlap the drain of the stores below)
+  double dpre[4] = {0.0, 0.0, 0.0, 0.0};
+  if (j.nb <= 1) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int e = 2 * (tid + 512 * p), row = e >> 6, col = e & 63;
+      if (row == col || row == col + 1) dpre[p] = diag_term(row);
+    }
+  }
   // ---- publish the slab, draw a ticket (CDNA guide, Guideline 16 / split-K reduction recipe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -808,10 +822,6 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     solve_rider<D>(j, smem_raw, (int)my_ticket);
     return;
   }
-  auto diag_term = [&](int row) -> double {
-    const float sv = (row < j.N) ? j.s[row] : 1.f;
-    return (row < j.N) ? ((sv > 0.f) ? (double)j.lamb / (double)sv : __builtin_nan("")) : 1.0;
-  };
   // Last arriver: all 8 waves factor.  The GP_NB slabs of a tile are summed by ALL 512 threads (8 elements each, every
   // load independent and in flight at once, fixed slab order: bit-repeatable).  Only what the factorisation reads is
   // fetched: rows of real concepts (the padding rows are the identity) and, for the diagonal tiles, the 4 x 4 tiles
@@ -838,8 +848,8 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
       double2_t a = v[0][p];
 #pragma unroll
       for (int b = 1; b < NBK; ++b) a += v[b][p];                            // fixed slab order: bit-repeatable
-      if (diag && row == col) a[0] = (row < nrow4 ? a[0] : 0.0) + diag_term(row_base + row);
-      if (diag && row == col + 1) a[1] = (row < nrow4 ? a[1] : 0.0) + diag_term(row_base + row);
+      if (diag && row == col) a[0] = (row < nrow4 ? a[0] : 0.0) + (j.nb <= 1 ? dpre[p] : diag_term(row_base + row));
+      if (diag && row == col + 1) a[1] = (row < nrow4 ? a[1] : 0.0) + (j.nb <= 1 ? dpre[p] : diag_term(row_base + row));
       out[p] = a;
     }
   };
