@@ -212,13 +212,12 @@ __device__ __forceinline__ void project_body_w(const float* __restrict__ W_old, 
 }
 
 // Optional riders of the projection launch (blocks 0..gp_riders(nb)-1): the whole small-system factorisation
-// of the dual form (N <= 128):  K = lambda S^-1 + C C^T  (f64 MFMA over the d features, GP_NB feature slices per
-// 64 x 64 tile of the system x 2 wave quads), then the Cholesky + block inverses by the rider block that finishes
-// its slab LAST.  Riders need nothing from the projection and vice versa, so riding along costs no launch and no
-// event.  The slab hand-off between rider blocks is the split-K reduction of the CDNA guide (G16) in its write-through
-// form: sc1 slab stores -> per-wave vmcnt(0) -> barrier -> one lane draws a relaxed agent-scope ticket; the block
-// drawing the last ticket reads all slabs with sc1 loads (summed in slab order: bit-repeatable) - no release / acquire
-// fence on either side (st_sc1 below).  Correct for any placement of the rider blocks.
+// of the dual form (N <= 128):  K = lambda S^-1 + C C^T  (f64 MFMA over the d features, split by OUTPUT sub-tile: GP_SUB1 / GP_SUB2
+// below), then the Cholesky + block inverses by the rider block that finishes its sub-tiles LAST.  Riders need nothing from the
+// projection and vice versa, so riding along costs no launch and no event.  The hand-off between rider blocks is the write-through
+// form of the CDNA guide's split-K recipe (G16): sc1 stores -> per-wave vmcnt(0) -> barrier -> one lane draws a relaxed agent-scope
+// ticket; the block drawing the last ticket reads the tiles with sc1 loads - no release / acquire fence on either side (st_sc1
+// below).  Correct for any placement of the rider blocks; bit-repeatable (every sum has a fixed order).
 //
 // Hand-off words (h->ticket, all zero between launches - nothing of the protocol lives in the kernel arguments, so a
 // launch can be captured into a hipGraph and replayed):
@@ -231,7 +230,7 @@ struct GramPotrfJob {
   const float* s;       // [N]
   int N;
   float lamb;
-  double* slabs;        // [tiles * GP_NB][64][64] partial Grams
+  double* slabs;        // [tiles][64][64]: the lower tiles (0,0) (1,0) (1,1) of the Gram, finished elements
   unsigned* ticket;     // the three hand-off words
   double* Lmat;         // [n, n], n = 64 * nb (only block (1, 0) is written: L_10 of a two-block system)
   double* Linv;         // [nb][64][64]
@@ -252,18 +251,18 @@ struct GramPotrfJob {
   float* Rsc;           // [d]
 };
 
-constexpr int GP_NB = 4;        // rider blocks per 64x64 tile of a TWO-block system (split over the feature axis)
-// A ONE-block system is split by OUTPUT instead: one rider per lower 16 x 16 sub-tile of the 64 x 64 Gram (ten of them), its eight
-// waves each contract an eighth of the features straight from global fragments (no LDS staging) and meet in LDS - the workgroup
-// writes FINISHED elements, so there is one "slab" and no summation by the block that factors (the f64 matrix pipe runs at 64 cycles
-// per 16 x 16 x 4 step and SIMD: a K-split over four riders spent 5.6 us in MFMAs, 1.8 publishing and 3.5 summing four slabs).
-constexpr int GP_SUB1 = 10;
-__host__ __device__ constexpr int gp_nb(int nb) { return nb <= 1 ? 1 : GP_NB; }               // slabs per tile of the system
+// The Gram is split by OUTPUT (round 6): a rider owns lower 16 x 16 sub-tiles of the system's 64 x 64 tiles, its eight waves each
+// contract an eighth of the features straight from global fragments (no LDS staging) and meet in LDS - the workgroup writes
+// FINISHED elements, so every tile has ONE slab and the block that factors sums nothing (the f64 matrix pipe runs at 64 cycles per
+// 16 x 16 x 4 step and SIMD: the K-split over four riders per tile of rounds 2-5 spent 5.6 us in MFMAs, 1.8 publishing and 3.5
+// summing four slabs; at 50 concepts the chain's first link went from 13.6 to 9.5 us).
+constexpr int GP_SUB1 = 10;     // riders of a one-block system (one sub-tile each)
+constexpr int GP_SUB2 = 2;      // sub-tiles per rider of a two-block system: 10 + 16 + 10 sub-tiles on 18 riders
 constexpr int GP_MAXB = 2;      // largest system the riders take: 128 x 128 (3 lower tiles)
 constexpr int GP_LD = 40;       // floats, k-contiguous NT tile stride (conflict-free b128)
 constexpr int GP_TLD = 66;      // doubles
 
-__host__ __device__ constexpr int gp_riders(int nb) { return nb <= 1 ? GP_SUB1 : GP_NB * nb * (nb + 1) / 2; }
+__host__ __device__ constexpr int gp_riders(int nb) { return nb <= 1 ? GP_SUB1 : 36 / GP_SUB2; }
 
 // Write-through (sc1) stores / L1-bypassing (sc1) loads of hand-off payloads: a relaxed agent-scope atomic of 8 bytes
 // lowers to global_store/load_dwordx2 sc1.  Payload published this way needs NO release fence (buffer_wbl2 writes back
@@ -593,10 +592,7 @@ constexpr size_t GP_F2_SMEM = sizeof(Potrf64Scratch) + 2 * 64 * LD * sizeof(doub
 template <int D>
 __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned char* smem_raw) {
   DBG(0);
-  float* As = (float*)smem_raw;                                   // [2 halves][64][GP_LD]  rows of block ti
-  float* Bs = As + 2 * 64 * GP_LD;                                // [2 halves][64][GP_LD]  rows of block tk
-  constexpr size_t AB_BYTES = (size_t)4 * 64 * GP_LD * sizeof(float);
-  double* P1 = (double*)(smem_raw + AB_BYTES);                    // [64][GP_TLD]
+  constexpr size_t AB_BYTES = (size_t)4 * 64 * GP_LD * sizeof(float);   // (the first 16 KB: the eight waves' partial sub-tiles)
   // the factorisation scratch ALIASES the Gram staging (As, Bs, P1 are dead once the slab is published), so a
   // single-tile rider needs 74 KB
   Potrf64Scratch* sc = (Potrf64Scratch*)smem_raw;
@@ -606,186 +602,68 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = w >> 2, wq = w & 3;
   const int wr = (wq >> 1) * 32, wc = (wq & 1) * 32;
-  const int ht = tid & 255;                                       // thread index within its half
-  const int nbk = gp_nb(j.nb);
-  const int tile = j.nb <= 1 ? 0 : blockIdx.x / nbk, blk = j.nb <= 1 ? 0 : blockIdx.x % nbk;      // tile of the system, feature slice
-  const int ti = tile == 0 ? 0 : 1, tk = tile == 2 ? 1 : 0;       // lower tiles in order (0,0) (1,0) (1,1)
   const int nriders = gp_riders(j.nb);
-  // 16 x 16 sub-tiles of this wave: a DIAGONAL tile of the system is only read in its lower triangle (fetch_tile below), so its
-  // ten lower sub-tiles are shared 3 + 3 + 2 + 2 over the four waves of a half instead of 4 each - the f64 matrix pipe runs at 64
-  // cycles per 16 x 16 x 4 step and SIMD, the Gram is bound by it (5.6 of the chain's first 8 us), a quarter of it was spent on
-  // sub-tiles nobody reads.  An off-diagonal tile (two-block systems) keeps the 2 x 2 quadrant per wave.
-  const bool gdiag = ti == tk;
-  const int wqs = __builtin_amdgcn_readfirstlane(wq);              // (wave-uniform: the sub-tile maps below are scalar branches)
-  int ga[4], gb[4], gn;
-  if (!gdiag) {
-    gn = 4;
-    ga[0] = ga[1] = 2 * (wq >> 1); ga[2] = ga[3] = 2 * (wq >> 1) + 1;
-    gb[0] = gb[2] = 2 * (wq & 1); gb[1] = gb[3] = 2 * (wq & 1) + 1;
-  } else if (wq == 0) { gn = 3; ga[0] = 0; gb[0] = 0; ga[1] = 1; gb[1] = 0; ga[2] = 1; gb[2] = 1; ga[3] = 0; gb[3] = 0; }
-  else if (wq == 1) { gn = 3; ga[0] = 2; gb[0] = 0; ga[1] = 2; gb[1] = 1; ga[2] = 2; gb[2] = 2; ga[3] = 0; gb[3] = 0; }
-  else if (wq == 2) { gn = 2; ga[0] = 3; gb[0] = 0; ga[1] = 3; gb[1] = 1; ga[2] = ga[3] = 0; gb[2] = gb[3] = 0; }
-  else { gn = 2; ga[0] = 3; gb[0] = 2; ga[1] = 3; gb[1] = 3; ga[2] = ga[3] = 0; gb[2] = gb[3] = 0; }
-  double4_t acc[4];
+  // ---- the Gram, split by OUTPUT: the lower 16 x 16 sub-tiles of the system's tiles in the order  K_00 (ten, lower) | K_10 (sixteen) |
+  // K_11 (ten, lower);  a one-block system has one rider per sub-tile, a two-block system two sub-tiles per rider (18 riders).  The
+  // eight waves of a rider each contract an eighth of the features straight from global fragments (lane (i, kq): row 16 s + i,
+  // features 16 step + 4 kq .. + 3 - the same permutation of the contraction index on both operands) and meet in LDS, summed in wave
+  // order: the rider writes FINISHED elements of the tile's one slab.
+  {
+    constexpr int FW = D / 8, NS = FW / 16;                          // features per wave, 16-feature steps
+    const int per = j.nb <= 1 ? 1 : GP_SUB2;
+    const int i16 = lane & 15, kq = lane >> 4;
+    double* Pw = (double*)smem_raw;                                   // [8][256]
+    auto lower = [](int q, int& sa, int& sb) { sa = q >= 6 ? 3 : (q >= 3 ? 2 : (q >= 1 ? 1 : 0)); sb = q - sa * (sa + 1) / 2; };
+    float4_t fa[GP_SUB2][NS], fb[GP_SUB2][NS];
+    int tl[GP_SUB2], sas[GP_SUB2], sbs[GP_SUB2];
+    double mas[GP_SUB2], mbs[GP_SUB2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  float* Ah = As + half * 64 * GP_LD;
-  float* Bh = Bs + half * 64 * GP_LD;
-  auto gram_mm = [&](auto nbk_c) __attribute__((always_inline)) {
-  constexpr int NBK = decltype(nbk_c)::value;
-  constexpr int KS = D / (2 * NBK);                               // features per (block, half) slice
-  constexpr int CHK = (KS % 32 == 0) ? 32 : 16;                   // features per staged chunk (d = 768 on eight riders: 48 = 3 x 16)
-  constexpr int NCH = KS / CHK;
-  constexpr int TPRW = CHK / 4, RPP = 256 / TPRW, NPP = 64 / RPP; // threads per row, rows per pass, passes of a half's 256 threads
-  const int lrow = ht / TPRW, lc4 = (ht % TPRW) * 4;
-  const int kbeg = (blk * 2 + half) * KS;
-  // the whole slice is fetched up front (one memory round trip instead of one per chunk)
-  float4_t pre[NCH][NPP], preb[NCH][NPP];
+    for (int u = 0; u < GP_SUB2; ++u) {
+      const int idx = (int)blockIdx.x * per + (u < per ? u : 0);
+      int t, sa, sb;
+      if (idx < 10) { t = 0; lower(idx, sa, sb); }
+      else if (idx < 26) { t = 1; sa = (idx - 10) >> 2; sb = (idx - 10) & 3; }
+      else { t = 2; lower(idx - 26, sa, sb); }
+      tl[u] = t; sas[u] = sa; sbs[u] = sb;
+      const int rowa = (t == 0 ? 0 : 64) + 16 * sa + i16, rowb = (t == 2 ? 64 : 0) + 16 * sb + i16;
+      mas[u] = rowa < j.N ? 1.0 : 0.0;                                // padding rows contribute zeros
+      mbs[u] = rowb < j.N ? 1.0 : 0.0;
+      const float* pa = j.C + (size_t)(rowa < j.N ? rowa : 0) * D + w * FW + 4 * kq;
+      const float* pb = j.C + (size_t)(rowb < j.N ? rowb : 0) * D + w * FW + 4 * kq;
+      if (u < per) {
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-    for (int p = 0; p < NPP; ++p) {
-      const int ra = ti * 64 + p * RPP + lrow, rb = tk * 64 + p * RPP + lrow;
-      pre[ch][p] = *(const float4_t*)(j.C + (size_t)(ra < j.N ? ra : j.N - 1) * D + kbeg + ch * CHK + lc4);
-      preb[ch][p] = *(const float4_t*)(j.C + (size_t)(rb < j.N ? rb : j.N - 1) * D + kbeg + ch * CHK + lc4);
-    }
-#ifdef UCE_CHAIN_DEBUG
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  DBG(6);
-#endif
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-#ifdef UCE_CHAIN_DEBUG
-    if (ch == 1) DBG(7);
-#endif
-#pragma unroll
-    for (int p = 0; p < NPP; ++p) {
-      const int r = p * RPP + lrow;
-      *(float4_t*)&Ah[r * GP_LD + lc4] = (ti * 64 + r < j.N) ? pre[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
-      *(float4_t*)&Bh[r * GP_LD + lc4] = (tk * 64 + r < j.N) ? preb[ch][p] : (float4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < CHK / 16; ++u) {
-      const int kofs = u * 16 + 4 * (lane >> 4);
-      auto frag = [&](const float* P, int blk16) { return *(const float4_t*)&P[(16 * blk16 + (lane & 15)) * GP_LD + kofs]; };
-      if (!gdiag) {
-        const float4_t fa0 = frag(Ah, ga[0]), fa1 = frag(Ah, ga[2]), fb0 = frag(Bh, gb[0]), fb1 = frag(Bh, gb[1]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double a0 = (double)fa0[t], a1 = (double)fa1[t], b0 = (double)fb0[t], b1 = (double)fb1[t];
-          acc[0] = mfma_f64(a0, b0, acc[0]);
-          acc[1] = mfma_f64(a0, b1, acc[1]);
-          acc[2] = mfma_f64(a1, b0, acc[2]);
-          acc[3] = mfma_f64(a1, b1, acc[3]);
-        }
-      } else {
-        // diagonal tile: both operands are rows of the SAME block (Ah == Bh row for row), so a wave converts each 16-row fragment
-        // once (v_cvt_f64_f32 shares the double-precision pipe with the MFMA) - 2 or 3 fragments for its 2 or 3 sub-tiles
-        if (wqs == 0) {
-          const float4_t x0 = frag(Ah, 0), x1 = frag(Ah, 1);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const double d0 = (double)x0[t], d1 = (double)x1[t];
-            acc[0] = mfma_f64(d0, d0, acc[0]);
-            acc[1] = mfma_f64(d1, d0, acc[1]);
-            acc[2] = mfma_f64(d1, d1, acc[2]);
-          }
-        } else if (wqs == 1) {
-          const float4_t x0 = frag(Ah, 0), x1 = frag(Ah, 1), x2 = frag(Ah, 2);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const double d0 = (double)x0[t], d1 = (double)x1[t], d2 = (double)x2[t];
-            acc[0] = mfma_f64(d2, d0, acc[0]);
-            acc[1] = mfma_f64(d2, d1, acc[1]);
-            acc[2] = mfma_f64(d2, d2, acc[2]);
-          }
-        } else if (wqs == 2) {
-          const float4_t x0 = frag(Ah, 0), x1 = frag(Ah, 1), x3 = frag(Ah, 3);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const double d0 = (double)x0[t], d1 = (double)x1[t], d3 = (double)x3[t];
-            acc[0] = mfma_f64(d3, d0, acc[0]);
-            acc[1] = mfma_f64(d3, d1, acc[1]);
-          }
-        } else {
-          const float4_t x2 = frag(Ah, 2), x3 = frag(Ah, 3);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const double d2 = (double)x2[t], d3 = (double)x3[t];
-            acc[0] = mfma_f64(d3, d2, acc[0]);
-            acc[1] = mfma_f64(d3, d3, acc[1]);
-          }
+        for (int s2 = 0; s2 < NS; ++s2) {
+          fa[u][s2] = *(const float4_t*)(pa + 16 * s2);
+          fb[u][s2] = *(const float4_t*)(pb + 16 * s2);
         }
       }
-    }
-    __syncthreads();
-  }
-  };
-  if (j.nb <= 1) {
-    // ---- one-block system: this rider = lower sub-tile (sa, sb), sb <= sa, in the order (0,0) (1,0) (1,1) (2,0) ...
-    const int bx = (int)blockIdx.x;
-    const int sa = bx >= 6 ? 3 : (bx >= 3 ? 2 : (bx >= 1 ? 1 : 0));
-    const int sb = bx - sa * (sa + 1) / 2;
-    constexpr int FW = D / 8, NS = FW / 16;                          // features per wave, 16-feature steps
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int rowa = 16 * sa + i16, rowb = 16 * sb + i16;
-    const float* pa = j.C + (size_t)(rowa < j.N ? rowa : 0) * D + w * FW + 4 * kq;
-    const float* pb = j.C + (size_t)(rowb < j.N ? rowb : 0) * D + w * FW + 4 * kq;
-    float4_t fa[NS], fb[NS];
-#pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) {
-      fa[s2] = *(const float4_t*)(pa + 16 * s2);
-      fb[s2] = *(const float4_t*)(pb + 16 * s2);
     }
 #ifdef UCE_CHAIN_DEBUG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DBG(6);
 #endif
-    const double ma = rowa < j.N ? 1.0 : 0.0, mb = rowb < j.N ? 1.0 : 0.0;   // padding rows contribute zeros
-    double4_t a4 = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2)
+    for (int u = 0; u < GP_SUB2; ++u) {
+      if (u < per) {
+        double4_t a4 = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a4 = mfma_f64(ma * (double)fa[s2][t], mb * (double)fb[s2][t], a4);
-    DBG(1);
-    // D layout: row = (lane >> 4) + 4 r, col = lane & 15.  The eight partial sub-tiles meet in LDS, summed in wave order
-    double* Pw = (double*)smem_raw;                                   // [8][256]
+        for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Pw[w * 256 + (kq + 4 * r) * 16 + i16] = a4[r];
-    __syncthreads();
-    if (tid < 256) {
-      double v = Pw[tid];
+          for (int t = 0; t < 4; ++t) a4 = mfma_f64(mas[u] * (double)fa[u][s2][t], mbs[u] * (double)fb[u][s2][t], a4);
+        // D layout: row = (lane >> 4) + 4 r, col = lane & 15
+        if (u) __syncthreads();                                       // (the previous sub-tile's partials have been summed)
 #pragma unroll
-      for (int ww = 1; ww < 8; ++ww) v += Pw[ww * 256 + tid];
-      st_sc1(&j.slabs[(16 * sa + (tid >> 4)) * 64 + 16 * sb + (tid & 15)], v);
-    }
-  } else {
-  gram_mm(std::integral_constant<int, GP_NB>{});
-  DBG(1);
-  // D layout of the f64 MFMA: row = (lane>>4) + 4r, col = lane & 15
-  const int c = lane & 15, rq = lane >> 4;
-  if (half == 1) {
+        for (int r = 0; r < 4; ++r) Pw[w * 256 + (kq + 4 * r) * 16 + i16] = a4[r];
+        __syncthreads();
+        if (tid < 256) {
+          double v = Pw[tid];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < gn) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P1[(16 * ga[i] + rq + 4 * r) * GP_TLD + 16 * gb[i] + c] = acc[i][r];
-      }
-  }
-  __syncthreads();
-  double* myslab = j.slabs + (size_t)blockIdx.x * 64 * 64;
-  if (half == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < gn) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * ga[i] + rq + 4 * r, col = 16 * gb[i] + c;
-          st_sc1(&myslab[row * 64 + col], acc[i][r] + P1[row * GP_TLD + col]);
+          for (int ww = 1; ww < 8; ++ww) v += Pw[ww * 256 + tid];
+          st_sc1(&j.slabs[(size_t)tl[u] * 4096 + (16 * sas[u] + (tid >> 4)) * 64 + 16 * sbs[u] + (tid & 15)], v);
         }
       }
-  }
+    }
+    DBG(1);
   }
   auto diag_term = [&](int row) -> double {
     const float sv = (row < j.N) ? j.s[row] : 1.f;
@@ -822,7 +700,7 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
     solve_rider<D>(j, smem_raw, (int)my_ticket);
     return;
   }
-  // Last arriver: all 8 waves factor.  The GP_NB slabs of a tile are summed by ALL 512 threads (8 elements each, every
+  // Last arriver: all 8 waves factor.  A tile's slab is fetched by ALL 512 threads (8 elements each, every
   // load independent and in flight at once, fixed slab order: bit-repeatable).  Only what the factorisation reads is
   // fetched: rows of real concepts (the padding rows are the identity) and, for the diagonal tiles, the 4 x 4 tiles
   // of the lower triangle.
@@ -898,9 +776,9 @@ __device__ __forceinline__ void gram_potrf_rider(const GramPotrfJob& j, unsigned
   // K_00 is reduced and factored while the slab loads of K_10 land (64 VGPRs of them ride through the elimination), the
   // loads of K_11 are issued behind the factor and land under the L_10 product - one CU sustains only ~10 KB/us of
   // L1-bypassing loads: summed before the factor, as the first form of this block did, they were 6 us of the chain
-  double2_t vb[GP_NB][4], vc[GP_NB][4];
+  double2_t vb[1][4], vc[1][4];
   {
-    double2_t va[GP_NB][4], o[4];
+    double2_t va[1][4], o[4];
     fetch_tile(0, 64, true, va);                                  // K_00
     fetch_tile(1, n4b, false, vb);                                // K_10: lands during the first factor (64 VGPRs pinned)
     reduce_tile(va, 64, 0, true, o);
