@@ -916,6 +916,13 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
         if with_torch:
             sp = lambda t: t.view(B, L, 8, dh).transpose(1, 2)  # noqa: E731
             ent["torch_sdpa_us"] = round(time_kernel(lambda: F.scaled_dot_product_attention(sp(q), sp(k), sp(v)), iters) * 1e3, 1)
+            # peaked logits (q, k x 5: scores 25x wider, the running maximum keeps moving and the rescale branch of the lazy
+            # maximum is taken far more often than on exchangeable scores) - the same kernel, the other end of its data dependence
+            qp, kp = (q.float() * 5).bfloat16(), (k.float() * 5).bfloat16()
+            ent["peaked_logits_us"] = round(time_kernel(lambda: H.sattn(qp, kp, v, 8, out=o), iters) * 1e3, 1)
+            ent["peaked_logits_torch_sdpa_us"] = round(
+                time_kernel(lambda: F.scaled_dot_product_attention(sp(qp), sp(kp), sp(v)), iters) * 1e3, 1)
+            del qp, kp
         ent["unet_dispatch"] = "uce_sattn_packed_fwd"      # every attn1 layer, whatever its length (sd/unet.py: no library attention)
         t = traffic.get(f"B{B}_L{L}_dh{dh}")
         if isinstance(t, dict):
