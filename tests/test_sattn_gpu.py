@@ -73,6 +73,48 @@ def test_sattn_peaked_logits_and_running_max(H):
     assert O.rel_fro(o.double().cpu(), ref.cpu()) < TOL_BF16
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sattn_two_peaks_far_above_the_rest(variant, dtype):
+    """One key scores `base`, a second `base + J`, every other key -64 (all in powers of two): the spread exceeds the f32 exponent
+    range, so a running maximum that misses a key of its half tile overflows.  Key 4 sits in the half of the lane pair whose maximum
+    hipcc 7.2.0 dropped from k_sattn_h (round 6: inf / NaN rows on q, k x 5; see lane_pair_max); the second peak comes early (same
+    tile) or late (key tile 51).  Every kernel form, forced."""
+    import os
+    from uce_amd import edit as E
+    old = os.environ.get("UCE_SATTN_QT")
+    os.environ["UCE_SATTN_QT"] = variant
+    try:
+        Hv = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_SATTN_QT"]
+        else:
+            os.environ["UCE_SATTN_QT"] = old
+    B, H_, L, dh = 1, 2, 4096, 40
+    C = H_ * dh
+    c = dh ** -0.5 * 1.4426950408889634
+    try:
+        for base, J, second in ((100.0, 4.0, 40), (0.0, 100.0, 3325), (60.0, 70.0, 3325), (70.0, 4.0, 40)):
+            if dtype == torch.float16 and base + J > 110:
+                continue                                     # the key itself would leave f16's range
+            g = torch.Generator().manual_seed(3)
+            q, k = torch.zeros(B, L, C), torch.zeros(B, L, C)
+            v = torch.randn(B, L, C, generator=g)
+            q[..., 0::dh] = 16.0
+            k[:, :, 0::dh] = -64.0 / (16 * c)
+            k[:, 4, 0::dh] = base / (16 * c)
+            k[:, second, 0::dh] = (base + J) / (16 * c)
+            q, k, v = q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda()
+            o = Hv.sattn(q, k, v, H_)
+            assert torch.isfinite(o.float()).all(), (base, J, second)
+            ref = _ref_gpu(q, k, v, H_)
+            assert O.rel_fro(o.double().cpu(), ref.cpu()) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16), (base, J, second)
+    finally:
+        torch.cuda.synchronize()
+        Hv.close()
+
+
 def test_sattn_matches_xattn_on_short_contexts(H):
     """Same problem through both kernels (Lk = 77 fits the cross-attention kernel)."""
     g = torch.Generator().manual_seed(5)

@@ -49,6 +49,18 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 
 constexpr int KT = 64;            // keys per tile
 
+// max over the lane pair (l, l ^ 32) with one v_permlane32_swap - as inline assembly: hipcc 7.2.0 lowers
+// __builtin_amdgcn_permlane32_swap with BOTH results in the first operand's register (tools/ubench/permlane32_swap_builtin.hip), so
+// the half of the exchange that carries the partner's value to lanes 0-31 is lost and `max(sw[0], sw[1])` is the maximum over the
+// LOWER lane's 16 keys for both lanes of a pair.  That is still one reference point per query, so the softmax stays right until one
+// of the other 16 keys exceeds it by 2^128 - rounds 3-5 shipped it; bench.py's peaked-logit case (q, k x 5) found it: inf / NaN
+// rows.  s_nop 1: the wait states the compiler itself puts between a VALU write of an operand and the swap.
+__device__ __forceinline__ float lane_pair_max(float x) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
 // (query tile, head, batch) of a workgroup.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
 // its own L2: with the natural order the query tiles of one (batch, head) land on all 8 XCDs and every XCD streams every
 // K / V^T from HBM (PMC: 2.1 GB per launch at L = 4096, B = 32 for 0.34 GB of Q + K + V + O).  Remapped, the workgroups
@@ -833,8 +845,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
             mb = fmaxf(mb, sc[i][8 + r]);
           }
           const float mab = fmaxf(ma, mb);
-          const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mab), __builtin_bit_cast(unsigned, mab), false, false);
-          mt[i] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+          mt[i] = lane_pair_max(mab);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
