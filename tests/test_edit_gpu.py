@@ -759,3 +759,31 @@ def test_batched_embeddings_on_gpu_match_the_reference_call_pattern():
     for k in one:
         assert one[k].dtype == torch.float32 and one[k].shape == (768,)
         assert float((one[k] - bat[k]).norm() / one[k].norm()) < 1e-5, k
+
+
+@pytest.mark.parametrize("rows_scale,d", [(1.0, 768), (0.013, 768), (0.05, 1000)])
+def test_artifact_streamed_from_the_device_has_the_bytes_of_save_file(rows_scale, d, tmp_path, monkeypatch):
+    """save_uce_state streams the slab through two pinned buffers under the file writes (edit._stream_to_file): the file must hold
+    exactly what safetensors' own save_file writes for the same tensors - at SD-1.4's size (ten chunks), at a slab smaller than one
+    chunk, and with a chunk size that does not divide the slab."""
+    from safetensors.torch import load_file, save_file
+    from uce_amd import edit as E
+    table = [(n, max(8, int(o * rows_scale) // 8 * 8)) for n, o in O.sd14_module_table()]
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(sum(o for _, o in table), d, generator=g).cuda()
+    offs = np.cumsum([0] + [o for _, o in table])[:-1]
+    slab = E.WeightSlab([n for n, _ in table], [int(x) for x in offs], [o for _, o in table], data)
+    if d == 1000:
+        monkeypatch.setattr(E, "SAVE_CHUNK_BYTES", 1_000_003 // 4 * 4)
+        E._save_pinned.clear()
+    path = E.save_uce_state(slab, str(tmp_path), "a")
+    E._save_pinned.clear()
+    host = {n + ".weight": data[o:o + r].cpu() for n, o, r in zip(slab.names, slab.offsets, slab.rows)}
+    save_file(host, str(tmp_path / "b.safetensors"))
+    a, b = load_file(path), load_file(str(tmp_path / "b.safetensors"))
+    assert list(a) == list(b) or sorted(a) == sorted(b)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    raw = open(path, "rb").read()
+    n = int.from_bytes(raw[:8], "little")
+    assert raw[8 + n:] == bytes(memoryview(data.cpu().numpy()).cast("B"))
