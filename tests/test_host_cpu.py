@@ -536,7 +536,7 @@ def test_prefix_encoding_gives_the_states_of_the_full_causal_forward():
     pipe = sdp.load_pipeline("tiny-sd-test", torch.float32, "cpu", synthetic=True, vae=False)
     seen = []
     real = pipe.encode_prompt_prefix
-    pipe.encode_prompt_prefix = lambda prompts, device, n_pos: (seen.append(n_pos), real(prompts, device, n_pos))[1]
+    pipe.encode_prompt_prefix = lambda prompts, device, n_pos, input_ids=None: (seen.append(n_pos), real(prompts, device, n_pos, input_ids))[1]
     prompts = ["Van Gogh", "", "art", "a painting by Picasso"]
     one = E.last_token_embeddings(pipe, prompts, "cpu")                       # per string: the reference's full-length calls
     bat = E.last_token_embeddings(pipe, prompts, "cpu", batch_size=4)

@@ -643,8 +643,8 @@ def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[
     if batch_size and batch_size > 1 and len(todo) > 1:
         prefix_ok = hasattr(pipe, "encode_prompt_prefix")
         T = pipe.tokenizer.model_max_length
-        mask_all = pipe.tokenizer(todo, padding="max_length", max_length=T, truncation=True, return_tensors="pt")["attention_mask"]
-        idx_all = mask_all.sum(dim=1) - 2
+        tok_all = pipe.tokenizer(todo, padding="max_length", max_length=T, truncation=True, return_tensors="pt")     # once: the ids
+        idx_all = tok_all["attention_mask"].sum(dim=1) - 2                                                          # go down with it
         i = 0
         while i < len(todo):
             B = batch_size
@@ -660,7 +660,8 @@ def last_token_embeddings(pipe, prompts: Sequence[str], device, cache: Optional[
             if prefix_ok and int(idx.min()) >= 0:
                 # the build's own pipeline: the causal encoder on positions 0 .. max(idx) only (a concept name ends at position
                 # 2-8 of 77; the states of a prefix do not depend on what follows it)
-                t_emb = pipe.encode_prompt_prefix(chunk, device, int(idx.max()) + 1)    # [B, max(idx) + 1, d]
+                t_emb = pipe.encode_prompt_prefix(chunk, device, int(idx.max()) + 1,
+                                                  input_ids=tok_all["input_ids"][i - len(chunk):i])     # [B, max(idx) + 1, d]
             else:
                 t_emb = pipe.encode_prompt(prompt=chunk, device=device, num_images_per_prompt=1,
                                            do_classifier_free_guidance=False)[0]        # [B, 77, d]
