@@ -588,6 +588,25 @@ def test_resident_edit_on_changing_inputs_matches_fp64_and_the_two_launch_form()
         H0.close()
 
 
+def test_resident_edit_at_every_sub_tile_boundary_of_the_system():
+    """The Gram of the one-launch edit is built by one rider per lower 16 x 16 sub-tile (two per rider for two-block systems), the D / R
+    fragments in tiles of 16 concepts: system sizes on both sides of every multiple of 16 up to 128, erase-only and mixed, against fp64."""
+    d, rows_ = 768, 1136
+    H1 = _handle_with("UCE_EDIT_RESIDENT", "1")
+    try:
+        W = O.linear_default_weight(rows_, d, np.random.Generator(np.random.PCG64(77)))
+        Wd = _dev(W)
+        for N in (15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 111, 112, 113, 127, 128):
+            for N_e in (N, max(1, N // 3)):
+                C, G, s = _synthetic(N, N_e, d, seed=1000 + N)
+                _, _, DTe = _exact(C, G, s, 0.5)
+                want = W.astype(np.float64) + W.astype(np.float64) @ DTe.T
+                a = H1.edit(_dev(C), _dev(G), _dev(s), 0.5, Wd, check=True)
+                assert O.rel_fro(a.cpu(), want) < EPS_BUILD, (N, N_e)
+    finally:
+        H1.close()
+
+
 @pytest.mark.parametrize("N_e,N_p,d,rows_", [(400, 300, 768, 3000), (300, 20, 768, 700), (500, 100, 1024, 1500)])
 def test_dual_edit_beyond_256_edit_concepts(H, N_e, N_p, d, rows_):
     """N < d with more than 256 edit concepts: dual system -> Cholesky (the persistent launch, carrying the f16 split of
