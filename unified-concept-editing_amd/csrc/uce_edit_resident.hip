@@ -45,8 +45,15 @@ __host__ __device__ constexpr int rs_nstage(int nct) { return 3 * nct; }       /
 #ifndef RS_ABL
 #define RS_ABL 0          // measurement builds only: 1 = phase B without its stores, 2 = without its MFMAs
 #endif
-#ifndef RS_ST_AUX
-#define RS_ST_AUX 0       // plain stores: phase B 14.5 us against 16-19 with the nt hint (profiles/r06/resident/ablation_stores_mfma_nt.log)
+// Cache policy of the W_new stores.  The nt hint costs 2-5 us of phase B (ablation_stores_mfma_nt.log).  Plain stores leave up to
+// 8 x 4 MB of the 76.7 MB dirty in the L2s, written back when the kernel ends - behind everything else; write-through (sc1) stores
+// take that out of the tail: whole step at up to 64 concepts 47.4-48.3 -> 45.8-46.4 us same box, three alternating runs
+// (profiles/r06/resident/ab_store_policy.log).  At 65-128 concepts the stores are spread over a phase B twice as long and plain
+// stores are the faster by ~1 us.  -DRS_ST_AUX=n forces one policy (measurement builds).
+#ifdef RS_ST_AUX
+template <int NCT> constexpr int rs_st_aux() { return RS_ST_AUX; }
+#else
+template <int NCT> constexpr int rs_st_aux() { return NCT <= 4 ? 16 : 0; }
 #endif
 // Cache policy of the fragment loads: sc1 (past the L1 and this XCD's L2), like every other consumer of a payload another workgroup of
 // the SAME launch published write-through (uce_lowrank_riders.h: st_sc1).  A plain load measured the same (the producer wave hides
@@ -383,7 +390,7 @@ __device__ __forceinline__ void rs_main(const float* __restrict__ W_old, float* 
 #if RS_ABL == 1
         if (o[0] == 12345.678f)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), orr, vo, 64 * t, RS_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), orr, vo, 64 * t, rs_st_aux<NCT>());
       }
     }
     // (the stores stay in flight: nothing in this loop waits on the vector-memory counter)
