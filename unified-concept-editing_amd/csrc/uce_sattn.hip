@@ -55,10 +55,22 @@ constexpr int KT = 64;            // keys per tile
 // LOWER lane's 16 keys for both lanes of a pair.  That is still one reference point per query, so the softmax stays right until one
 // of the other 16 keys exceeds it by 2^128 - rounds 3-5 shipped it; bench.py's peaked-logit case (q, k x 5) found it: inf / NaN
 // rows.  s_nop 1: the wait states the compiler itself puts between a VALU write of an operand and the swap.
+// v_max3_f32 / v_max_f32 as issued: fmaxf() canonicalises operands the compiler cannot prove quiet (every MFMA result) - a
+// `v_max_f32 x, x, x` per input, a third of the running-maximum instructions of a key tile.  The scores are never signalling NaNs.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float lane_pair_max(float x) {
   unsigned a = __builtin_bit_cast(unsigned, x), b = a;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+  return vmax2(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
 
 // (query tile, head, batch) of a workgroup.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
@@ -672,26 +684,37 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
   const unsigned short* vbase = VTI ? Vt + (size_t)b * Lk * ld + (size_t)h * dh : Vt + ((size_t)b * H + h) * DVP * LkP;
   uint4_t rk[NKL], rv[NVL];
-  auto g_load_k = [&](int t) {
-    const int key0 = t * KT;
+  // K (and the inline V) tile by BUFFER loads: the thread's chunk (key, dim) of a tile is a fixed byte offset, the tile's first key
+  // row moves the descriptor's base (scalar arithmetic), keys >= Lk fall off the end of its range and chunks of dims >= dh carry an
+  // out-of-range offset - both come back as zeros.  (As plain global loads the same tile took ~50 vector instructions of address
+  // work, zero fills and 12 exec-mask branches per wave and key tile - a tenth of the loop's VALU issue.)
+  unsigned kv_off[NKL];
 #pragma unroll
-    for (int i = 0; i < NKL; ++i) {
-      const int e = tid + 256 * i;
-      const int key = e / KCH, dim = (e - key * KCH) * 8;
-      rk[i] = (uint4_t){0u, 0u, 0u, 0u};
-      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
-    }
+  for (int i = 0; i < NKL; ++i) {
+    const int e = tid + 256 * i;
+    const int key = e / KCH, dim = (e - key * KCH) * 8;
+    kv_off[i] = (e < KT * KCH && dim < dh) ? (unsigned)(((long)key * ld + dim) * 2) : 0x80000000u;
+  }
+  auto tile_rsrc = [&](const unsigned short* base, int t) {
+    const long left = ((long)(Lk - t * KT - 1) * ld + dh) * 2;         // bytes up to the end of the last key's head slice
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)t * KT * ld), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL),
+                                             0x00020000);
+  };
+  auto g_load_k = [&](int t) {
+    const __amdgpu_buffer_rsrc_t r = tile_rsrc(kbase, t);
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) rk[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(r, kv_off[i], 0, 0));
   };
   auto g_load_v = [&](int t) {
-    const int key0 = t * KT;
+    if constexpr (VTI) {
+      const __amdgpu_buffer_rsrc_t r = tile_rsrc(vbase, t);
 #pragma unroll
-    for (int i = 0; i < NVL; ++i) {
-      const int e = tid + 256 * i;
-      if constexpr (VTI) {
-        const int key = e / KCH, dim = (e - key * KCH) * 8;
-        rv[i] = (uint4_t){0u, 0u, 0u, 0u};
-        if (e < KT * KCH && key0 + key < Lk && dim < dh) rv[i] = *(const uint4_t*)(vbase + (size_t)(key0 + key) * ld + dim);
-      } else {
+      for (int i = 0; i < NVL; ++i) rv[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(r, kv_off[i], 0, 0));
+    } else {
+      const int key0 = t * KT;
+#pragma unroll
+      for (int i = 0; i < NVL; ++i) {
+        const int e = tid + 256 * i;
         const int dv = e / VCH, kc = (e - dv * VCH) * 8;
         if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
       }
@@ -838,14 +861,14 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
         const int nt = i >> 2, s2 = (i >> 1) & 1, x = i & 1;
         oacc[x][nt] = mfma32<F16>(vf[nt][s2], pf[x][s2], oacc[x][nt]);
         if (i < 2) {                            // the tile maximum of query tile i (both key halves of the lane pair)
-          float ma = sc[i][0], mb = sc[i][8];
+          float ma = vmax3(sc[i][0], sc[i][1], sc[i][2]), mb = vmax3(sc[i][8], sc[i][9], sc[i][10]);
 #pragma unroll
-          for (int r = 1; r < 8; ++r) {
-            ma = fmaxf(ma, sc[i][r]);
-            mb = fmaxf(mb, sc[i][8 + r]);
+          for (int r = 3; r < 7; r += 2) {
+            ma = vmax3(ma, sc[i][r], sc[i][r + 1]);
+            mb = vmax3(mb, sc[i][8 + r], sc[i][9 + r]);
           }
-          const float mab = fmaxf(ma, mb);
-          mt[i] = lane_pair_max(mab);
+          ma = vmax3(ma, sc[i][7], sc[i][15]);
+          mt[i] = lane_pair_max(vmax2(ma, mb));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
