@@ -62,6 +62,7 @@ __host__ __device__ inline GnMap gn_map(int C) {
 // "h + time_emb_proj(...)[:, :, None, None]" and the bias of the convolution that produced x, folded in).
 // `x2` (optional): the channels [C1, C) of every pixel come from a second tensor x2 [N, HW, C - C1] - the skip connection of an
 // up block, whose torch.cat([x, skip], dim=1) is then never written (C1 % 8 == 0; x2 == nullptr: C1 == C).
+// (non-temporal loads HERE were measured and lose 5-15 %: the last-level cache keeps the tail of the tensor for the apply pass)
 template <bool F16>
 __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int C1,
                                                   const unsigned short* __restrict__ addend,
@@ -163,7 +164,12 @@ __global__ __launch_bounds__(256) void k_gn_stats(const unsigned short* __restri
   }
 }
 
-template <bool F16>
+// NTM: cache policy of the pass over the activation - 0 plain; 1 non-temporal stores; 2 non-temporal loads as well.  An activation far
+// larger than the caches is read once and written once here: the hints take the normalised tensor's lines out of the way of the
+// loads (N = 256: 64 x 64 x 320 432 -> 378 us for statistics + apply, 16 x 16 x 2560 226 -> 172; profiles/r06/gn_nontemporal_ab.log);
+// a tensor the 256 MB last-level cache can hold keeps plain loads (the statistics pass has just brought it in) and, below 100 MB,
+// plain stores (the next kernel reads it back).
+template <bool F16, int NTM = 0>
 __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int C1,
                                                   const unsigned short* __restrict__ addend,
                                                   const unsigned short* __restrict__ gamma,
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
   const GnMap mp = gn_map(C);
   const int tpr = mp.active / mp.RPI;
   const int tid = threadIdx.x;
-  const int n = blockIdx.y, ch = blockIdx.x;
+  const int n = blockIdx.y, ch = blockIdx.x;      // (walking the tensor backwards - the tail the statistics pass read last - measured the same)
   const int cpg = C / G;
   // the partials of this sample, folded by all 256 threads: thread (sub, g) sums chunks sub, sub + nsub, ... of group g,
   // then one thread per group adds the nsub sums - a fixed order (bit-repeatable), 8 dependent steps instead of 64
@@ -243,7 +249,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
     for (int j = 0; j < MAXO; ++j) {
       const int oc = oc0 + j * tpr;
       v[j] = (uint4_t){0u, 0u, 0u, 0u};
-      if (j < mp.NO && oc < mp.OC) v[j] = *(const uint4_t*)(src[j] + (size_t)p * pst[j]);
+      if (j < mp.NO && oc < mp.OC) {
+        if constexpr (NTM >= 2) v[j] = __builtin_nontemporal_load((const uint4_t*)(src[j] + (size_t)p * pst[j]));
+        else v[j] = *(const uint4_t*)(src[j] + (size_t)p * pst[j]);
+      }
     }
   };
   auto put = [&](int p, const uint4_t (&v)[MAXO]) {
@@ -260,7 +269,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
           f[i] = w;
         }
         const uint4_t o = {pack2<F16>(f[0], f[1]), pack2<F16>(f[2], f[3]), pack2<F16>(f[4], f[5]), pack2<F16>(f[6], f[7])};
-        *(uint4_t*)(yb + (size_t)p * C + oc * 8) = o;
+        if constexpr (NTM >= 1) __builtin_nontemporal_store(o, (uint4_t*)(yb + (size_t)p * C + oc * 8));
+        else *(uint4_t*)(yb + (size_t)p * C + oc * 8) = o;
       }
     }
   };
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short* __restri
 //   departs last re-arms both - nothing of the protocol is in the kernel arguments, so the launch can be captured and replayed).
 // Hand-off: write-through (sc1) stores -> vmcnt(0) -> barrier -> relaxed agent-scope ticket; poll -> barrier -> sc1 loads
 // (uce_lowrank_riders.h has the reasoning).
+constexpr double GN_NT_STORE_BYTES = 100e6, GN_NT_LOAD_BYTES = 256e6;   // k_gn_apply's cache policy by activation size
 constexpr int GNF_MAX_WG = 1024;
 constexpr int GNF_MAX_N = 1024;
 constexpr unsigned GNF_SPIN_MAX = 1u << 24;
@@ -550,19 +561,23 @@ static int groupnorm_launch(uce_handle_t h, const void* x, const void* x2, int C
       return UCE_OK;
     }
   }
+  // cache policy of the apply pass by the size of the activation (see k_gn_apply)
+  const double act_bytes = 2.0 * (double)N * HW * C;
+  const int ntm = act_bytes >= GN_NT_LOAD_BYTES ? 2 : (act_bytes >= GN_NT_STORE_BYTES ? 1 : 0);
+#define UCE_GNA(F16V, NTV)                                                                                                          \
+  hipLaunchKernelGGL((k_gn_apply<F16V, NTV>), grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)x2, C1,           \
+                     (const unsigned short*)addend, (const unsigned short*)gamma, (const unsigned short*)beta, (const float*)ws,    \
+                     (unsigned short*)y, HW, C, G, chunks, eps, silu, ald)
   if (dtype == UCE_DTYPE_F16) {
     hipLaunchKernelGGL(k_gn_stats<true>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
                        (const unsigned short*)addend, ws, HW, C, G, chunks, ald);
-    hipLaunchKernelGGL(k_gn_apply<true>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
-                       (const unsigned short*)addend, (const unsigned short*)gamma,
-                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu, ald);
+    if (ntm == 2) UCE_GNA(true, 2); else if (ntm == 1) UCE_GNA(true, 1); else UCE_GNA(true, 0);
   } else {
     hipLaunchKernelGGL(k_gn_stats<false>, grid, block, smem, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
                        (const unsigned short*)addend, ws, HW, C, G, chunks, ald);
-    hipLaunchKernelGGL(k_gn_apply<false>, grid, block, 0, st, (const unsigned short*)x, (const unsigned short*)x2, C1,
-                       (const unsigned short*)addend, (const unsigned short*)gamma,
-                       (const unsigned short*)beta, (const float*)ws, (unsigned short*)y, HW, C, G, chunks, eps, silu, ald);
+    if (ntm == 2) UCE_GNA(false, 2); else if (ntm == 1) UCE_GNA(false, 1); else UCE_GNA(false, 0);
   }
+#undef UCE_GNA
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
