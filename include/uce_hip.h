@@ -187,6 +187,17 @@ int uce_sattn_fwd(uce_handle_t h, const void* q, const void* k, const void* v, v
 int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, float scale, int dtype,
                          uce_stream_t stream);
 
+/* The packed self-attention in the exp2 domain: the q columns of qkv already hold q * scale * log2(e) - written that way by
+ * uce_linear_colscale_fwd (the scale is applied to the f32 product, so q is rounded ONCE, as in the unscaled projection) - and
+ * the softmax numerator is exp2(q' . k - max).  Where uce_sattn_exp2_form(h, B, H, L, dh) returns 1 (dh = 40 on the streaming
+ * two-tile kernel: SD-1.4's 64 x 64 level) the running maximum rides in the head's padding dim and a score leaves the matrix pipe
+ * as the argument of exp2 - no multiply-add per element in a loop that is bound by vector-instruction issue; every other shape
+ * runs its usual kernel with a unit factor.  Same result as uce_sattn_packed_fwd on the unscaled projection up to the rounding
+ * of q' in place of q (diffusers Attention / AttnProcessor2_0 under evalscripts/generate-images-sd.py:37-42). */
+int uce_sattn_exp2_form(uce_handle_t h, int B, int H, int L, int dh);
+int uce_sattn_packed_exp2_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, int dtype,
+                              uce_stream_t stream);
+
 /* SURVEY section 8(f) row 3 - GroupNorm (+ SiLU) of the U-Net / VAE at inference (diffusers ResnetBlock2D:
  * conv(silu(group_norm(x)))) for channels-last activations:  x, y [N, HW, C] (an NCHW tensor in
  * torch.channels_last memory format), gamma, beta [C], all bf16 or f16; G <= 64 groups of C/G consecutive
@@ -271,6 +282,13 @@ int uce_conv3x3_nhwc_fwd(uce_handle_t h, const void* x, const void* w, const voi
 enum { UCE_EPILOGUE_NONE = 0, UCE_EPILOGUE_GEGLU = 1, UCE_EPILOGUE_F32 = 2 };
 int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr,
                    void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream);
+
+/* uce_linear_fwd (no bias, no residual, 16-bit output) whose columns [0, scale_cols) leave multiplied by `scale`:
+ *   y[:, :scale_cols] = scale * (x w^T)[:, :scale_cols],  y[:, scale_cols:] = (x w^T)[:, scale_cols:]
+ * - the f32 accumulator is scaled before the one rounding to the element type.  scale_cols % 32 == 0.  The packed q | k | v
+ * projection of an attn1 layer with scale_cols = H * dh, scale = dh^-0.5 * log2(e) feeds uce_sattn_packed_exp2_fwd. */
+int uce_linear_colscale_fwd(uce_handle_t h, const void* x, long ldx, const void* w, void* y, long ldy, long M, int N, int K,
+                            int scale_cols, float scale, int dtype, uce_stream_t stream);
 
 /* uce_linear_fwd over a two-source contraction: columns [0, K1) of a row of the input come from x (row stride ldx), columns
  * [K1, K) from x2 (row stride ldx2) - the 1x1 conv_shortcut of an up block's ResnetBlock2D reading x and the skip connection in

@@ -486,3 +486,34 @@ def test_linear_few_tile_geglu_two_sources_and_graph_replay(H):
             gr.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, y2)
+
+
+@pytest.mark.parametrize("M,K,N,cols,dtype", [
+    (8192, 320, 960, 320, torch.bfloat16),      # packed q | k | v of the 64 x 64 level, one prompt's CFG pair
+    (65536, 320, 960, 320, torch.bfloat16),     # the many-tile forms
+    (512, 1280, 3840, 1280, torch.bfloat16),    # few tiles: the split-contraction form (the scale follows the slab reduction)
+    (300, 64, 96, 32, torch.float16),           # ragged rows, one scaled MFMA tile
+    (1000, 320, 960, 0, torch.bfloat16),        # no scaled columns: the plain projection
+])
+def test_linear_colscale(H, M, K, N, cols, dtype):
+    """uce_linear_colscale_fwd: columns [0, cols) = round(scale * f32 product) - ONE rounding, checked against the f32 product scaled
+    and rounded by torch; the other columns are bit-equal to uce_linear_fwd's."""
+    g = torch.Generator().manual_seed(M + N)
+    x, w = _rand((M, K), g, dtype), _rand((N, K), g, dtype, 0.05)
+    scale = 40 ** -0.5 * 1.4426950408889634
+    y = H.linear_colscale(x, w, cols, scale)
+    plain = H.linear(x, w)
+    assert torch.equal(y[:, cols:], plain[:, cols:])
+    if cols:
+        f = x.double() @ w.double().T
+        ref = (f[:, :cols] * scale).to(dtype)
+        # f32 accumulation order vs fp64: at most one unit in the last place of the 16-bit result on a few elements
+        d = (y[:, :cols].double() - ref.double()).abs()
+        ulp = ref.double().abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+        # (plus the f32 summation error itself, which is relative to the sum of |terms|, not to a result that cancels)
+        ulp = ulp + 2e-6 * scale * (x.double().abs() @ w.double().abs().T)[:, :cols]
+        assert (d <= ulp).all()
+        assert (d > 0).double().mean() < 0.02
+        # and it is NOT the double rounding round(scale * round(product))
+        twice = (plain[:, :cols].float() * scale).to(dtype)
+        assert (y[:, :cols] != twice).double().mean() > 0.05

@@ -262,3 +262,85 @@ def test_sattn_half_tile_pipeline_both_inline_v_forms(vti, B, H_, Lq, Lk, dh, dt
     ref = _ref_gpu(q, k, v, H_)
     assert O.rel_fro(o.double().cpu(), ref.cpu()) < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16)
     assert torch.equal(o, o1)
+
+
+def _exp2_inputs(B, L, heads, dh, dtype, seed, gain=1.0):
+    """x-free stand-in for the projection: f32 q | k | v, the q columns scaled by dh^-0.5 * log2(e) BEFORE the one rounding."""
+    g = torch.Generator().manual_seed(seed)
+    C = heads * dh
+    f = torch.randn(B, L, 3 * C, generator=g) * gain
+    c = dh ** -0.5 * 1.4426950408889634
+    scaled = f.clone()
+    scaled[..., :C] *= c
+    return f.to(dtype).cuda(), scaled.to(dtype).cuda(), c
+
+
+def _ref_exp2(qkv_scaled, heads):
+    """fp64 softmax in the exp2 domain on the rounded, pre-scaled q: 2^(q'.k) / sum."""
+    B, L, C3 = qkv_scaled.shape
+    C = C3 // 3
+    dh = C // heads
+    sp = lambda t: t.double().view(B, L, heads, dh).transpose(1, 2)
+    q, k, v = (sp(t) for t in qkv_scaled.split(C, dim=-1))
+    s = q @ k.transpose(-1, -2) * 0.6931471805599453                  # exp2(x) = exp(x ln 2)
+    return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, C)
+
+
+@pytest.mark.parametrize("B,L,dtype,gain", [
+    (16, 2048, torch.bfloat16, 1.0),      # 1024 two-tile workgroups: the exp2-domain kernel by rule
+    (4, 2050, torch.bfloat16, 1.0),       # a ragged last key tile (masking) on the same kernel
+    (16, 2048, torch.float16, 1.0),
+    (32, 1024, torch.bfloat16, 5.0),      # peaked logits (q, k x 5): the reference point keeps moving, sc -= d / rescale path
+    (2, 4096, torch.bfloat16, 1.0),       # one prompt's CFG pair at the 64 x 64 level
+])
+def test_sattn_packed_exp2_matches_fp64(H, B, L, dtype, gain):
+    """uce_sattn_packed_exp2_fwd (scores = exp2 arguments straight off the matrix pipe, the running maximum in the head's padding
+    dim) against fp64 on the same pre-scaled q, and against uce_sattn_packed_fwd on the unscaled projection (they differ by the
+    rounding of q' in place of q only)."""
+    heads, dh = 8, 40
+    plain, scaled, _ = _exp2_inputs(B, L, heads, dh, dtype, seed=L + B, gain=gain)
+    assert H.sattn_exp2_form(B, heads, L, dh)
+    o = H.sattn_packed_exp2(scaled, heads)
+    tol = TOL_BF16 if dtype == torch.bfloat16 else TOL_F16
+    assert torch.isfinite(o.float()).all()
+    err = O.rel_fro(o.double().cpu(), _ref_exp2(scaled, heads).cpu())
+    assert err < tol, err
+    # the same attention from the unscaled projection: equal up to the rounding of q (bf16: 2^-9 per element of q, times the logit spread)
+    o2 = H.sattn_packed(plain, heads)
+    assert O.rel_fro(o.double().cpu(), o2.double().cpu()) < (4 if gain > 1 else 2) * tol
+
+
+def test_sattn_packed_exp2_other_shapes_take_the_unit_factor_path(H):
+    """Shapes without the exp2-domain form (another head dim, a short layer) run their usual kernels on the pre-scaled q."""
+    for B, L, heads, dh in ((2, 256, 8, 160), (2, 64, 8, 160), (2, 1024, 8, 80), (1, 300, 4, 40)):
+        assert not H.sattn_exp2_form(B, heads, L, dh)
+        _, scaled, _ = _exp2_inputs(B, L, heads, dh, torch.bfloat16, seed=L)
+        o = H.sattn_packed_exp2(scaled, heads)
+        assert O.rel_fro(o.double().cpu(), _ref_exp2(scaled, heads).cpu()) < TOL_BF16
+
+
+def test_sattn_packed_exp2_two_tile_kernel_small_and_ragged():
+    """The exp2-domain kernel forced at small / ragged shapes (UCE_SATTN_QT=4): one key tile, a single key, Lq off the tile size."""
+    import os
+    from uce_amd import edit as E
+    old = os.environ.get("UCE_SATTN_QT")
+    os.environ["UCE_SATTN_QT"] = "4"
+    try:
+        Hv = E.UceHandle("cuda:0")
+    finally:
+        if old is None:
+            del os.environ["UCE_SATTN_QT"]
+        else:
+            os.environ["UCE_SATTN_QT"] = old
+    try:
+        for B, L, dtype, gain in ((1, 1, torch.bfloat16, 1.0), (2, 33, torch.bfloat16, 1.0), (1, 64, torch.float16, 1.0),
+                                  (3, 130, torch.bfloat16, 4.0), (1, 700, torch.bfloat16, 1.0), (2, 257, torch.float16, 3.0)):
+            assert Hv.sattn_exp2_form(B, 4, L, 40)
+            _, scaled, _ = _exp2_inputs(B, L, 4, 40, dtype, seed=L, gain=gain)
+            o = Hv.sattn_packed_exp2(scaled, 4)
+            assert torch.isfinite(o.float()).all()
+            err = O.rel_fro(o.double().cpu(), _ref_exp2(scaled, 4).cpu())
+            assert err < (TOL_BF16 if dtype == torch.bfloat16 else TOL_F16), (B, L, err)
+    finally:
+        torch.cuda.synchronize()
+        Hv.close()

@@ -201,7 +201,7 @@ static int env_int(const char* name, int dflt) {
 
 extern "C" {
 
-int uce_version(void) { return 113; }
+int uce_version(void) { return 114; }
 
 const char* uce_strerror(int code) {
   switch (code) {

@@ -285,7 +285,8 @@ int uce_ensure_Vt(uce_ctx* h, size_t elems);
 int uce_ensure_sk(uce_ctx* h, size_t bytes, size_t tiles);
 size_t sattn_vt_elems(int B, int H, int Lk, int dh);
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st, int qt_variant = 0, long ld = 0, int vti = 0, float lazy = 8.f);
+                 float scale, int dtype, hipStream_t st, int qt_variant = 0, long ld = 0, int vti = 0, float lazy = 8.f,
+                 bool exp2q = false);
 int launch_xattn(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk,
                  int dh, float scale, int dtype, hipStream_t st, int variant = 1);
 // all keys resident (Lk <= 128), row stride ld of q / k / v: the short self-attention layers

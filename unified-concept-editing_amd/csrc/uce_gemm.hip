@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : ((NST == 4 || BK == 64) ? 2 
                                                   unsigned short* __restrict__ Y, long ldy, long M, int N, int K,
                                                   int mtiles, int ntiles, int outf32,
                                                   const unsigned short* __restrict__ X2, long ldx2, int K1,
-                                                  float* __restrict__ skws, unsigned* __restrict__ sktick, int S) {
+                                                  float* __restrict__ skws, unsigned* __restrict__ sktick, int S,
+                                                  int scols, float cscale) {
   static_assert(WGM * WGN == NW && (NW == 8 || (NW == 4 && BK == 64 && NST == 2)), "waves (the four-wave form: two-stage ring only - its wait counts)");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(BM == 128 || BM == 256, "A image: whole DMA instructions per wave");
@@ -253,6 +254,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : ((NST == 4 || BK == 64) ? 2 
     }
   }
 
+  // uce_linear_colscale_fwd: columns [0, scols) of the product leave multiplied by cscale (scols a multiple of 32: whole MFMA
+  // tiles; the f32 accumulator is scaled, so the element is rounded once) - the q columns of a packed q | k | v projection
+  // carrying scale * log2(e) for the exp2-domain self-attention
+  if (scols > 0) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+      if (n0 + (wn * TN + a) * 32 < scols) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] *= cscale;
+      }
+  }
+
   // ---- epilogue.  Register 4 g + i of tile a = column n0 + (wn TN + a) 32 + 8 g + 4 lh + i, row m0 + (wm TM + b) 32 + li
   if constexpr (WIDE) {
     __builtin_amdgcn_s_barrier();                                      // every wave's tail re-loads have landed: the ring is free
@@ -316,6 +331,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : ((NST == 4 || BK == 64) ? 2 
   }
 }
 
+// the column scale of the call in flight on this thread (uce_linear_colscale_fwd sets it around linear_entry; every other entry
+// point leaves {0, 1}): one kernel signature, no extra parameter through the tile-choice chain
+struct ColScale { int cols; float scale; };
+static thread_local ColScale g_colscale = {0, 1.f};
+
 template <int WGM, int WGN, int TM, int TN, bool F16, bool GEGLU, bool WIDE, int NST, int BK = 32, bool SK = false, int NW = 8>
 int launch_one(const void* x, long ldx, const void* w, const void* bias, const void* res, long ldr, void* y, long ldy, long M, int N,
                int K, hipStream_t st, int outf32 = 0, const void* x2 = nullptr, long ldx2 = 0,
@@ -351,7 +371,8 @@ int launch_one(const void* x, long ldx, const void* w, const void* bias, const v
   }
   hipLaunchKernelGGL((k_gemm_dma<WGM, WGN, TM, TN, F16, GEGLU, WIDE, NST, BK, SK, NW>), dim3((unsigned)nwg), dim3(64 * NW), smem, st, (const unsigned short*)x,
                      ldx, (const unsigned short*)w, (const unsigned short*)bias, (const unsigned short*)res, ldr,
-                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, (const unsigned short*)x2, ldx2, K1, skws, sktick, S);
+                     (unsigned short*)y, ldy, M, N, K, (int)mtiles, ntiles, outf32, (const unsigned short*)x2, ldx2, K1, skws, sktick, S,
+                     g_colscale.cols, g_colscale.scale);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
 }
@@ -492,6 +513,15 @@ static int linear_entry(uce_handle_t h, const void* x, long ldx, const void* w, 
 extern "C" int uce_linear_fwd(uce_handle_t h, const void* x, long ldx, const void* w, const void* bias, const void* residual,
                               long ldr, void* y, long ldy, long M, int N, int K, int epilogue, int dtype, uce_stream_t stream) {
   return linear_entry(h, x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, epilogue, dtype, stream, "uce_linear_fwd");
+}
+
+extern "C" int uce_linear_colscale_fwd(uce_handle_t h, const void* x, long ldx, const void* w, void* y, long ldy, long M, int N,
+                                      int K, int scale_cols, float scale, int dtype, uce_stream_t stream) {
+  if (scale_cols < 0 || scale_cols > N || scale_cols % 32) return UCE_EINVAL;
+  g_colscale = {scale_cols, scale};
+  const int rc = linear_entry(h, x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, UCE_EPILOGUE_NONE, dtype, stream, "uce_linear_colscale_fwd");
+  g_colscale = {0, 1.f};
+  return rc;
 }
 
 extern "C" int uce_linear_cat_fwd(uce_handle_t h, const void* x, long ldx, const void* x2, long ldx2, int K1, const void* w,

@@ -640,7 +640,14 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
 // lane l the column l & 15.  Replaces the inline transpose's eight 2-byte scattered stores per 16-byte chunk (LDS bank conflicts on
 // 0.32 of the LDS cycles, profiles/r04/session2_sattn_h_pmc_sq.txt).  The 192-byte row stride puts the four key rows of a
 // 32-lane half on four disjoint 16-bank sets ((a / 4) % 64: 0, 48, 32, 16); the ones column (dim DVP - 1) replaces the ones row.
-template <int DHP, bool F16, bool VTI, bool VTR = false>
+// REL (exp2-domain scores; launched for dh = DHP - 8 only): Q arrives carrying scale * log2(e) already - from the epilogue of the
+// projection that produced it (uce_linear_colscale_fwd: ONE rounding of the f32 product, so nothing is lost against rounding q and
+// scaling the f32 score) - and the head's first padding dim holds 1.0 on the K side and minus the running maximum on the Q side:
+// a score leaves the matrix pipe as the ARGUMENT of exp2, no v_fma_f32 per element in the softmax (the loop is bound by VALU
+// issue).  The maximum is only a reference point (O and the denominator are formed with the same one): it is kept rounded to the
+// element type, so its product with 1.0 is exact.  (Round 6 built this with the scale applied to the bf16 Q fragments inside the
+// kernel - a second rounding of q: 2.3e-3 -> 3.0e-3 against fp64, retired; the scale belongs in the producer.)
+template <int DHP, bool F16, bool VTI, bool VTR = false, bool REL = false>
 __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                  int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
@@ -657,6 +664,8 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;
   static_assert(!VTR || VTI, "the transposing reads replace the inline transpose");
   constexpr int VRS = 96;                                              // VTR: elements per key row of V (64 dims + 32: see above)
+  // REL: the Q-side slot of dim dh = DHP - 8 - fragment QSS, first element, in the lanes of half QSH
+  constexpr int QSS = (DHP - 8) / 16, QSH = ((DHP - 8) / 8) & 1;
   constexpr int KB = KT * KLD, VB = VTR ? KT * VRS : DVP * VLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Kbuf = (unsigned short*)smem_raw;                  // [3][KB]
@@ -689,11 +698,13 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   // out-of-range offset - both come back as zeros.  (As plain global loads the same tile took ~50 vector instructions of address
   // work, zero fills and 12 exec-mask branches per wave and key tile - a tenth of the loop's VALU issue.)
   unsigned kv_off[NKL];
+  unsigned k_one[NKL];                        // REL: the 1.0 that meets -max on the Q side, OR-ed into the (zero) chunk of dim dh on its way to LDS
 #pragma unroll
   for (int i = 0; i < NKL; ++i) {
     const int e = tid + 256 * i;
     const int key = e / KCH, dim = (e - key * KCH) * 8;
     kv_off[i] = (e < KT * KCH && dim < dh) ? (unsigned)(((long)key * ld + dim) * 2) : 0x80000000u;
+    k_one[i] = (REL && e < KT * KCH && dim == dh) ? (unsigned)one : 0u;
   }
   auto tile_rsrc = [&](const unsigned short* base, int t) {
     const long left = ((long)(Lk - t * KT - 1) * ld + dh) * 2;         // bytes up to the end of the last key's head slice
@@ -726,6 +737,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
     for (int i = 0; i < NKL; ++i) {
       const int e = tid + 256 * i;
       const int key = e / KCH, dim = (e - key * KCH) * 8;
+      if constexpr (REL) rk[i][0] |= k_one[i];
       if (e < KT * KCH) *(uint4_t*)(Ks + key * KLD + dim) = rk[i];
     }
   };
@@ -873,17 +885,42 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (__any(mt[0] > m[0] + lazy_raw || mt[1] > m[1] + lazy_raw)) {  // lazy running maximum: see k_sattn
+    if constexpr (REL) {
+      // sc is relative to mc already (exp2 domain): it was formed with the reference of the previous sub-step.  Lazy running
+      // maximum as in k_sattn; the first half always moves it (mc starts at 0, whatever the scores are), in either direction.
+      // A move corrects this half's scores (sc -= d) and rewrites the Q-side slot, so the S^T of the next half - issued in the
+      // tail below - is formed against the new reference.
+      if (__any(mt[0] > lazy || mt[1] > lazy) || hh == 0) {
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const float m_new = fmaxf(m[x], mt[x]);
-        const float alpha = __builtin_amdgcn_exp2f((m[x] - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first half
-        m[x] = m_new;
-        mc[x] = m_new * scale_log2e;
+        for (int x = 0; x < 2; ++x) {
+          const float want = mc[x] + (hh == 0 ? mt[x] : fmaxf(mt[x], 0.f));
+          const unsigned nb = pack2<F16>(-want, 0.f) & 0xffffu;               // -max, rounded to the element type
+          const float m_new = F16 ? -(float)__builtin_bit_cast(f16x2_t, nb)[0] : -__builtin_bit_cast(float, nb << 16);
+          const float d = m_new - mc[x];
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          mc[x] = m_new;
+          if (lh == QSH) qf[x][QSS][0] = (qf[x][QSS][0] & 0xffff0000u) | nb;
 #pragma unroll
-        for (int nt = 0; nt < NDV; ++nt)
+          for (int r = 0; r < 16; ++r) sc[x][r] -= d;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[x][nt][r] *= alpha;
+          for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[x][nt][r] *= alpha;
+        }
+      }
+    } else {
+      if (__any(mt[0] > m[0] + lazy_raw || mt[1] > m[1] + lazy_raw)) {  // lazy running maximum: see k_sattn
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const float m_new = fmaxf(m[x], mt[x]);
+          const float alpha = __builtin_amdgcn_exp2f((m[x] - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first half
+          m[x] = m_new;
+          mc[x] = m_new * scale_log2e;
+#pragma unroll
+          for (int nt = 0; nt < NDV; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[x][nt][r] *= alpha;
+        }
       }
     }
   };
@@ -908,8 +945,8 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
 #pragma unroll
         for (int p = i * PPC; p < (i + 1) * PPC && p < 16; ++p) {
           const int x = p >> 3, r0 = 2 * (p & 7);
-          const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[x][r0], scale_log2e, -mc[x]));
-          const float e1 = __builtin_amdgcn_exp2f(fmaf(sc[x][r0 + 1], scale_log2e, -mc[x]));
+          const float e0 = __builtin_amdgcn_exp2f(REL ? sc[x][r0] : fmaf(sc[x][r0], scale_log2e, -mc[x]));
+          const float e1 = __builtin_amdgcn_exp2f(REL ? sc[x][r0 + 1] : fmaf(sc[x][r0 + 1], scale_log2e, -mc[x]));
           pf[x][r0 >> 3][(r0 & 7) >> 1] = pack2<F16>(e0, e1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -986,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_h(const unsigned short* __rest
   }
 }
 
-template <int DHP, bool VTI, bool VTR = false>
+template <int DHP, bool VTI, bool VTR = false, bool REL = false>
 int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                  float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 255) / 256, H, B);
@@ -996,15 +1033,15 @@ int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, i
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, true, VTI, VTR, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_h<DHP, false, VTI, VTR, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_h<DHP, true, VTI, VTR, REL>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
-    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_h<DHP, false, VTI, VTR, REL>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -1075,13 +1112,15 @@ static bool sattn_use_h(int qt_variant, int dh, int Lq, int Lk, int H, int B) {
 // the kernel for one shape, with (VTI) or without the V^T pre-pass already run
 template <bool VTI>
 int launch_body(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh, float scale,
-                int dtype, hipStream_t st, int qt_variant, long ld, float lazy, int vti = 0) {
+                int dtype, hipStream_t st, int qt_variant, long ld, float lazy, int vti = 0, bool exp2q = false) {
   // measured on MI355X at the generation batch (B = 32, H = 8; us per launch, k_sattn QT = 1 | QT = 2 | k_sattn_p):
   //   L = 4096, dh = 40:  1691 | 1576 | 1788   (the pipelined form drops from 3 to 2 waves per SIMD at dh = 40 and loses)
   //   L = 1024, dh = 80:   212 |  -   |  197   (two waves per SIMD either way: the pipeline wins)
   if (sattn_use_h(qt_variant, dh, Lq, Lk, H, B)) {
     // inline V: row-major in LDS + transposing reads (UCE_SATTN_VTI = 0 / 3), or transposed on the way in (= 1)
     if constexpr (VTI) {
+      // q already carries scale * log2(e) (uce_sattn_packed_exp2_fwd): the exp2-domain form where the head has a padding dim to spare
+      if (exp2q && dh == 40 && vti != 1) return launch_cfg_h<48, true, true, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
       if (vti != 1) return launch_cfg_h<48, true, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
     }
     return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
@@ -1129,12 +1168,12 @@ constexpr float SATTN_LAZY = 8.f;
 constexpr int SATTN_SHORT_KEYS = 128;
 
 int launch_sattn(const void* q, const void* k, const void* v, void* vt, void* o, int B, int H, int Lq, int Lk, int dh,
-                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, float lazy) {
+                 float scale, int dtype, hipStream_t st, int qt_variant, long ld, int vti, float lazy, bool exp2q) {
   const int LkP = (Lk + KT - 1) / KT * KT;
   if (ld <= 0) ld = (long)H * dh;
   // at most 128 keys: every key resident, plain softmax - k_xattn's form (uce_xattn.hip); UCE_SATTN_QT != 0 keeps the streaming kernels
   if (qt_variant == 0 && Lk <= SATTN_SHORT_KEYS) return launch_xattn_short_self(q, k, v, o, B, H, Lq, Lk, dh, scale, dtype, st, ld);
-  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy, vti);
+  if (sattn_inline_vt(Lk, vti, sattn_use_h(qt_variant, dh, Lq, Lk, H, B))) return launch_body<true>(q, k, v, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, qt_variant, ld, lazy, vti, exp2q);
   const int DVP = sattn_dvp(dh);
   const int ones_row = dh < DVP ? DVP - 1 : -1;
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
@@ -1179,4 +1218,31 @@ extern "C" int uce_sattn_packed_fwd(uce_handle_t h, const void* qkv, void* o, in
   UceProfScope ps(h, "uce_sattn_packed_fwd", (hipStream_t)stream);
   return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, scale, dtype, (hipStream_t)stream, h->sw.sattn_qt, 3 * C,
                       h->sw.sattn_vti, SATTN_LAZY);
+}
+
+// exp2-domain self-attention on a packed projection whose q columns already carry scale * log2(e) (uce_linear_colscale_fwd wrote them):
+// softmax numerator = exp2(q' . k - max).  Where the head has a padding dim to spare and the two-tile streaming kernel runs (dh = 40
+// at SD-1.4's 64 x 64 level) the scores leave the matrix pipe as the argument of exp2 (k_sattn_h<.., REL>); every other shape takes
+// its usual kernel with a unit factor in place of scale * log2(e) - the same arithmetic, one multiplication by 1.0 per score.
+extern "C" int uce_sattn_exp2_form(uce_handle_t h, int B, int H, int L, int dh) {
+  if (!h || B <= 0 || H <= 0 || L <= 0) return 0;
+  const int qt = h->sw.sattn_qt;                                       // (4 = the two-tile kernel at every shape: tests)
+  return dh == 40 && (qt == 4 || (qt == 0 && L > SATTN_SHORT_KEYS)) && h->sw.sattn_vti != 1 && h->sw.sattn_vti != 2 &&
+         sattn_use_h(qt, dh, L, L, H, B);
+}
+
+extern "C" int uce_sattn_packed_exp2_fwd(uce_handle_t h, const void* qkv, void* o, int B, int H, int L, int dh, int dtype,
+                                         uce_stream_t stream) {
+  const unsigned short* p = (const unsigned short*)qkv;
+  const long C = (long)H * dh;
+  if (const int rc = sattn_check(h, p, p, p, o, B, H, L, L, dh, dtype)) return rc;
+  UCE_ENTER(h);
+  if (!sattn_inline_vt(L, h->sw.sattn_vti, sattn_use_h(h->sw.sattn_qt, dh, L, L, H, B))) {
+    const int rc = uce_ensure_Vt(h, sattn_vt_elems(B, H, L, dh));
+    if (rc) return rc;
+  }
+  UceProfScope ps(h, "uce_sattn_packed_exp2_fwd", (hipStream_t)stream);
+  // scale = 1 / log2(e): the kernels multiply it by log2(e) again - a unit factor (0.6931471805599453 * 1.4426950408889634 rounds to 1.0f)
+  return launch_sattn(p, p + C, p + 2 * C, h->Vt, o, B, H, L, L, dh, 0.6931471805599453f, dtype, (hipStream_t)stream, h->sw.sattn_qt,
+                      3 * C, h->sw.sattn_vti, SATTN_LAZY, true);
 }

@@ -269,6 +269,36 @@ class UceHandle:
                                                  _stream_ptr(self.device)), "uce_sattn_packed_fwd")
         return out
 
+    LOG2E = 1.4426950408889634
+
+    def sattn_exp2_form(self, B: int, heads: int, L: int, dh: int) -> bool:
+        """True where uce_sattn_packed_exp2_fwd has its own kernel form for the shape (scores leave the matrix pipe as exp2's argument)."""
+        return bool(self.lib.uce_sattn_exp2_form(self._h, B, heads, L, dh))
+
+    def linear_colscale(self, x: torch.Tensor, weight: torch.Tensor, scale_cols: int, scale: float) -> torch.Tensor:
+        """`x @ weight.T` with columns [0, scale_cols) multiplied by `scale` in the f32 accumulator (uce_linear_colscale_fwd)."""
+        K, N = x.shape[-1], weight.shape[0]
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[x.dtype]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.uce_linear_colscale_fwd(self._h, _ptr(x2), x2.stride(0), _ptr(w), _ptr(y), N, x2.shape[0], N, K,
+                                                    int(scale_cols), float(scale), dt, _stream_ptr(self.device)),
+                   "uce_linear_colscale_fwd")
+        return y
+
+    def sattn_packed_exp2(self, qkv: torch.Tensor, heads: int) -> torch.Tensor:
+        """Self-attention on a packed projection whose q columns carry dh^-0.5 * log2(e) (linear_colscale) -> [B, L, C]."""
+        B, Lq, C3 = qkv.shape
+        Cc = C3 // 3
+        dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}[qkv.dtype]
+        out = torch.empty(B, Lq, Cc, dtype=qkv.dtype, device=qkv.device)
+        _lib.check(self.lib.uce_sattn_packed_exp2_fwd(self._h, _ptr(qkv), _ptr(out), B, heads, Lq, Cc // heads, dt,
+                                                      _stream_ptr(self.device)), "uce_sattn_packed_exp2_fwd")
+        return out
+
     def groupnorm_nhwc(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float,
                        silu: bool, addend: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """GroupNorm (+ SiLU) of a channels-last [N, C, H, W] tensor through uce_groupnorm_nhwc_fwd; `addend` [N, C]

@@ -44,6 +44,8 @@ SIGNATURES = {
     "uce_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "uce_sattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "uce_sattn_packed_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "uce_sattn_exp2_form": (_i, [_vp, _i, _i, _i, _i]),
+    "uce_sattn_packed_exp2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "uce_groupnorm_chunks": (_i, [_i]),
     "uce_groupnorm_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _l, _vp]),
     "uce_groupnorm_cat_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _l, _vp]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "uce_im2col3x3_c4": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "uce_conv3x3_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "uce_linear_fwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp]),
+    "uce_linear_colscale_fwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _f, _i, _vp]),
     "uce_linear_cat_fwd": (_i, [_vp, _vp, _l, _vp, _l, _i, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp]),
     "uce_softmax_rows": (_i, [_vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     "uce_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),

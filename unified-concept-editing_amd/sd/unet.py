@@ -478,7 +478,15 @@ class Attention(nn.Module):
             from .. import edit as _edit
             wq, wk, wv = self.to_q.weight, self.to_k.weight, self.to_v.weight
             wqkv = derived(self, "qkv", _pkey(wq, wk, wv), lambda: torch.cat([wq.detach(), wk.detach(), wv.detach()]).contiguous())
-            o = _edit.UceHandle.get(x.device).sattn_packed(linear_w(x.contiguous(), wqkv), self.heads)
+            handle = _edit.UceHandle.get(x.device)
+            dh = wq.shape[0] // self.heads
+            if handle.sattn_exp2_form(x.shape[0], self.heads, x.shape[1], dh):
+                # the 64 x 64 level: q leaves the projection carrying dh^-0.5 * log2(e) (scaled in the f32 accumulator: one rounding,
+                # as for the plain q) and the attention kernel feeds its scores to exp2 as they leave the matrix pipe
+                qkv = handle.linear_colscale(x.contiguous(), wqkv, wq.shape[0], dh ** -0.5 * handle.LOG2E)
+                o = handle.sattn_packed_exp2(qkv, self.heads)
+            else:
+                o = handle.sattn_packed(linear_w(x.contiguous(), wqkv), self.heads)
             return linear(self.to_out[0], o, residual)
         ctx = x if context is None else context
         q = linear(self.to_q, x)
