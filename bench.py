@@ -475,7 +475,7 @@ def count_generation_flops(pipe, device, steps: int):
         return n
 
     def account(name, a, k):
-        if name == "linear":
+        if name in ("linear", "linear_colscale"):
             x, w = a[0], a[1]
             K = w.shape[1]
             fam["linear"] += 2.0 * (prod(x.shape) // x.shape[-1]) * w.shape[0] * K
@@ -493,7 +493,7 @@ def count_generation_flops(pipe, device, steps: int):
         elif name == "conv3x3_c4":
             x, w = a[0], a[1]
             fam["conv"] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 36 * w.shape[0]
-        elif name == "sattn_packed":
+        elif name in ("sattn_packed", "sattn_packed_exp2"):
             B, L, C3 = a[0].shape
             fam["sattn"] += 4.0 * B * L * L * (C3 // 3)
         elif name == "sattn":
@@ -517,7 +517,8 @@ def count_generation_flops(pipe, device, steps: int):
                 depth[0] -= 1
         setattr(E.UceHandle, name, g)
 
-    names = ("linear", "linear_f32", "conv3x3_nhwc", "conv3x3_igemm", "conv3x3_c4", "sattn_packed", "sattn", "xattn")
+    names = ("linear", "linear_f32", "linear_colscale", "conv3x3_nhwc", "conv3x3_igemm", "conv3x3_c4", "sattn_packed", "sattn_packed_exp2",
+             "sattn", "xattn")
     for n in names:
         wrap(n)
     try:
@@ -924,6 +925,17 @@ def sattn_leg(device, B, iters: int = 10, with_torch: bool = True):
                 time_kernel(lambda: F.scaled_dot_product_attention(sp(qp), sp(kp), sp(v)), iters) * 1e3, 1)
             del qp, kp
         ent["unet_dispatch"] = "uce_sattn_packed_fwd"      # every attn1 layer, whatever its length (sd/unet.py: no library attention)
+        if with_torch and H.sattn_exp2_form(B, 8, L, dh):    # (not in the --only sattn passes: tools/pmc_fold.py counts their launches)
+            # what the U-Net issues for this layer: the packed projection writes q * dh^-0.5 * log2(e) (uce_linear_colscale_fwd, one
+            # rounding) and the attention kernel takes its scores as exp2 arguments.  Timed on the same values (q scaled in f32, then
+            # rounded); tests/test_sattn_gpu.py holds its parity against fp64.
+            c = dh ** -0.5 * 1.4426950408889634
+            qkv = torch.cat([(q.float() * c).bfloat16(), k, v], dim=-1)
+            ms2 = time_kernel(lambda: H.sattn_packed_exp2(qkv, 8), iters)
+            ent["exp2_domain_us"] = round(ms2 * 1e3, 1)
+            ent["exp2_domain_frac"] = round(fl / (ms2 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4)
+            ent["unet_dispatch"] = "uce_linear_colscale_fwd + uce_sattn_packed_exp2_fwd"
+            del qkv
         t = traffic.get(f"B{B}_L{L}_dh{dh}")
         if isinstance(t, dict):
             ent["traffic"] = t.get("total_bytes")

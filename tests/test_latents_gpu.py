@@ -148,6 +148,7 @@ def test_unet_call_at_the_generation_batch_matches_fp32_within_the_per_call_tole
         from uce_amd import edit as E
         calls = {"linear": 0, "conv": 0, "packed": 0}
         orig = (E.UceHandle.linear, E.UceHandle.conv3x3_igemm, E.UceHandle.sattn_packed)
+        orig_exp2 = E.UceHandle.sattn_packed_exp2           # the 64 x 64 level: q pre-scaled by its projection, scores in the exp2 domain
 
         def wrap(name, fn):
             def inner(self, *a, **k):
@@ -156,10 +157,12 @@ def test_unet_call_at_the_generation_batch_matches_fp32_within_the_per_call_tole
             return inner
         E.UceHandle.linear, E.UceHandle.conv3x3_igemm, E.UceHandle.sattn_packed = (wrap("linear", orig[0]), wrap("conv", orig[1]),
                                                                                    wrap("packed", orig[2]))
+        E.UceHandle.sattn_packed_exp2 = wrap("packed", orig_exp2)
         try:
             got = pipe.unet(x.contiguous(memory_format=torch.channels_last), t, ctx.to(dev)).float()
         finally:
             E.UceHandle.linear, E.UceHandle.conv3x3_igemm, E.UceHandle.sattn_packed = orig
+            E.UceHandle.sattn_packed_exp2 = orig_exp2
     finally:
         _set_hip(True)
     assert calls["packed"] >= 15 and calls["linear"] >= 100 and calls["conv"] >= 20, calls     # the own kernels really ran

@@ -40,6 +40,9 @@ def _ref_gpu(q, k, v, heads, scale=None):
     (2, 10, 130, 97, 64, torch.float16),        # f16 path
     (1, 2, 70, 191, 16, torch.bfloat16),        # the tiny test U-Net's head dim
     (1, 3, 50, 65, 96, torch.float16),
+    (32, 8, 256, 256, 160, torch.bfloat16),     # 512 workgroups at dh = 160: the one-LDS-image form, two workgroups per CU
+    (64, 8, 130, 200, 136, torch.float16),      # the same form, ragged both ways, the denominator in V^T's row of ones (dh < 160)
+    (70, 8, 100, 1, 160, torch.bfloat16),       # ... and a single key
 ])
 def test_sattn_shapes(H, B, H_, Lq, Lk, dh, dtype):
     g = torch.Generator().manual_seed(Lq * 7 + dh + Lk)

@@ -131,8 +131,11 @@ __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V
 // VTI: no V^T pre-pass - `Vt` is V itself ([B, Lk, ld] rows like K) and the tile is transposed on its way into LDS (16-byte
 // global loads, eight 2-byte LDS stores per load); the padding rows of the V^T image (and its row of ones) are written once.
 // ld: row stride (elements) of Q, K and V - H * dh for separate tensors, 3 * H * dh for one packed projection.
-template <int DHP, bool F16, int QT, bool VTI>
-__global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
+// NBUF = 1: ONE K / V^T image in LDS (a second barrier per key tile, the next tile still prefetched into registers) under a
+// two-workgroups-per-CU register cap - the dh = 160 layers (16 x 16 level: 4 key tiles per workgroup) ran one wave per SIMD with
+// 86 KB of ring, every global load, barrier and softmax of a tile exposed.
+template <int DHP, bool F16, int QT, bool VTI, int NBUF = 2>
+__global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
                                                unsigned short one, float lazy) {
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   };
   if constexpr (VTI) {
     // rows dh .. DVP - 1 of both V^T images never change: zeros, and ones in the last row when it is a padding row
-    for (int e = tid; e < 2 * (DVP - 0) * KT; e += 256) {
+    for (int e = tid; e < NBUF * (DVP - 0) * KT; e += 256) {
       const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
       const int dv = rem / KT, key = rem - dv * KT;
       if (dv >= dh) smem[buf * BUF + KT * KLD + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
+    const int cur = NBUF == 2 ? (kt & 1) : 0;
     const unsigned short* Ks = smem + cur * BUF;
     const unsigned short* Vs = Ks + KT * KLD;
     if (kt + 1 < ntiles) g_load(kt + 1);
@@ -347,7 +350,10 @@ __global__ __launch_bounds__(256) void k_sattn(const unsigned short* __restrict_
           for (int t = 0; t < QT; ++t) oacc[t][nt] = mfma32<F16>(vf, pf[t][j][s2], oacc[t][nt]);
         }
     }
-    if (kt + 1 < ntiles) s_store(cur ^ 1);
+    if (kt + 1 < ntiles) {
+      if constexpr (NBUF == 1) __syncthreads();    // every wave is done reading the one image
+      s_store(NBUF == 2 ? (cur ^ 1) : 0);
+    }
     __syncthreads();
   }
 
@@ -1072,25 +1078,25 @@ int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, i
   return UCE_OK;
 }
 
-template <int DHP, int QT, bool VTI>
+template <int DHP, int QT, bool VTI, int NBUF = 2>
 int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
-  const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  const size_t smem = (size_t)NBUF * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT, VTI, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT, VTI, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn<DHP, true, QT, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn<DHP, true, QT, VTI, NBUF>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
-    hipLaunchKernelGGL((k_sattn<DHP, false, QT, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn<DHP, false, QT, VTI, NBUF>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -1139,6 +1145,10 @@ int launch_body(const void* q, const void* k, const void* vt, void* o, int B, in
   if (dh <= 80) return launch_cfg<80, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if (dh <= 96) return launch_cfg<96, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   if (dh <= 128) return launch_cfg<128, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  // dh = 160 (the 16 x 16 level): two workgroups per CU on one LDS image each where there are workgroups for it (UCE_SATTN_QT = 1
+  // keeps the two-image form)
+  if (qt_variant == 0 && (long)((Lq + 127) / 128) * H * B >= 512)
+    return launch_cfg<160, 1, VTI, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   return launch_cfg<160, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
 }
 
