@@ -73,6 +73,18 @@ __device__ __forceinline__ float lane_pair_max(float x) {
   return vmax2(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
 
+// maximum of a 64-key tile's 32 scores per lane (two 32 x 32 accumulators), then over the lane pair: 16 v_max3 / v_max as issued
+// + one swap, where fmaxf() over the same values is 32 maxima and 32 canonicalising ones
+__device__ __forceinline__ float tile_max32(const float16_t (&sc)[2]) {
+  float a = vmax3(sc[0][0], sc[0][1], sc[0][2]), b = vmax3(sc[1][0], sc[1][1], sc[1][2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) {
+    a = vmax3(a, sc[0][r], sc[0][r + 1]);
+    b = vmax3(b, sc[1][r], sc[1][r + 1]);
+  }
+  return lane_pair_max(vmax3(vmax2(a, sc[0][15]), b, sc[1][15]));
+}
+
 // (query tile, head, batch) of a workgroup.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
 // its own L2: with the natural order the query tiles of one (batch, head) land on all 8 XCDs and every XCD streams every
 // K / V^T from HBM (PMC: 2.1 GB per launch at L = 4096, B = 32 for 0.34 GB of Q + K + V + O).  Remapped, the workgroups
@@ -294,12 +306,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
     uint4_t pf[QT][2][2];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      float mt = sacc[t][0][0];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][j][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float mt = tile_max32(sacc[t]);
       // LAZY running maximum: raised only when a tile's maximum is more than `lazy` powers of two above it, so exp2's argument
       // stays <= lazy (P <= 2^lazy: the same relative precision in bf16 / f16, f32 sums) and the rescale of O below is rare.  With
       // the exact running maximum SOME lane's maximum moves in almost every tile of a 64-query wave (probability
@@ -430,26 +437,35 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
   const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
   const unsigned short* vbase = VTI ? Vt + (size_t)b * Lk * ld + (size_t)h * dh : Vt + ((size_t)b * H + h) * DVP * LkP;
   uint4_t rk[NKL], rv[NVL];
-  auto g_load_k = [&](int t) {
-    const int key0 = t * KT;
+  // K (and the inline V) tile by buffer loads, as in k_sattn_h: a fixed per-thread byte offset against a descriptor that moves with
+  // the tile; keys >= Lk fall off its end and chunks of dims >= dh carry an out-of-range offset - both come back as zeros
+  unsigned kv_off[NKL];
 #pragma unroll
-    for (int i = 0; i < NKL; ++i) {
-      const int e = tid + 256 * i;
-      const int key = e / KCH, dim = (e - key * KCH) * 8;
-      rk[i] = (uint4_t){0u, 0u, 0u, 0u};
-      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
-    }
+  for (int i = 0; i < NKL; ++i) {
+    const int e = tid + 256 * i;
+    const int key = e / KCH, dim = (e - key * KCH) * 8;
+    kv_off[i] = (e < KT * KCH && dim < dh) ? (unsigned)(((long)key * ld + dim) * 2) : 0x80000000u;
+  }
+  auto tile_rsrc = [&](const unsigned short* base, int t) {
+    const long left = ((long)(Lk - t * KT - 1) * ld + dh) * 2;         // bytes up to the end of the last key's head slice
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)t * KT * ld), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL),
+                                             0x00020000);
+  };
+  auto g_load_k = [&](int t) {
+    const __amdgpu_buffer_rsrc_t r = tile_rsrc(kbase, t);
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) rk[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(r, kv_off[i], 0, 0));
   };
   auto g_load_v = [&](int t) {
-    const int key0 = t * KT;
+    if constexpr (VTI) {
+      const __amdgpu_buffer_rsrc_t r = tile_rsrc(vbase, t);
 #pragma unroll
-    for (int i = 0; i < NVL; ++i) {
-      const int e = tid + 256 * i;
-      if constexpr (VTI) {
-        const int key = e / KCH, dim = (e - key * KCH) * 8;
-        rv[i] = (uint4_t){0u, 0u, 0u, 0u};
-        if (e < KT * KCH && key0 + key < Lk && dim < dh) rv[i] = *(const uint4_t*)(vbase + (size_t)(key0 + key) * ld + dim);
-      } else {
+      for (int i = 0; i < NVL; ++i) rv[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(r, kv_off[i], 0, 0));
+    } else {
+      const int key0 = t * KT;
+#pragma unroll
+      for (int i = 0; i < NVL; ++i) {
+        const int e = tid + 256 * i;
         const int dv = e / VCH, kc = (e - dv * VCH) * 8;
         if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
       }
@@ -549,12 +565,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
           sc[j][r] = (key < Lk) ? sc[j][r] : -INFINITY;
         }
     }
-    float mt = sc[0][0];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[j][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mt = tile_max32(sc);
     const float m_new = (mt > m + lazy_raw) ? mt : m;          // lazy running maximum (see k_sattn)
     const float alpha = __builtin_amdgcn_exp2f((m - m_new) * scale_log2e);
     const float mc = m_new * scale_log2e;
