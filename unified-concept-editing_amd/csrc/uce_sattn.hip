@@ -399,7 +399,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
 // ---------------------------------------------------------------------------------------------
 // (forced to three waves per SIMD at dh = 40 - 168 VGPRs, 22 spilled - it ran 2071 us against 1747 at two waves and 1580 for
 //  k_sattn with two query tiles per wave: measured in round 3, not adopted)
-template <int DHP, bool F16, bool VTI>
+// VTR (with VTI; DVP = 64 or 96): V stays row-major in LDS and the P V fragments come out of ds_read_b64_tr_b16, as in k_sattn_h -
+// three 16-byte stores per thread and tile in place of 24 scattered 2-byte ones.
+template <int DHP, bool F16, bool VTI, bool VTR = false>
 __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                  const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                  int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
@@ -413,9 +415,12 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
   constexpr int NKL = (KT * KCH + 255) / 256;
   constexpr int VCH = KT / 8;
   constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;
+  static_assert(!VTR || (VTI && (DVP == 64 || DVP == 96)), "row-major V: the inline form, key rows 192 bytes apart");
+  constexpr int VRS = 96;                                              // VTR: elements per key row of V (48 banks: see k_sattn_h)
+  constexpr int VB = VTR ? KT * VRS : DVP * VLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Kbuf = (unsigned short*)smem_raw;                  // [2][KT * KLD]
-  unsigned short* Vbuf = Kbuf + 2 * KT * KLD;                        // [2][DVP * VLD]
+  unsigned short* Vbuf = Kbuf + 2 * KT * KLD;                        // [2][VB]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int qx, h, b;
@@ -481,11 +486,14 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
     }
   };
   auto s_store_v = [&](int buf) {
-    unsigned short* Vs = Vbuf + buf * DVP * VLD;
+    unsigned short* Vs = Vbuf + buf * VB;
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      if constexpr (VTI) {
+      if constexpr (VTR) {
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        if (e < KT * KCH && dim < dh) *(uint4_t*)(Vs + key * VRS + dim) = rv[i];
+      } else if constexpr (VTI) {
         const int key = e / KCH, dim = (e - key * KCH) * 8;
         if (e < KT * KCH && dim < dh) {
 #pragma unroll
@@ -503,13 +511,20 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
       }
     }
   };
-  if constexpr (VTI) {
+  if constexpr (VTR) {
+    for (int e = tid; e < 2 * DVP * KT; e += 256) {                    // the padding dims of every key row: zeros, dim DVP - 1 = 1
+      const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
+      const int key = rem / DVP, dv = rem - key * DVP;
+      if (dv >= dh) Vbuf[buf * VB + key * VRS + dv] = (dv == DVP - 1) ? one : (unsigned short)0;
+    }
+  } else if constexpr (VTI) {
     for (int e = tid; e < 2 * DVP * KT; e += 256) {
       const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
       const int dv = rem / KT, key = rem - dv * KT;
-      if (dv >= dh) Vbuf[buf * DVP * VLD + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
+      if (dv >= dh) Vbuf[buf * VB + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
     }
   }
+  const int tr_off = (4 * lh + ((lane & 15) >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   // S^T = K Q^T of the tile in K buffer `buf`
   auto qk = [&](int buf, float16_t (&sacc)[2]) {
     const unsigned short* Ks = Kbuf + buf * KT * KLD;
@@ -595,7 +610,7 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int q = 0; q < 4; ++q) pf[j][s2][q] = pack2<F16>(sc[j][8 * s2 + 2 * q], sc[j][8 * s2 + 2 * q + 1]);
-    const unsigned short* Vs = Vbuf + cur * DVP * VLD;
+    const unsigned short* Vs = Vbuf + cur * VB;
 #pragma unroll
     for (int nt = 0; nt < NDV; ++nt) {
       const unsigned short* vrow = Vs + (nt * 32 + lq) * VLD + 4 * lh;
@@ -603,9 +618,19 @@ __global__ __launch_bounds__(256) void k_sattn_p(const unsigned short* __restric
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const uint2_t lo = *(const uint2_t*)(vrow + j * 32 + 16 * s2);
-          const uint2_t hi = *(const uint2_t*)(vrow + j * 32 + 16 * s2 + 8);
-          const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
+          uint4_t vf;
+          if constexpr (VTR) {                  // keys 32 j + 16 s2 + 4 lh + {0..3, 8..11} of dim 32 nt + lq
+            typedef short v4s_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+            const unsigned short* a = Vs + tr_off + (32 * j + 16 * s2) * VRS + 32 * nt;
+            const uint2_t l2 = __builtin_bit_cast(uint2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)a));
+            const uint2_t h2 = __builtin_bit_cast(uint2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(a + 8 * VRS)));
+            vf = (uint4_t){l2[0], l2[1], h2[0], h2[1]};
+          } else {
+            const uint2_t lo = *(const uint2_t*)(vrow + j * 32 + 16 * s2);
+            const uint2_t hi = *(const uint2_t*)(vrow + j * 32 + 16 * s2 + 8);
+            vf = (uint4_t){lo[0], lo[1], hi[0], hi[1]};
+          }
           oacc[nt] = mfma32<F16>(vf, pf[j][s2], oacc[nt]);
         }
     }
@@ -1065,25 +1090,25 @@ int launch_cfg_h(const void* q, const void* k, const void* vt, void* o, int B, i
 }
 
 
-template <int DHP, bool VTI>
+template <int DHP, bool VTI, bool VTR = false>
 int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                  float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 127) / 128, H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
-  const size_t smem = (size_t)2 * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  const size_t smem = (size_t)2 * (KT * (DHP + 8) + (VTR ? KT * 96 : NDV * 32 * (KT + 4))) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, true, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, false, VTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, true, VTI, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn_p<DHP, false, VTI, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn_p<DHP, true, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_p<DHP, true, VTI, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
-    hipLaunchKernelGGL((k_sattn_p<DHP, false, VTI>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn_p<DHP, false, VTI, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -1143,8 +1168,12 @@ int launch_body(const void* q, const void* k, const void* vt, void* o, int B, in
     return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   }
   if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80)
+  if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80) {
+    if constexpr (VTI) {                        // inline V: row-major + transposing reads unless UCE_SATTN_VTI = 1 asks for the 2-byte stores
+      if (vti != 1) return launch_cfg_p<80, true, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+    }
     return launch_cfg_p<80, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  }
   if (dh <= 48) {
     // two query tiles per wave once there are enough 256-row workgroups to fill the chip twice over
     const long wg2 = (long)((Lq + 255) / 256) * H * B;
