@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void k_vt(const unsigned short* __restrict__ V
 // NBUF = 1: ONE K / V^T image in LDS (a second barrier per key tile, the next tile still prefetched into registers) under a
 // two-workgroups-per-CU register cap - the dh = 160 layers (16 x 16 level: 4 key tiles per workgroup) ran one wave per SIMD with
 // 86 KB of ring, every global load, barrier and softmax of a tile exposed.
-template <int DHP, bool F16, int QT, bool VTI, int NBUF = 2>
+// VTR (with VTI): V row-major in LDS + ds_read_b64_tr_b16 for the P V fragments (k_sattn_h's form); key rows VRS elements apart
+// (a stride of 16 / 48 banks: the four key rows a 32-lane half reads fall on disjoint bank sets).
+template <int DHP, bool F16, int QT, bool VTI, int NBUF = 2, bool VTR = false>
 __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                                const unsigned short* __restrict__ Vt, unsigned short* __restrict__ O,
                                                int H, int Lq, int Lk, int LkP, int dh, float scale_log2e, long ld,
@@ -160,7 +162,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
   constexpr int NKL = (KT * KCH + 255) / 256;     // K chunks per thread per tile
   constexpr int VCH = KT / 8;               // 16-byte chunks per V^T row (8)
   constexpr int NVL = VTI ? NKL : (DVP * VCH + 255) / 256;    // V^T chunks per thread per tile (VTI: chunks of V rows, like K)
-  constexpr int BUF = KT * KLD + DVP * VLD;       // elements per buffer
+  static_assert(!VTR || VTI, "the transposing reads replace the inline transpose");
+  constexpr int VRS = (DVP % 128 == 32 || DVP % 128 == 96) ? DVP : DVP + 32;
+  constexpr int BUF = KT * KLD + (VTR ? KT * VRS : DVP * VLD);       // elements per buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // 2 buffers of BUF elements
   unsigned short* smem = (unsigned short*)smem_raw;
 
@@ -188,23 +192,35 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
   const unsigned short* kbase = K + (size_t)b * Lk * ld + (size_t)h * dh;
   const unsigned short* vbase = VTI ? Vt + (size_t)b * Lk * ld + (size_t)h * dh : Vt + ((size_t)b * H + h) * DVP * LkP;
   uint4_t rk[NKL], rv[NVL];
+  // K (and the inline V) tile by buffer loads (see k_sattn_h): keys >= Lk fall off the descriptor's end, chunks of dims >= dh carry
+  // an out-of-range offset - zeros either way (the padding keys carry P = 0)
+  unsigned kv_off[NKL];
+#pragma unroll
+  for (int i = 0; i < NKL; ++i) {
+    const int e = tid + 256 * i;
+    const int key = e / KCH, dim = (e - key * KCH) * 8;
+    kv_off[i] = (e < KT * KCH && dim < dh) ? (unsigned)(((long)key * ld + dim) * 2) : 0x80000000u;
+  }
+  auto tile_rsrc = [&](const unsigned short* base, int t) {
+    const long left = ((long)(Lk - t * KT - 1) * ld + dh) * 2;         // bytes up to the end of the last key's head slice
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)t * KT * ld), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL),
+                                             0x00020000);
+  };
   auto g_load = [&](int t) {
     const int key0 = t * KT;
+    {
+      const __amdgpu_buffer_rsrc_t r = tile_rsrc(kbase, t);
 #pragma unroll
-    for (int i = 0; i < NKL; ++i) {
-      const int e = tid + 256 * i;
-      const int key = e / KCH, dim = (e - key * KCH) * 8;
-      rk[i] = (uint4_t){0u, 0u, 0u, 0u};
-      if (e < KT * KCH && key0 + key < Lk && dim < dh) rk[i] = *(const uint4_t*)(kbase + (size_t)(key0 + key) * ld + dim);
+      for (int i = 0; i < NKL; ++i) rk[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(r, kv_off[i], 0, 0));
     }
+    if constexpr (VTI) {
+      const __amdgpu_buffer_rsrc_t r = tile_rsrc(vbase, t);
 #pragma unroll
-    for (int i = 0; i < NVL; ++i) {
-      const int e = tid + 256 * i;
-      if constexpr (VTI) {                     // 8 dims of one key (keys >= Lk: zeros, the padding keys carry P = 0)
-        const int key = e / KCH, dim = (e - key * KCH) * 8;
-        rv[i] = (uint4_t){0u, 0u, 0u, 0u};
-        if (e < KT * KCH && key0 + key < Lk && dim < dh) rv[i] = *(const uint4_t*)(vbase + (size_t)(key0 + key) * ld + dim);
-      } else {
+      for (int i = 0; i < NVL; ++i) rv[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(r, kv_off[i], 0, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NVL; ++i) {
+        const int e = tid + 256 * i;
         const int dv = e / VCH, kc = (e - dv * VCH) * 8;
         if (e < DVP * VCH) rv[i] = *(const uint4_t*)(vbase + (size_t)dv * LkP + key0 + kc);   // zero padded by k_vt
       }
@@ -222,7 +238,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int e = tid + 256 * i;
-      if constexpr (VTI) {                     // transposed: element q of the chunk -> row dim + q, column key
+      if constexpr (VTR) {                     // as it arrived: 8 dims of one key
+        const int key = e / KCH, dim = (e - key * KCH) * 8;
+        if (e < KT * KCH && dim < dh) *(uint4_t*)(Vs + key * VRS + dim) = rv[i];
+      } else if constexpr (VTI) {              // transposed: element q of the chunk -> row dim + q, column key
         const int key = e / KCH, dim = (e - key * KCH) * 8;
         if (e < KT * KCH && dim < dh) {
 #pragma unroll
@@ -241,7 +260,13 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
       }
     }
   };
-  if constexpr (VTI) {
+  if constexpr (VTR) {
+    for (int e = tid; e < NBUF * DVP * KT; e += 256) {          // the padding dims of every key row: zeros, dim DVP - 1 = 1
+      const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
+      const int key = rem / DVP, dv = rem - key * DVP;
+      if (dv >= dh) smem[buf * BUF + KT * KLD + key * VRS + dv] = (dv == DVP - 1) ? one : (unsigned short)0;
+    }
+  } else if constexpr (VTI) {
     // rows dh .. DVP - 1 of both V^T images never change: zeros, and ones in the last row when it is a padding row
     for (int e = tid; e < NBUF * (DVP - 0) * KT; e += 256) {
       const int buf = e / (DVP * KT), rem = e - buf * (DVP * KT);
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
       if (dv >= dh) smem[buf * BUF + KT * KLD + dv * VLD + key] = (dv == DVP - 1) ? one : (unsigned short)0;
     }
   }
+  const int tr_off = (4 * lh + ((lane & 15) >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   // dh < DVP: row DVP - 1 of V^T is all ones (k_vt), so O^T's last row IS the running softmax denominator - summed
   // by the matrix core, rescaled with the other rows - and the 32 VALU adds per tile go away.
@@ -350,9 +376,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void k_sattn(const unsigned
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const uint2_t lo = *(const uint2_t*)(vrow + j * 32 + 16 * s2);
-          const uint2_t hi = *(const uint2_t*)(vrow + j * 32 + 16 * s2 + 8);
-          const uint4_t vf = {lo[0], lo[1], hi[0], hi[1]};
+          uint4_t vf;
+          if constexpr (VTR) {                  // keys 32 j + 16 s2 + 4 lh + {0..3, 8..11} of dim 32 nt + lq
+            typedef short v4s_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+            const unsigned short* a = Vs + tr_off + (32 * j + 16 * s2) * VRS + 32 * nt;
+            const uint2_t l2 = __builtin_bit_cast(uint2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)a));
+            const uint2_t h2 = __builtin_bit_cast(uint2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(a + 8 * VRS)));
+            vf = (uint4_t){l2[0], l2[1], h2[0], h2[1]};
+          } else {
+            const uint2_t lo = *(const uint2_t*)(vrow + j * 32 + 16 * s2);
+            const uint2_t hi = *(const uint2_t*)(vrow + j * 32 + 16 * s2 + 8);
+            vf = (uint4_t){lo[0], lo[1], hi[0], hi[1]};
+          }
 #pragma unroll
           for (int t = 0; t < QT; ++t) oacc[t][nt] = mfma32<F16>(vf, pf[t][j][s2], oacc[t][nt]);
         }
@@ -1114,25 +1150,26 @@ int launch_cfg_p(const void* q, const void* k, const void* vt, void* o, int B, i
   return UCE_OK;
 }
 
-template <int DHP, int QT, bool VTI, int NBUF = 2>
+template <int DHP, int QT, bool VTI, int NBUF = 2, bool VTR = false>
 int launch_cfg(const void* q, const void* k, const void* vt, void* o, int B, int H, int Lq, int Lk, int LkP, int dh,
                float scale, int dtype, hipStream_t st, long ld, float lazy) {
   const dim3 grid((Lq + 128 * QT - 1) / (128 * QT), H, B);
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NDV = (DHP + 31) / 32;
-  const size_t smem = (size_t)NBUF * (KT * (DHP + 8) + NDV * 32 * (KT + 4)) * sizeof(unsigned short);
+  constexpr int DVP = NDV * 32, VRS = (DVP % 128 == 32 || DVP % 128 == 96) ? DVP : DVP + 32;
+  const size_t smem = (size_t)NBUF * (KT * (DHP + 8) + (VTR ? KT * VRS : DVP * (KT + 4))) * sizeof(unsigned short);
   const unsigned short one = dtype == UCE_DTYPE_F16 ? 0x3C00 : 0x3F80;
   static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
   if (const int tok = attr_once.first()) {
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT, VTI, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT, VTI, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, true, QT, VTI, NBUF, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UCE_HIP_TRY(hipFuncSetAttribute((const void*)k_sattn<DHP, false, QT, VTI, NBUF, VTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.commit(tok);
   }
   if (dtype == UCE_DTYPE_F16)
-    hipLaunchKernelGGL((k_sattn<DHP, true, QT, VTI, NBUF>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn<DHP, true, QT, VTI, NBUF, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   else
-    hipLaunchKernelGGL((k_sattn<DHP, false, QT, VTI, NBUF>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
+    hipLaunchKernelGGL((k_sattn<DHP, false, QT, VTI, NBUF, VTR>), grid, dim3(256), smem, st, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)vt, (unsigned short*)o, H, Lq, Lk, LkP, dh, sl2, ld, one, lazy);
   UCE_LAUNCH_CHECK();
   return UCE_OK;
@@ -1181,15 +1218,21 @@ int launch_body(const void* q, const void* k, const void* vt, void* o, int B, in
       return launch_cfg<48, 2, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
     return launch_cfg<48, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   }
-  if (dh <= 64) return launch_cfg<64, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  if (dh <= 80) return launch_cfg<80, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  if (dh <= 96) return launch_cfg<96, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  if (dh <= 128) return launch_cfg<128, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  // one query tile per wave; inline V row-major + transposing reads unless UCE_SATTN_VTI = 1 asks for the 2-byte stores
+  constexpr bool R = VTI;
+  const bool tr = R && vti != 1;
+#define UCE_SA1(DHP_, NB_)                                                                                                          \
+  return tr ? launch_cfg<DHP_, 1, VTI, NB_, R>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy)                       \
+            : launch_cfg<DHP_, 1, VTI, NB_>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  if (dh <= 64) { UCE_SA1(64, 2) }
+  if (dh <= 80) { UCE_SA1(80, 2) }
+  if (dh <= 96) { UCE_SA1(96, 2) }
+  if (dh <= 128) { UCE_SA1(128, 2) }
   // dh = 160 (the 16 x 16 level): two workgroups per CU on one LDS image each where there are workgroups for it (UCE_SATTN_QT = 1
   // keeps the two-image form)
-  if (qt_variant == 0 && (long)((Lq + 127) / 128) * H * B >= 512)
-    return launch_cfg<160, 1, VTI, 1>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  return launch_cfg<160, 1, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
+  if (qt_variant == 0 && (long)((Lq + 127) / 128) * H * B >= 512) { UCE_SA1(160, 1) }
+  UCE_SA1(160, 2)
+#undef UCE_SA1
 }
 
 }  // namespace
