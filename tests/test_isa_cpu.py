@@ -39,7 +39,9 @@ def _kernel(asm: str, mangled_part: str) -> list:
 
 
 def _epilogue(lines: list) -> list:
-    last = max(i for i, l in enumerate(lines) if "v_mfma" in l)
+    """Everything behind the main loop in the listing: after the last MFMA AND the last LDS-DMA (block placement may put the
+    loop's staging blocks - with their wave-uniform two-source branch - behind the last MFMA in the text)."""
+    last = max(i for i, l in enumerate(lines) if "v_mfma" in l or (" lds" in l and "buffer_load" in l))
     return lines[last:]
 
 

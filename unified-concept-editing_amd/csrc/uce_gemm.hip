@@ -257,15 +257,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : ((NST == 4 || BK == 64) ? 2 
   // uce_linear_colscale_fwd: columns [0, scols) of the product leave multiplied by cscale (scols a multiple of 32: whole MFMA
   // tiles; the f32 accumulator is scaled, so the element is rounded once) - the q columns of a packed q | k | v projection
   // carrying scale * log2(e) for the exp2-domain self-attention
-  if (scols > 0) {
+  if (scols > 0) {                                                     // (uniform; the factor of a tile is a scalar select: straight-line code)
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
-      if (n0 + (wn * TN + a) * 32 < scols) {
+    for (int a = 0; a < TN; ++a) {
+      const float f = (n0 + (wn * TN + a) * 32 < scols) ? cscale : 1.0f;
 #pragma unroll
-        for (int b = 0; b < TM; ++b)
+      for (int b = 0; b < TM; ++b)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] *= cscale;
-      }
+        for (int r = 0; r < 16; ++r) acc[a][b][r] *= f;
+    }
   }
 
   // ---- epilogue.  Register 4 g + i of tile a = column n0 + (wn TN + a) 32 + 8 g + 4 lh + i, row m0 + (wm TM + b) 32 + li

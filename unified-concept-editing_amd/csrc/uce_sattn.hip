@@ -1205,7 +1205,10 @@ int launch_body(const void* q, const void* k, const void* vt, void* o, int B, in
     return launch_cfg_h<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
   }
   if (qt_variant == 3 && dh <= 48) return launch_cfg_p<48, VTI>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
-  if ((qt_variant == 0 || qt_variant == 3) && dh > 64 && dh <= 80) {
+  // 64 < dh <= 80 (the 32 x 32 level, L = 1024): with the K / V tiles by buffer loads and V row-major in LDS the one-tile kernel needs
+  // 164 VGPRs - THREE workgroups per CU (47 KB of LDS each) - and passes the pipelined one, which holds two tiles' scores and stays at
+  // two: L = 1024 at B = 128 471 against 552 us same box.  The pipelined kernel keeps the V^T pre-pass case and UCE_SATTN_QT = 3.
+  if ((qt_variant == 3 || (qt_variant == 0 && !(VTI && vti != 1))) && dh > 64 && dh <= 80) {
     if constexpr (VTI) {                        // inline V: row-major + transposing reads unless UCE_SATTN_VTI = 1 asks for the 2-byte stores
       if (vti != 1) return launch_cfg_p<80, true, true>(q, k, vt, o, B, H, Lq, Lk, LkP, dh, scale, dtype, st, ld, lazy);
     }
