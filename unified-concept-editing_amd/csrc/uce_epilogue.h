@@ -43,20 +43,25 @@ __device__ __forceinline__ unsigned add2(unsigned a, unsigned b) {       // (a.l
                     tof<F16>((unsigned short)(a >> 16)) + tof<F16>((unsigned short)(b >> 16)));
 }
 
-// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26) on one v_rcp, one v_exp and nine FMAs - the library erff is a branchy
-// ~30-instruction polynomial, and the GEGLU epilogue evaluates it once per output element with nothing to overlap it.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = __builtin_fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  const float r = fmaf(-p * t, e, 1.0f);
-  return __builtin_copysignf(r, x);
+// GELU, erf form (diffusers GEGLU: F.gelu), on ONE transcendental.  With u = |g|:  gelu(g) = max(g, 0) - u h(u),
+//   h(u) = 0.5 erfc(u / sqrt 2) = 2^( P(u) - u^2 log2(e) / 2 ),   P(u) ~ log2(0.5 erfcx(u / sqrt 2))  on [0, 6.25]
+// P: degree 7, Chebyshev fit (tools/fit_gelu.py), the argument clamped at 6.25 (beyond it u h(u) < 3e-9).  Against fp64 over
+// |g| <= 12 in f32 arithmetic: 5.9e-7 absolute, 5.9e-6 relative (bf16 resolves 4e-3, f16 5e-4).  17 VALU issue slots per element
+// (min, 7 FMA, mul, FMA, v_exp_f32 at four, max, FMA, the product with the hidden value) where the Abramowitz-Stegun 7.1.26 form it
+// replaces (a v_rcp_f32 AND a v_exp_f32, nine FMAs, copysign: 1.5e-7 absolute) took 23 - the GEGLU epilogue evaluates it 64 times per
+// lane and tile with no matrix work beside it (one workgroup per CU): ~40 % of the 256 x 256 tile's time at K = 320.
+__device__ __forceinline__ float gelu_erf(float g) {
+  const float u = __builtin_fminf(__builtin_fabsf(g), 6.25f);
+  float p = fmaf(-1.837149047e-06f, u, 6.163556782e-05f);
+  p = fmaf(p, u, -9.307270628e-04f);
+  p = fmaf(p, u, 8.508252472e-03f);
+  p = fmaf(p, u, -5.395976999e-02f);
+  p = fmaf(p, u, 2.628816807e-01f);
+  p = fmaf(p, u, -1.151250035e+00f);
+  p = fmaf(p, u, -9.999953876e-01f);
+  const float h = __builtin_amdgcn_exp2f(fmaf(u * u, -0.72134752044448170f, p));
+  return fmaf(-u, h, __builtin_fmaxf(g, 0.0f));      // (the clamped u: beyond 6.25 the term is < 1.4e-9 either way, and +inf stays +inf)
 }
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erf_as(g * 0.70710678118654752f)); }
 
 // CH: 32-column MFMA tiles parked at once (the row of a slab is CH * 64 bytes, CH * 32 for GEGLU).  CH = TN parks the wave's
 // whole width (fewest passes); CH = 2 keeps the region at 4.5 KB per wave for the two-workgroups-per-CU tile forms.
