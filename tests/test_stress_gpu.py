@@ -230,3 +230,16 @@ def test_edit_and_attention_through_the_address_sanitizer_build(tmp_path):
                     "of the same build run in tests/test_abi_cpu.py")
     assert "AddressSanitizer" not in res.stderr, res.stderr[-3000:]
     assert res.returncode == 0 and "asan gpu child ok" in res.stdout, (res.returncode, res.stdout[-500:], res.stderr[-3000:])
+
+
+def test_random_self_attention_shapes_through_every_kernel_form():
+    """tools/stress_sattn.py (short form): 120 random (batch, heads, head dim, lengths, dtype) through uce_sattn_fwd, the packed and the
+    exp2-domain entry points, on the by-rule handle and on one that forces the two-tile kernel - each against fp64 (the buffer-load
+    tile descriptors, the row-major V image and the one-LDS-image form see every ragged edge here)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_sattn.py"), "120", "5"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0 and "ok: 120 shapes" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
